@@ -1,0 +1,116 @@
+/* mmr.h -- C-ABI of the MI355X-native SynthMorph/VoxelMorph hot path.
+ *
+ * The reference (ivadomed/multimodal-registration) has no FFI: its boundary is
+ * the Python operator surface of voxelmorph/neurite.
+ * Each entry point below names the reference call site whose arithmetic it
+ * replaces; `multimodal-registration_amd/` binds them with ctypes and mirrors
+ * the reference's operator names on top.
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, a negative MMR_E* code otherwise; never throw,
+ *     never allocate or free caller memory; outputs and scratch are
+ *     caller-provided DEVICE pointers (gfx950), NDHWC contiguous;
+ *   - `stream` is a hipStream_t passed as void*; work is only ordered by it;
+ *   - stateless and re-entrant.
+ */
+#ifndef MMR_H
+#define MMR_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMR_OK 0
+#define MMR_EINVAL (-1)     /* bad shape / null pointer / unsupported combination */
+#define MMR_EHIP (-2)       /* HIP launch or runtime error */
+#define MMR_EUNSUPPORTED (-3)
+
+#define MMR_INTERP_LINEAR 0
+#define MMR_INTERP_NEAREST 1
+
+#define MMR_DT_F32 0
+#define MMR_DT_BF16 1
+
+int mmr_version(void);
+const char* mmr_error_string(int code);
+/* last HIP error text recorded by a failing call on this thread */
+const char* mmr_last_hip_error(void);
+
+/* ---- spatial transform ------------------------------------------------- *
+ * vxm.layers.SpatialTransformer / vxm.utils.transform / ne.utils.interpn
+ * (train_synthmorph.py:67,298; 3d_reg.py:331-334,377-380; inside VxmDense).
+ * out[b,x,c] = vol[b, x + flow[b,x,:], c]; voxel units, 'ij'; clamp-to-edge;
+ * if has_fill, positions with a coordinate <0 or >max get `fill`.
+ * flow: [B,X,Y,Z,3], or [B,X,Y,Z,C,3] when channelwise != 0.             */
+int mmr_warp3d_f32(const float* vol, const float* flow, float* out,
+                   int B, int X, int Y, int Z, int C,
+                   int interp, int has_fill, float fill, int channelwise, void* stream);
+/* nearest-neighbour label resampling, bit-exact (labels_to_image warp). */
+int mmr_warp3d_nearest_u8(const uint8_t* vol, const float* flow, uint8_t* out,
+                          int B, int X, int Y, int Z, int C,
+                          int has_fill, uint8_t fill, void* stream);
+
+/* ne.utils.resize + vxm RescaleTransform (inside VxmDense; 3d_reg.py:394):
+ * align-corners trilinear from (X,Y,Z) to (Xo,Yo,Zo), values times `mul`.
+ * pre_scale!=0 multiplies before interpolating (factor>1 branch).          */
+int mmr_resize_trilinear_f32(const float* in, float* out, int B, int X, int Y, int Z, int C,
+                             int Xo, int Yo, int Zo, float mul, int pre_scale, void* stream);
+
+/* vxm.utils.compose([A,B]) (bids_two_steps_registration.py:324):
+ * out = B + A o (id + B). Also one scaling-and-squaring step when a == b. */
+int mmr_compose_f32(const float* a, const float* b, float* out,
+                    int B, int X, int Y, int Z, void* stream);
+
+/* vxm.layers.VecInt('ss', int_steps) (config.json:41): out = integrate(vel).
+ * `tmp` is scratch of the same size as vel; vel is not modified.           */
+int mmr_vecint_f32(const float* vel, float* out, float* tmp,
+                   int B, int X, int Y, int Z, int nsteps, void* stream);
+
+/* ---- U-Net ------------------------------------------------------------- *
+ * Conv3D(nf,3,'same')+bias(+LeakyReLU) of VxmDense's U-Net
+ * (train_synthmorph.py:296; 3d_reg.py:305).  Implicit GEMM on MFMA.
+ * Weights are first re-packed from the Keras layout [3][3][3][Cin][Cout]
+ * (fp32, device) into the kernel's tap-major MFMA operand image.           */
+int64_t mmr_conv3d_k3_packed_bytes(int Cin, int Cout, int dtype);
+int mmr_conv3d_k3_pack(const float* w_keras, void* w_packed, int Cin, int Cout, int dtype,
+                       int transpose_flip, void* stream);
+/* in0: [B,X0,Y0,Z0,C0] (if up0: at half resolution, nearest-upsampled on the
+ * fly = UpSampling3D(2)); in1: optional skip [B,X,Y,Z,C1] concatenated AFTER
+ * in0's channels (= concatenate([upsampled, skip])).  dtype selects element
+ * type of in0/in1/w_packed/out (bf16 in, fp32 accumulate, or exact fp32).
+ * out_f32 != 0 stores fp32 output even for the bf16 path.
+ * pool_out: optional MaxPooling3D(2) of the activated output, fused.       */
+int mmr_conv3d_k3_fwd(const void* in0, int C0, int up0, const void* in1, int C1,
+                      const void* w_packed, const float* bias, void* out, void* pool_out,
+                      int B, int X, int Y, int Z, int Cout,
+                      int leaky, float alpha, int dtype, int out_f32, void* stream);
+/* First layer: concatenate([moving, fixed]) (2 x 1 channel, fp32) -> Cout. */
+int mmr_conv3d_k3_cin2_fwd(const float* src, const float* trg, const float* w_keras, const float* bias,
+                           void* out, void* pool_out, int B, int X, int Y, int Z, int Cout,
+                           int leaky, float alpha, int out_dtype, void* stream);
+int mmr_maxpool3d2_fwd(const void* in, void* out, int B, int X, int Y, int Z, int C, int dtype, void* stream);
+
+/* ---- losses ------------------------------------------------------------ *
+ * vxm.losses.Dice().loss (train_synthmorph.py:306). ws: >= mmr_dice_ws_bytes.
+ * loss_out[0] = -mean_{b,l} divide_no_nan(2 sum(t p), sum(t + p)).         */
+int64_t mmr_dice_ws_bytes(int B, int64_t nvox, int L);
+int mmr_dice_fwd_f32(const float* y_true, const float* y_pred, float* loss_out, float* top_bot,
+                     void* ws, int B, int64_t nvox, int L, void* stream);
+/* vxm.losses.Grad('l2', loss_mult).loss(None, flow) (train_synthmorph.py:307) -> out[B]. */
+int64_t mmr_grad_l2_ws_bytes(int B, int X, int Y, int Z, int C);
+int mmr_grad_l2_fwd_f32(const float* flow, float* out, void* ws,
+                        int B, int X, int Y, int Z, int C, float loss_mult, void* stream);
+/* vxm.losses.NCC(win) (BASELINE.json config 5; no reference call site) -> out[B]. */
+int64_t mmr_ncc_ws_bytes(int B, int X, int Y, int Z);
+int mmr_ncc_fwd_f32(const float* I, const float* J, float* out, void* ws,
+                    int B, int X, int Y, int Z, int win, float eps, void* stream);
+/* bending energy of a displacement field (config 5) -> out[B]. */
+int64_t mmr_bending_ws_bytes(int B, int X, int Y, int Z);
+int mmr_bending_fwd_f32(const float* flow, float* out, void* ws,
+                        int B, int X, int Y, int Z, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMR_H */

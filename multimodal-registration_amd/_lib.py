@@ -1,0 +1,80 @@
+"""ctypes binding of the C-ABI declared in include/mmr.h.
+
+There is no CPU fallback: loading fails loudly when libmmr_hip.so is missing,
+and every entry point raises ``MmrError`` on a non-zero return code.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_uint8, c_void_p
+
+from . import build as _build
+
+_LIB = None
+
+P = c_void_p
+I = c_int
+F = c_float
+
+# name -> (restype, argtypes); mirrors include/mmr.h one to one
+SIGNATURES = {
+    "mmr_version": (I, []),
+    "mmr_error_string": (ctypes.c_char_p, [I]),
+    "mmr_last_hip_error": (ctypes.c_char_p, []),
+    "mmr_warp3d_f32": (I, [P, P, P, I, I, I, I, I, I, I, F, I, P]),
+    "mmr_warp3d_nearest_u8": (I, [P, P, P, I, I, I, I, I, I, c_uint8, P]),
+    "mmr_resize_trilinear_f32": (I, [P, P, I, I, I, I, I, I, I, I, F, I, P]),
+    "mmr_compose_f32": (I, [P, P, P, I, I, I, I, P]),
+    "mmr_vecint_f32": (I, [P, P, P, I, I, I, I, I, P]),
+    "mmr_conv3d_k3_packed_bytes": (c_int64, [I, I, I]),
+    "mmr_conv3d_k3_pack": (I, [P, P, I, I, I, I, P]),
+    "mmr_conv3d_k3_fwd": (I, [P, I, I, P, I, P, P, P, P, I, I, I, I, I, I, F, I, I, P]),
+    "mmr_conv3d_k3_cin2_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, F, I, P]),
+    "mmr_maxpool3d2_fwd": (I, [P, P, I, I, I, I, I, I, P]),
+    "mmr_dice_ws_bytes": (c_int64, [I, c_int64, I]),
+    "mmr_dice_fwd_f32": (I, [P, P, P, P, P, I, c_int64, I, P]),
+    "mmr_grad_l2_ws_bytes": (c_int64, [I, I, I, I, I]),
+    "mmr_grad_l2_fwd_f32": (I, [P, P, P, I, I, I, I, I, F, P]),
+    "mmr_ncc_ws_bytes": (c_int64, [I, I, I, I]),
+    "mmr_ncc_fwd_f32": (I, [P, P, P, P, I, I, I, I, I, F, P]),
+    "mmr_bending_ws_bytes": (c_int64, [I, I, I, I]),
+    "mmr_bending_fwd_f32": (I, [P, P, P, I, I, I, I, P]),
+}
+
+
+class MmrError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Load libmmr_hip.so (building it first if sources are newer and hipcc exists)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        try:
+            _build.build()
+        except Exception as e:  # no silent fallback
+            raise MmrError(f"libmmr_hip.so is missing and could not be built: {e}") from e
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise MmrError(f"{path} does not export {name}; rebuild with __graft_entry__.build()") from e
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        lib = load()
+        msg = lib.mmr_error_string(int(rc)).decode()
+        hip = lib.mmr_last_hip_error().decode()
+        raise MmrError(f"{what} failed: {msg}" + (f" [{hip}]" if rc == -2 and hip else ""))

@@ -1,0 +1,500 @@
+// Conv3D(k=3,'same',stride 1) + bias + LeakyReLU for VxmDense's U-Net as an
+// implicit GEMM on the gfx950 matrix cores (reference call sites:
+// train_synthmorph.py:296, 3d_reg.py:305; semantics SURVEY.md Appendix A1).
+//
+//   M = output voxels (a 4x8x8 tile = 256 rows per workgroup)
+//   N = Cout tile (BN = 32*WN*NT)
+//   K = 27 taps x Cin, walked as  slice (128 B of channels) -> tap -> k-step
+//
+// Data movement per workgroup (512 threads = 8 waves, 1 workgroup / CU):
+//   * A: the haloed input tile (6x10x10 voxels x 128 B of channels) is staged
+//     ONCE per channel slice into LDS (rows padded to 144 B so that b128
+//     fragment reads of consecutive voxels spread over the banks); all 27 taps
+//     read it with a constant per-tap address offset -> every input byte is
+//     fetched from L2/HBM 2.3x (halo) instead of 27x.  The loader folds
+//     UpSampling3D(2) (nearest) and the skip concatenation, so neither tensor
+//     is ever materialised.
+//   * B: weights are pre-packed (mmr_conv3d_k3_pack) into the exact LDS image
+//     [tile][slice][tap][16B-chunk][cout][16 B]; each tap's BN x 128 B block is
+//     streamed with global_load_lds (LDS-DMA, 16 B/lane) into a double buffer
+//     while the previous tap computes.
+//   * MFMA: bf16 -> v_mfma_f32_32x32x16_bf16 (fp32 accumulate);
+//           fp32 -> v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain).
+//     Both element types share the byte-level layout (a 16 B chunk = 8 bf16 or
+//     4 fp32 consecutive input channels), so one kernel template serves both.
+#include "common.hpp"
+
+namespace mmr {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int TX = 4, TY = 8, TZ = 8;                 // output tile
+constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2;  // halo tile
+constexpr int HROWS = HX * HY * HZ;                   // 600
+constexpr int ROWB = 144;                             // 128 B of channels + 16 B pad
+constexpr int A_BYTES = HROWS * ROWB;                 // 86400
+constexpr int CONV_THREADS = 512;
+
+struct ConvParams {
+    const char* in0;
+    const char* in1;
+    const char* wp;
+    const float* bias;
+    char* out;
+    int B, X, Y, Z;
+    int C0, C1, up0;
+    int Cout;  // real output channels (row stride of out)
+    int leaky;
+    float alpha;
+    int out_f32;
+    int ntx, nty, ntz;
+};
+
+template <int DT> struct Elt;
+template <> struct Elt<MMR_DT_BF16> { static constexpr int size = 2; static constexpr int kc = 64; };
+template <> struct Elt<MMR_DT_F32> { static constexpr int size = 4; static constexpr int kc = 32; };
+
+__device__ __forceinline__ void glds16(const char* g, char* l)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int DT, int WM, int WN, int MT, int NT>
+__global__ void __launch_bounds__(CONV_THREADS, 2)
+conv3d_k3_kernel(const ConvParams p)
+{
+    static_assert(WM * WN == 8, "8 waves");
+    static_assert(WM * MT * 32 == TX * TY * TZ, "M tile");
+    constexpr int BN = WN * NT * 32;
+    constexpr int ES = Elt<DT>::size;
+    constexpr int KC = Elt<DT>::kc;
+    constexpr int B_BYTES = BN * 128;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;
+    char* sB = smem + A_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    int bid = blockIdx.x;
+    const int tzi = bid % p.ntz; bid /= p.ntz;
+    const int tyi = bid % p.nty; bid /= p.nty;
+    const int txi = bid % p.ntx;
+    const int b = bid / p.ntx;
+    const int x0 = txi * TX, y0 = tyi * TY, z0 = tzi * TZ;
+    const int ntile = blockIdx.y;
+
+    int a_off[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int v = (wm * MT + m) * 32 + (lane & 31);
+        const int vx = v >> 6, vy = (v >> 3) & 7, vz = v & 7;
+        a_off[m] = ((vx * HY + vy) * HZ + vz) * ROWB + (lane >> 5) * 16;
+    }
+    int b_off[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) b_off[n] = (((lane >> 5) * BN) + (wn * NT + n) * 32 + (lane & 31)) * 16;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const int nslices = (p.C0 + p.C1) / KC;
+    const char* wtile = p.wp + (size_t)ntile * nslices * 27 * B_BYTES;
+    const int X2 = p.X >> 1, Y2 = p.Y >> 1, Z2 = p.Z >> 1;
+
+    int cur = 0;
+    for (int s = 0; s < nslices; ++s) {
+        __syncthreads();  // previous slice fully consumed
+        // ---- stage the haloed A tile for this channel slice ----
+        {
+            const int ch0 = s * KC;
+            const bool first = ch0 < p.C0;
+            const char* src = first ? p.in0 : p.in1;
+            const int Cs = first ? p.C0 : p.C1;
+            const int chs = first ? ch0 : ch0 - p.C0;
+            const bool up = first && p.up0;
+            for (int i = tid; i < HROWS * 8; i += CONV_THREADS) {
+                const int row = i >> 3, chunk = i & 7;
+                const int hx = row / (HY * HZ), hy = (row / HZ) % HY, hz = row % HZ;
+                const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
+                uint4 val = make_uint4(0, 0, 0, 0);
+                if (gx >= 0 && gx < p.X && gy >= 0 && gy < p.Y && gz >= 0 && gz < p.Z) {
+                    size_t vox;
+                    if (up) vox = (((size_t)b * X2 + (gx >> 1)) * Y2 + (gy >> 1)) * Z2 + (gz >> 1);
+                    else vox = (((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz;
+                    val = *reinterpret_cast<const uint4*>(src + (vox * Cs + chs) * ES + chunk * 16);
+                }
+                *reinterpret_cast<uint4*>(sA + row * ROWB + chunk * 16) = val;
+            }
+        }
+        const char* wslice = wtile + (size_t)s * 27 * B_BYTES;
+        // tap 0 weights
+#pragma unroll
+        for (int it = 0; it < B_BYTES / (CONV_THREADS * 16); ++it)
+            glds16(wslice + (it * CONV_THREADS + tid) * 16, sB + cur * B_BYTES + (it * CONV_THREADS + wave * 64) * 16);
+        if (B_BYTES < CONV_THREADS * 16) {
+            if (tid * 16 < B_BYTES) glds16(wslice + tid * 16, sB + cur * B_BYTES + wave * 64 * 16);
+        }
+        __syncthreads();
+
+        for (int tap = 0; tap < 27; ++tap) {
+            if (tap + 1 < 27) {
+                const char* wt = wslice + (size_t)(tap + 1) * B_BYTES;
+                char* dst = sB + (cur ^ 1) * B_BYTES;
+#pragma unroll
+                for (int it = 0; it < B_BYTES / (CONV_THREADS * 16); ++it)
+                    glds16(wt + (it * CONV_THREADS + tid) * 16, dst + (it * CONV_THREADS + wave * 64) * 16);
+                if (B_BYTES < CONV_THREADS * 16) {
+                    if (tid * 16 < B_BYTES) glds16(wt + tid * 16, dst + wave * 64 * 16);
+                }
+            }
+            const int tapoff = ((tap / 9) * (HY * HZ) + ((tap / 3) % 3) * HZ + (tap % 3)) * ROWB;
+            const char* bA = sA + tapoff;
+            const char* bB = sB + cur * B_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                uint4 fa[MT], fb[NT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) fa[m] = *reinterpret_cast<const uint4*>(bA + a_off[m] + ks * 32);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) fb[n] = *reinterpret_cast<const uint4*>(bB + b_off[n] + ks * 2 * BN * 16);
+                if constexpr (DT == MMR_DT_BF16) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8, fa[m]), __builtin_bit_cast(bf16x8, fb[n]), acc[m][n], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int n = 0; n < NT; ++n)
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                    __builtin_bit_cast(f32x4, fa[m])[j], __builtin_bit_cast(f32x4, fb[n])[j], acc[m][n], 0, 0, 0);
+                }
+            }
+            __syncthreads();  // drains the LDS-DMA of tap+1 and frees buffer `cur`
+            cur ^= 1;
+        }
+    }
+
+    // ---- epilogue: bias + LeakyReLU, store ----
+    const bool store_f32 = (DT == MMR_DT_F32) || p.out_f32;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = ntile * BN + (wn * NT + n) * 32 + (lane & 31);
+        const bool cok = co < p.Cout;
+        const float bv = (cok && p.bias) ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int v = (wm * MT + m) * 32 + row;
+                const int gx = x0 + (v >> 6), gy = y0 + ((v >> 3) & 7), gz = z0 + (v & 7);
+                if (cok && gx < p.X && gy < p.Y && gz < p.Z) {
+                    float val = acc[m][n][r] + bv;
+                    if (p.leaky && val < 0.f) val *= p.alpha;
+                    const size_t o = ((((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz) * p.Cout + co;
+                    if (store_f32) reinterpret_cast<float*>(p.out)[o] = val;
+                    else reinterpret_cast<bf16_t*>(p.out)[o] = f32_to_bf16(val);
+                }
+            }
+        }
+    }
+}
+
+// ---- weight packing ------------------------------------------------------ //
+__host__ __device__ inline int conv_bn(int Cout)
+{
+    if (Cout % 256 == 0) return 256;
+    if (Cout % 128 == 0) return 128;
+    if (Cout % 64 == 0) return 64;
+    return 32;
+}
+
+template <int DT>
+__global__ void pack_kernel(const float* __restrict__ w, char* __restrict__ wp, int Cin, int Cout, int BN, int ntiles,
+                            int transpose_flip)
+{
+    constexpr int ES = Elt<DT>::size;
+    constexpr int KC = Elt<DT>::kc;
+    constexpr int EPC = 16 / ES;  // elements per 16-B chunk
+    const int nslices = Cin / KC;
+    const int64_t total = (int64_t)ntiles * nslices * 27 * 8 * BN;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i;
+        const int col = (int)(r % BN); r /= BN;
+        const int chunk = (int)(r % 8); r /= 8;
+        const int tap = (int)(r % 27); r /= 27;
+        const int s = (int)(r % nslices);
+        const int t = (int)(r / nslices);
+        const int co = t * BN + col;
+        char* dst = wp + i * 16;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const int ci = s * KC + chunk * EPC + e;
+            float v = 0.f;
+            if (co < Cout) {
+                if (transpose_flip) v = w[((int64_t)(26 - tap) * Cout + co) * Cin + ci];  // keras dims [27][Cout][Cin]
+                else v = w[((int64_t)tap * Cin + ci) * Cout + co];
+            }
+            if (DT == MMR_DT_BF16) reinterpret_cast<bf16_t*>(dst)[e] = f32_to_bf16(v);
+            else reinterpret_cast<float*>(dst)[e] = v;
+        }
+    }
+}
+
+template <int DT, int WM, int WN, int MT, int NT>
+int launch_conv(const ConvParams& p, int ntiles_n, hipStream_t st)
+{
+    constexpr int BN = WN * NT * 32;
+    constexpr int LDS = A_BYTES + 2 * BN * 128;
+    static bool attr_set = false;
+    auto kern = conv3d_k3_kernel<DT, WM, WN, MT, NT>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
+        attr_set = true;
+    }
+    const int64_t nblk = (int64_t)p.B * p.ntx * p.nty * p.ntz;
+    if (nblk > 0x7fffffff) return MMR_EINVAL;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, ntiles_n), dim3(CONV_THREADS), LDS, st, p);
+    return check_launch();
+}
+
+template <int DT>
+int dispatch_conv(const ConvParams& p, hipStream_t st)
+{
+    const int BN = conv_bn(p.Cout);
+    const int nt = (p.Cout + BN - 1) / BN;
+    switch (BN) {
+        case 256: return launch_conv<DT, 2, 4, 4, 2>(p, nt, st);
+        case 128: return launch_conv<DT, 4, 2, 2, 2>(p, nt, st);
+        case 64: return launch_conv<DT, 8, 1, 1, 2>(p, nt, st);
+        default: return launch_conv<DT, 8, 1, 1, 1>(p, nt, st);
+    }
+}
+
+// ---- first layer: concat(moving, fixed) (2 ch) -> Cout, VALU ------------- //
+// Block = 4x4x16 voxel tile; thread = (cout, voxel-group); the thread's 54
+// weights live in registers, the haloed 2-channel patch in LDS (broadcast reads).
+constexpr int F_TX = 4, F_TY = 4, F_TZ = 16;
+template <int OUT_DT>
+__global__ void __launch_bounds__(256)
+conv3d_cin2_kernel(const float* __restrict__ src, const float* __restrict__ trg, const float* __restrict__ w,
+                   const float* __restrict__ bias, void* __restrict__ out, int B, int X, int Y, int Z, int Cout,
+                   int leaky, float alpha, int ntx, int nty, int ntz)
+{
+    constexpr int PX = F_TX + 2, PY = F_TY + 2, PZ = F_TZ + 2;
+    __shared__ float patch[PX][PY][PZ][2];
+    int bid = blockIdx.x;
+    const int tzi = bid % ntz; bid /= ntz;
+    const int tyi = bid % nty; bid /= nty;
+    const int txi = bid % ntx;
+    const int b = bid / ntx;
+    const int x0 = txi * F_TX, y0 = tyi * F_TY, z0 = tzi * F_TZ;
+    const size_t nvox = (size_t)X * Y * Z;
+    for (int i = threadIdx.x; i < PX * PY * PZ; i += 256) {
+        const int hz = i % PZ, hy = (i / PZ) % PY, hx = i / (PZ * PY);
+        const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
+        float a = 0.f, c = 0.f;
+        if (gx >= 0 && gx < X && gy >= 0 && gy < Y && gz >= 0 && gz < Z) {
+            const size_t o = (size_t)b * nvox + ((size_t)gx * Y + gy) * Z + gz;
+            a = src[o];
+            c = trg[o];
+        }
+        patch[hx][hy][hz][0] = a;
+        patch[hx][hy][hz][1] = c;
+    }
+    __syncthreads();
+    const int ngroups = 256 / (Cout < 256 ? Cout : 256);  // voxel groups per block (Cout<=256, divides 256)
+    for (int cobase = 0; cobase < Cout; cobase += 256) {
+        const int co = cobase + (threadIdx.x % (Cout < 256 ? Cout : 256));
+        const int grp = threadIdx.x / (Cout < 256 ? Cout : 256);
+        float wr[54];
+#pragma unroll
+        for (int k = 0; k < 54; ++k) wr[k] = w[k * Cout + co];  // keras [27][2][Cout]
+        const float bv = bias ? bias[co] : 0.f;
+        for (int v = grp; v < F_TX * F_TY * F_TZ; v += ngroups) {
+            const int vz = v % F_TZ, vy = (v / F_TZ) % F_TY, vx = v / (F_TZ * F_TY);
+            float acc = bv;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dz = 0; dz < 3; ++dz) {
+                        const float2 pv = *reinterpret_cast<const float2*>(&patch[vx + dx][vy + dy][vz + dz][0]);
+                        const int t = (dx * 3 + dy) * 3 + dz;
+                        acc = fmaf(pv.x, wr[t * 2], acc);
+                        acc = fmaf(pv.y, wr[t * 2 + 1], acc);
+                    }
+            const int gx = x0 + vx, gy = y0 + vy, gz = z0 + vz;
+            if (gx < X && gy < Y && gz < Z) {
+                if (leaky && acc < 0.f) acc *= alpha;
+                const size_t o = ((size_t)b * nvox + ((size_t)gx * Y + gy) * Z + gz) * Cout + co;
+                if (OUT_DT == MMR_DT_BF16) reinterpret_cast<bf16_t*>(out)[o] = f32_to_bf16(acc);
+                else reinterpret_cast<float*>(out)[o] = acc;
+            }
+        }
+    }
+}
+
+// ---- MaxPooling3D(2), 16 B per lane -------------------------------------- //
+template <int DT>
+__global__ void __launch_bounds__(256)
+maxpool_kernel(const char* __restrict__ in, char* __restrict__ out, int B, int X, int Y, int Z, int C)
+{
+    constexpr int ES = Elt<DT>::size;
+    constexpr int EPC = 16 / ES;
+    const int Xo = X / 2, Yo = Y / 2, Zo = Z / 2;
+    const int cch = C / EPC;  // 16-B chunks per voxel
+    const int64_t total = (int64_t)B * Xo * Yo * Zo * cch;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i;
+        const int ch = (int)(r % cch); r /= cch;
+        const int z = (int)(r % Zo); r /= Zo;
+        const int y = (int)(r % Yo); r /= Yo;
+        const int x = (int)(r % Xo);
+        const int b = (int)(r / Xo);
+        float m[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) m[e] = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int gx = 2 * x + (k >> 2), gy = 2 * y + ((k >> 1) & 1), gz = 2 * z + (k & 1);
+            const uint4 v = *reinterpret_cast<const uint4*>(
+                in + ((((size_t)b * X + gx) * Y + gy) * Z + gz) * C * ES + (size_t)ch * 16);
+            if (DT == MMR_DT_BF16) {
+                const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    m[2 * e] = fmaxf(m[2 * e], __uint_as_float(u[e] << 16));
+                    m[2 * e + 1] = fmaxf(m[2 * e + 1], __uint_as_float(u[e] & 0xffff0000u));
+                }
+            } else {
+                m[0] = fmaxf(m[0], __uint_as_float(v.x));
+                m[1] = fmaxf(m[1], __uint_as_float(v.y));
+                m[2] = fmaxf(m[2], __uint_as_float(v.z));
+                m[3] = fmaxf(m[3], __uint_as_float(v.w));
+            }
+        }
+        uint4 o;
+        if (DT == MMR_DT_BF16) {
+            unsigned u[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                u[e] = (__float_as_uint(m[2 * e]) >> 16) | (__float_as_uint(m[2 * e + 1]) & 0xffff0000u);
+            o = make_uint4(u[0], u[1], u[2], u[3]);
+        } else {
+            o = make_uint4(__float_as_uint(m[0]), __float_as_uint(m[1]), __float_as_uint(m[2]), __float_as_uint(m[3]));
+        }
+        *reinterpret_cast<uint4*>(out + (size_t)i * 16) = o;
+    }
+}
+
+}  // namespace mmr
+
+using namespace mmr;
+
+extern "C" int64_t mmr_conv3d_k3_packed_bytes(int Cin, int Cout, int dtype)
+{
+    if (Cin < 1 || Cout < 1) return MMR_EINVAL;
+    const int kc = (dtype == MMR_DT_BF16) ? 64 : 32;
+    if (dtype != MMR_DT_BF16 && dtype != MMR_DT_F32) return MMR_EINVAL;
+    if (Cin % kc) return MMR_EINVAL;
+    const int BN = conv_bn(Cout);
+    const int nt = (Cout + BN - 1) / BN;
+    return (int64_t)nt * (Cin / kc) * 27 * BN * 128;
+}
+
+extern "C" int mmr_conv3d_k3_pack(const float* w_keras, void* w_packed, int Cin, int Cout, int dtype,
+                                  int transpose_flip, void* stream)
+{
+    const int64_t bytes = mmr_conv3d_k3_packed_bytes(Cin, Cout, dtype);
+    if (!w_keras || !w_packed || bytes < 0) return MMR_EINVAL;
+    const int BN = conv_bn(Cout);
+    const int nt = (Cout + BN - 1) / BN;
+    const int grid = stream_grid(bytes / 16, 256);
+    if (dtype == MMR_DT_BF16)
+        hipLaunchKernelGGL(pack_kernel<MMR_DT_BF16>, dim3(grid), dim3(256), 0, as_stream(stream), w_keras,
+                           (char*)w_packed, Cin, Cout, BN, nt, transpose_flip);
+    else
+        hipLaunchKernelGGL(pack_kernel<MMR_DT_F32>, dim3(grid), dim3(256), 0, as_stream(stream), w_keras,
+                           (char*)w_packed, Cin, Cout, BN, nt, transpose_flip);
+    return check_launch();
+}
+
+extern "C" int mmr_conv3d_k3_fwd(const void* in0, int C0, int up0, const void* in1, int C1, const void* w_packed,
+                                 const float* bias, void* out, void* pool_out, int B, int X, int Y, int Z, int Cout,
+                                 int leaky, float alpha, int dtype, int out_f32, void* stream)
+{
+    if (!in0 || !w_packed || !out || B < 1 || X < 1 || Y < 1 || Z < 1 || Cout < 1 || C0 < 1 || C1 < 0) return MMR_EINVAL;
+    if (dtype != MMR_DT_BF16 && dtype != MMR_DT_F32) return MMR_EINVAL;
+    if (C1 > 0 && !in1) return MMR_EINVAL;
+    if (pool_out) return MMR_EUNSUPPORTED;  // fused pooling: planned; use mmr_maxpool3d2_fwd
+    const int kc = (dtype == MMR_DT_BF16) ? 64 : 32;
+    if (C0 % kc || C1 % kc) return MMR_EINVAL;
+    if (up0 && ((X | Y | Z) & 1)) return MMR_EINVAL;
+    ConvParams p;
+    p.in0 = (const char*)in0; p.in1 = (const char*)in1; p.wp = (const char*)w_packed; p.bias = bias;
+    p.out = (char*)out;
+    p.B = B; p.X = X; p.Y = Y; p.Z = Z; p.C0 = C0; p.C1 = C1; p.up0 = up0; p.Cout = Cout;
+    p.leaky = leaky; p.alpha = alpha; p.out_f32 = out_f32;
+    p.ntx = (X + TX - 1) / TX; p.nty = (Y + TY - 1) / TY; p.ntz = (Z + TZ - 1) / TZ;
+    if (dtype == MMR_DT_BF16) return dispatch_conv<MMR_DT_BF16>(p, as_stream(stream));
+    return dispatch_conv<MMR_DT_F32>(p, as_stream(stream));
+}
+
+extern "C" int mmr_conv3d_k3_cin2_fwd(const float* src, const float* trg, const float* w_keras, const float* bias,
+                                      void* out, void* pool_out, int B, int X, int Y, int Z, int Cout, int leaky,
+                                      float alpha, int out_dtype, void* stream)
+{
+    if (!src || !trg || !w_keras || !out || B < 1 || X < 1 || Y < 1 || Z < 1 || Cout < 1) return MMR_EINVAL;
+    if (pool_out) return MMR_EUNSUPPORTED;
+    if (!((Cout <= 256 && 256 % Cout == 0) || Cout % 256 == 0)) return MMR_EINVAL;
+    const int ntx = (X + F_TX - 1) / F_TX, nty = (Y + F_TY - 1) / F_TY, ntz = (Z + F_TZ - 1) / F_TZ;
+    const int64_t nblk = (int64_t)B * ntx * nty * ntz;
+    if (nblk > 0x7fffffff) return MMR_EINVAL;
+    if (out_dtype == MMR_DT_BF16)
+        hipLaunchKernelGGL(conv3d_cin2_kernel<MMR_DT_BF16>, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), src,
+                           trg, w_keras, bias, out, B, X, Y, Z, Cout, leaky, alpha, ntx, nty, ntz);
+    else if (out_dtype == MMR_DT_F32)
+        hipLaunchKernelGGL(conv3d_cin2_kernel<MMR_DT_F32>, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), src,
+                           trg, w_keras, bias, out, B, X, Y, Z, Cout, leaky, alpha, ntx, nty, ntz);
+    else
+        return MMR_EINVAL;
+    return check_launch();
+}
+
+extern "C" int mmr_maxpool3d2_fwd(const void* in, void* out, int B, int X, int Y, int Z, int C, int dtype, void* stream)
+{
+    if (!in || !out || B < 1 || X < 2 || Y < 2 || Z < 2 || C < 1) return MMR_EINVAL;
+    const int epc = (dtype == MMR_DT_BF16) ? 8 : 4;
+    if (dtype != MMR_DT_BF16 && dtype != MMR_DT_F32) return MMR_EINVAL;
+    if (C % epc) return MMR_EINVAL;
+    const int64_t total = (int64_t)B * (X / 2) * (Y / 2) * (Z / 2) * (C / epc);
+    if (dtype == MMR_DT_BF16)
+        hipLaunchKernelGGL(maxpool_kernel<MMR_DT_BF16>, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream),
+                           (const char*)in, (char*)out, B, X, Y, Z, C);
+    else
+        hipLaunchKernelGGL(maxpool_kernel<MMR_DT_F32>, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream),
+                           (const char*)in, (char*)out, B, X, Y, Z, C);
+    return check_launch();
+}

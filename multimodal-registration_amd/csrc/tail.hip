@@ -1,0 +1,244 @@
+// HBM-bound "tail" of VxmDense: spatial transformer, align-corners resize,
+// compose / scaling-and-squaring.  One thread per output element, channels
+// fastest so a wave's 8 corner gathers are contiguous channel runs (NDHWC).
+// Arithmetic order follows neurite's interpn with FP
+// contraction off, so results match the fp32 restatement operation for
+// operation.
+#include "common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace mmr {
+
+struct Axis {
+    int i0, i1;
+    float w0, w1;
+};
+
+__device__ __forceinline__ Axis axis_setup(float loc, int maxi)
+{
+    const float m = (float)maxi;
+    const float fl = floorf(loc);
+    const float cl = fminf(fmaxf(loc, 0.f), m);
+    const float l0 = fminf(fmaxf(fl, 0.f), m);
+    const float l1 = fminf(l0 + 1.f, m);
+    Axis a;
+    a.i0 = (int)l0;
+    a.i1 = (int)l1;
+    a.w0 = l1 - cl;
+    a.w1 = 1.f - a.w0;
+    return a;
+}
+
+// sum over the 8 corners in itertools.product order, weight = (wx*wy)*wz.
+// `p` points at channel c of voxel (0,0,0) of this batch item; strides in elements.
+template <typename LoadF>
+__device__ __forceinline__ float trilinear(const Axis& ax, const Axis& ay, const Axis& az,
+                                           int64_t sx, int64_t sy, int64_t sz, LoadF ld)
+{
+    const int64_t x0 = ax.i0 * sx, x1 = ax.i1 * sx;
+    const int64_t y0 = ay.i0 * sy, y1 = ay.i1 * sy;
+    const int64_t z0 = az.i0 * sz, z1 = az.i1 * sz;
+    // issue all 8 gathers before use
+    const float v000 = ld(x0 + y0 + z0), v001 = ld(x0 + y0 + z1);
+    const float v010 = ld(x0 + y1 + z0), v011 = ld(x0 + y1 + z1);
+    const float v100 = ld(x1 + y0 + z0), v101 = ld(x1 + y0 + z1);
+    const float v110 = ld(x1 + y1 + z0), v111 = ld(x1 + y1 + z1);
+    const float w00 = ax.w0 * ay.w0, w01 = ax.w0 * ay.w1, w10 = ax.w1 * ay.w0, w11 = ax.w1 * ay.w1;
+    float o = 0.f;
+    o = o + (w00 * az.w0) * v000;
+    o = o + (w00 * az.w1) * v001;
+    o = o + (w01 * az.w0) * v010;
+    o = o + (w01 * az.w1) * v011;
+    o = o + (w10 * az.w0) * v100;
+    o = o + (w10 * az.w1) * v101;
+    o = o + (w11 * az.w0) * v110;
+    o = o + (w11 * az.w1) * v111;
+    return o;
+}
+
+__device__ __forceinline__ int nearest_idx(float loc, int maxi)
+{
+    // tf.round = round half to even; clamp after the int cast like interpn
+    const float r = rintf(loc);
+    const float c = fminf(fmaxf(r, 0.f), (float)maxi);
+    return (int)c;
+}
+
+template <int INTERP, typename T>
+__global__ void __launch_bounds__(256)
+warp3d_kernel(const T* __restrict__ vol, const float* __restrict__ flow, T* __restrict__ out,
+              int B, int X, int Y, int Z, int C, int has_fill, T fill, int channelwise)
+{
+    const int64_t nvox = (int64_t)X * Y * Z;
+    const int64_t total = (int64_t)B * nvox * C;
+    const int64_t sz = C, sy = (int64_t)Z * C, sx = (int64_t)Y * Z * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t v = i / C;  // b*nvox + vox
+        const int64_t b = v / nvox;
+        const int64_t r = v - b * nvox;
+        const int z = (int)(r % Z);
+        const int y = (int)((r / Z) % Y);
+        const int x = (int)(r / ((int64_t)Z * Y));
+        const float* f = channelwise ? flow + (v * C + c) * 3 : flow + v * 3;
+        const float lx = (float)x + f[0], ly = (float)y + f[1], lz = (float)z + f[2];
+        const T* base = vol + b * nvox * C + c;
+        T o;
+        if (INTERP == MMR_INTERP_NEAREST) {
+            const int ix = nearest_idx(lx, X - 1), iy = nearest_idx(ly, Y - 1), iz = nearest_idx(lz, Z - 1);
+            o = base[ix * sx + iy * sy + iz * sz];
+        } else {
+            const Axis ax = axis_setup(lx, X - 1), ay = axis_setup(ly, Y - 1), az = axis_setup(lz, Z - 1);
+            o = (T)trilinear(ax, ay, az, sx, sy, sz, [&](int64_t off) { return (float)base[off]; });
+        }
+        if (has_fill) {
+            const bool oob = (lx < 0.f) | (lx > (float)(X - 1)) | (ly < 0.f) | (ly > (float)(Y - 1)) |
+                             (lz < 0.f) | (lz > (float)(Z - 1));
+            if (oob) o = fill;
+        }
+        out[i] = o;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+resize_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int X, int Y, int Z, int C,
+              int Xo, int Yo, int Zo, float stx, float sty, float stz, float mul, int pre_scale)
+{
+    const int64_t nvo = (int64_t)Xo * Yo * Zo, nvi = (int64_t)X * Y * Z;
+    const int64_t total = (int64_t)B * nvo * C;
+    const int64_t sz = C, sy = (int64_t)Z * C, sx = (int64_t)Y * Z * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t v = i / C;
+        const int64_t b = v / nvo;
+        const int64_t r = v - b * nvo;
+        const int z = (int)(r % Zo);
+        const int y = (int)((r / Zo) % Yo);
+        const int x = (int)(r / ((int64_t)Zo * Yo));
+        const Axis ax = axis_setup((float)x * stx, X - 1);
+        const Axis ay = axis_setup((float)y * sty, Y - 1);
+        const Axis az = axis_setup((float)z * stz, Z - 1);
+        const float* base = in + b * nvi * C + c;
+        float o;
+        if (pre_scale) {
+            o = trilinear(ax, ay, az, sx, sy, sz, [&](int64_t off) { return base[off] * mul; });
+        } else {
+            o = trilinear(ax, ay, az, sx, sy, sz, [&](int64_t off) { return base[off]; }) * mul;
+        }
+        out[i] = o;
+    }
+}
+
+// out = s*b + (s*a) o (id + s*b), 3-channel fields; s folds VecInt's 1/2^n.
+__global__ void __launch_bounds__(256)
+compose_kernel(const float* __restrict__ a, const float* __restrict__ bf, float* __restrict__ out,
+               int B, int X, int Y, int Z, float s)
+{
+    const int64_t nvox = (int64_t)X * Y * Z;
+    const int64_t total = (int64_t)B * nvox * 3;
+    const int64_t sz = 3, sy = (int64_t)Z * 3, sx = (int64_t)Y * Z * 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % 3);
+        const int64_t v = i / 3;
+        const int64_t b = v / nvox;
+        const int64_t r = v - b * nvox;
+        const int z = (int)(r % Z);
+        const int y = (int)((r / Z) % Y);
+        const int x = (int)(r / ((int64_t)Z * Y));
+        const float* f = bf + v * 3;
+        const float f0 = f[0] * s, f1 = f[1] * s, f2 = f[2] * s;
+        const Axis ax = axis_setup((float)x + f0, X - 1);
+        const Axis ay = axis_setup((float)y + f1, Y - 1);
+        const Axis az = axis_setup((float)z + f2, Z - 1);
+        const float* base = a + b * nvox * 3 + c;
+        const float w = trilinear(ax, ay, az, sx, sy, sz, [&](int64_t off) { return base[off] * s; });
+        const float own = (c == 0) ? f0 : (c == 1 ? f1 : f2);
+        out[i] = own + w;
+    }
+}
+
+}  // namespace mmr
+
+using namespace mmr;
+
+extern "C" int mmr_warp3d_f32(const float* vol, const float* flow, float* out, int B, int X, int Y, int Z, int C,
+                              int interp, int has_fill, float fill, int channelwise, void* stream)
+{
+    if (!vol || !flow || !out || B < 1 || X < 1 || Y < 1 || Z < 1 || C < 1) return MMR_EINVAL;
+    if (interp != MMR_INTERP_LINEAR && interp != MMR_INTERP_NEAREST) return MMR_EINVAL;
+    const int64_t total = (int64_t)B * X * Y * Z * C;
+    const int grid = stream_grid(total, 256);
+    if (interp == MMR_INTERP_LINEAR)
+        hipLaunchKernelGGL((warp3d_kernel<MMR_INTERP_LINEAR, float>), dim3(grid), dim3(256), 0, as_stream(stream),
+                           vol, flow, out, B, X, Y, Z, C, has_fill, fill, channelwise);
+    else
+        hipLaunchKernelGGL((warp3d_kernel<MMR_INTERP_NEAREST, float>), dim3(grid), dim3(256), 0, as_stream(stream),
+                           vol, flow, out, B, X, Y, Z, C, has_fill, fill, channelwise);
+    return check_launch();
+}
+
+extern "C" int mmr_warp3d_nearest_u8(const uint8_t* vol, const float* flow, uint8_t* out, int B, int X, int Y,
+                                     int Z, int C, int has_fill, uint8_t fill, void* stream)
+{
+    if (!vol || !flow || !out || B < 1 || X < 1 || Y < 1 || Z < 1 || C < 1) return MMR_EINVAL;
+    const int64_t total = (int64_t)B * X * Y * Z * C;
+    hipLaunchKernelGGL((warp3d_kernel<MMR_INTERP_NEAREST, uint8_t>), dim3(stream_grid(total, 256)), dim3(256), 0,
+                       as_stream(stream), vol, flow, out, B, X, Y, Z, C, has_fill, fill, 0);
+    return check_launch();
+}
+
+extern "C" int mmr_resize_trilinear_f32(const float* in, float* out, int B, int X, int Y, int Z, int C, int Xo,
+                                        int Yo, int Zo, float mul, int pre_scale, void* stream)
+{
+    if (!in || !out || B < 1 || X < 1 || Y < 1 || Z < 1 || C < 1 || Xo < 1 || Yo < 1 || Zo < 1) return MMR_EINVAL;
+    const float stx = (float)(X - 1) / (float)(Xo > 1 ? Xo - 1 : 1);
+    const float sty = (float)(Y - 1) / (float)(Yo > 1 ? Yo - 1 : 1);
+    const float stz = (float)(Z - 1) / (float)(Zo > 1 ? Zo - 1 : 1);
+    const int64_t total = (int64_t)B * Xo * Yo * Zo * C;
+    hipLaunchKernelGGL(resize_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), in, out, B, X,
+                       Y, Z, C, Xo, Yo, Zo, stx, sty, stz, mul, pre_scale);
+    return check_launch();
+}
+
+extern "C" int mmr_compose_f32(const float* a, const float* b, float* out, int B, int X, int Y, int Z, void* stream)
+{
+    if (!a || !b || !out || B < 1 || X < 1 || Y < 1 || Z < 1) return MMR_EINVAL;
+    if (out == a || out == b) return MMR_EINVAL;
+    const int64_t total = (int64_t)B * X * Y * Z * 3;
+    hipLaunchKernelGGL(compose_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), a, b, out, B,
+                       X, Y, Z, 1.0f);
+    return check_launch();
+}
+
+extern "C" int mmr_vecint_f32(const float* vel, float* out, float* tmp, int B, int X, int Y, int Z, int nsteps,
+                              void* stream)
+{
+    if (!vel || !out || !tmp || B < 1 || X < 1 || Y < 1 || Z < 1 || nsteps < 0 || nsteps > 30) return MMR_EINVAL;
+    if (out == vel || tmp == vel || out == tmp) return MMR_EINVAL;
+    const int64_t total = (int64_t)B * X * Y * Z * 3;
+    hipStream_t st = as_stream(stream);
+    if (nsteps == 0) {
+        if (hipMemcpyAsync(out, vel, total * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return MMR_EHIP;
+        return MMR_OK;
+    }
+    const int grid = stream_grid(total, 256);
+    // ping-pong so that the last step lands in `out`
+    float* bufs[2] = {out, tmp};
+    int cur = (nsteps % 2 == 1) ? 0 : 1;  // destination of step 0
+    const float* src = vel;
+    float s = 1.0f / (float)(1 << nsteps);
+    for (int k = 0; k < nsteps; ++k) {
+        float* dst = bufs[cur];
+        hipLaunchKernelGGL(compose_kernel, dim3(grid), dim3(256), 0, st, src, src, dst, B, X, Y, Z, s);
+        int rc = check_launch();
+        if (rc) return rc;
+        src = dst;
+        s = 1.0f;
+        cur ^= 1;
+    }
+    return MMR_OK;
+}

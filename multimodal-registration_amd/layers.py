@@ -1,0 +1,68 @@
+"""Layer-level mirrors of ``vxm.layers`` (reference: train_synthmorph.py:298)."""
+import numpy as np
+import torch
+
+from . import ops
+
+
+def to_device(a, dtype=torch.float32, device="cuda"):
+    """NumPy / tensor -> contiguous device tensor (Keras casts float64 inputs to fp32)."""
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device, dtype=dtype).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dtype).contiguous()
+
+
+class SpatialTransformer:
+    """``vxm.layers.SpatialTransformer(interp_method, name=, fill_value=None)([vol, flow])``.
+
+    vol [B,X,Y,Z,C], flow [B,X,Y,Z,3] in voxels, 'ij' indexing, clamp-to-edge
+    unless ``fill_value`` is given.
+    """
+
+    def __init__(self, interp_method="linear", indexing="ij", single_transform=False, fill_value=None,
+                 shift_center=True, name=None, **kwargs):
+        if indexing != "ij":
+            raise ValueError("only indexing='ij' is supported (the reference never changes it)")
+        ops.interp_code(interp_method)
+        self.interp_method = interp_method
+        self.fill_value = fill_value
+        self.single_transform = single_transform
+        self.name = name
+
+    def __call__(self, inputs):
+        vol, flow = inputs
+        numpy_in = not isinstance(vol, torch.Tensor)
+        vol = to_device(vol)
+        flow = to_device(flow)
+        if self.single_transform and flow.shape[0] == 1 and vol.shape[0] > 1:
+            flow = flow.expand(vol.shape[0], *flow.shape[1:]).contiguous()
+        out = ops.warp3d(vol, flow, self.interp_method, self.fill_value)
+        return out.cpu().numpy() if numpy_in else out
+
+
+class VecInt:
+    """``vxm.layers.VecInt(method='ss', int_steps=)`` (config.json:41)."""
+
+    def __init__(self, indexing="ij", method="ss", int_steps=7, name=None, **kwargs):
+        if method not in ("ss", "scaling_and_squaring"):
+            raise ValueError("only scaling-and-squaring integration is implemented (what the reference uses)")
+        self.int_steps = int_steps
+
+    def __call__(self, vel):
+        numpy_in = not isinstance(vel, torch.Tensor)
+        out = ops.vecint(to_device(vel), self.int_steps)
+        return out.cpu().numpy() if numpy_in else out
+
+
+class RescaleTransform:
+    """``vxm.layers.RescaleTransform(zoom_factor)``: resize a dense field and scale its vectors."""
+
+    def __init__(self, zoom_factor, interp_method="linear", name=None, **kwargs):
+        if interp_method != "linear":
+            raise ValueError("RescaleTransform supports interp_method='linear' only")
+        self.zoom_factor = zoom_factor
+
+    def __call__(self, trf):
+        numpy_in = not isinstance(trf, torch.Tensor)
+        out = ops.rescale_transform(to_device(trf), self.zoom_factor)
+        return out.cpu().numpy() if numpy_in else out

@@ -1,0 +1,58 @@
+"""Mirrors of ``vxm.losses`` used by the reference (train_synthmorph.py:303-307)
+plus the NCC / bending-energy terms of BASELINE.json config 5."""
+import torch
+
+from . import ops
+from .layers import to_device
+
+
+class Dice:
+    """``vxm.losses.Dice().loss(y_true, y_pred)`` -> scalar (Appendix A6)."""
+
+    def loss(self, y_true, y_pred):
+        return ops.dice_loss(to_device(y_true), to_device(y_pred))
+
+
+class Grad:
+    """``vxm.losses.Grad('l2', loss_mult=).loss(None, flow)`` -> [B] (Appendix A7)."""
+
+    def __init__(self, penalty="l1", loss_mult=None, vox_weight=None):
+        if penalty != "l2":
+            raise ValueError("only penalty='l2' is implemented (what the reference uses)")
+        self.loss_mult = 1.0 if loss_mult is None else float(loss_mult)
+
+    def loss(self, _, y_pred):
+        return ops.grad_l2_loss(to_device(y_pred), self.loss_mult)
+
+
+class NCC:
+    """``vxm.losses.NCC(win).loss(I, J)`` -> [B]; cc = cross^2/(I_var*J_var+eps) (Appendix A8)."""
+
+    def __init__(self, win=None, eps=1e-5):
+        self.win = 9 if win is None else int(win if not isinstance(win, (list, tuple)) else win[0])
+        self.eps = eps
+
+    def loss(self, y_true, y_pred):
+        return ops.ncc_loss(to_device(y_true), to_device(y_pred), self.win, self.eps)
+
+
+class BendingEnergy:
+    """Mean squared second differences of a displacement field -> [B] (defined by this build)."""
+
+    def loss(self, _, y_pred):
+        return ops.bending_energy(to_device(y_pred))
+
+
+def dice_loss_zeropad(y_true, y_pred):
+    """Intent of the reference's ``losses.dice_loss_zeropad`` (losses.py:13-21; the reference
+    function itself always raises): Dice over labels 1..L-1 of batch item 0 with
+    voxels masked where channel 0 >= 1 in either map.  Composed from device ops."""
+    t = to_device(y_true)[0:1]
+    p = to_device(y_pred)[0:1]
+    keep = ~((t[..., 0:1] >= 1) | (p[..., 0:1] >= 1))
+    t = (t * keep).contiguous()
+    p = (p * keep).contiguous()
+    _, tb = ops.dice_loss(t, p, return_parts=True)
+    top, bot = tb[0, 1:, 0], tb[0, 1:, 1]
+    d = torch.where(bot != 0, top / bot, torch.zeros_like(top))
+    return -d.mean()

@@ -1,0 +1,263 @@
+"""``vxm.networks.VxmDense`` / ``Transform`` on MI355X.
+
+Reference call sites: train_synthmorph.py:271-277,296-297; 3d_reg.py:277,
+297-314,331-334; bids_two_steps_registration.py:303-325.  Semantics follow
+SURVEY.md section 3.4 / Appendix A1.  The object keeps Keras' positional weight
+list (``get_weights``/``set_weights``: [kernel (3,3,3,Cin,Cout), bias (Cout)] x
+11 layers) so the reference's runtime-shape rebuild + weight transplant
+(3d_reg.py:305-306) works unchanged.
+"""
+import json
+import math
+import types
+
+import numpy as np
+import torch
+
+from . import ops
+from .layers import to_device
+
+DEFAULT_FEATURES = [[16, 32, 32, 32], [32, 32, 32, 32, 32, 16, 16]]
+
+
+def _plan(enc, dec):
+    """[(name, cin_parts, cout)] in Keras weight-creation order."""
+    plan, skips = [], []
+    cin = (2,)
+    nlev = len(enc)
+    for i, nf in enumerate(enc):
+        plan.append((f"unet_enc_conv_{i}_0", cin, nf))
+        skips.append(nf)
+        cin = (nf,)
+    for i in range(nlev):
+        nf = dec[i]
+        plan.append((f"unet_dec_conv_{i}_0", cin, nf))
+        cin = (nf, skips.pop())
+    for j, nf in enumerate(dec[nlev:]):
+        plan.append((f"unet_dec_final_conv_{j}", cin, nf))
+        cin = (nf,)
+    plan.append(("flow", cin, 3))
+    return plan
+
+
+class VxmDense:
+    """VoxelMorph dense registration network, forward on gfx950 HIP kernels.
+
+    ``compute_dtype``: 'bf16' (bf16 activations/weights, fp32 MFMA accumulate;
+    BASELINE.json config 2) or 'fp32' (exact-fp32 MFMA; the 1e-4 parity path).
+    """
+
+    def __init__(self, inshape, nb_unet_features=None, nb_unet_levels=None, unet_feat_mult=1,
+                 nb_unet_conv_per_level=1, int_steps=7, svf_resolution=1, int_resolution=2,
+                 int_downsize=None, bidir=False, use_probs=False, src_feats=1, trg_feats=1,
+                 unet_half_res=False, input_model=None, hyp_model=None, fill_value=None,
+                 reg_field="preintegrated", name="vxm_dense", compute_dtype="bf16", device="cuda", seed=0):
+        if len(inshape) != 3:
+            raise ValueError("VxmDense here is 3-D only (the reference registers 3-D volumes)")
+        if bidir or use_probs or unet_half_res or hyp_model is not None or nb_unet_conv_per_level != 1:
+            raise NotImplementedError("bidir / use_probs / unet_half_res / hyp_model / conv_per_level!=1 "
+                                      "are not used by the reference and not implemented")
+        if src_feats != 1 or trg_feats != 1:
+            raise NotImplementedError("src_feats = trg_feats = 1 only")
+        if int_downsize is not None:
+            int_resolution = int_downsize
+        if nb_unet_features is None:
+            nb_unet_features = DEFAULT_FEATURES
+        enc, dec = [list(map(int, f)) for f in nb_unet_features]
+        if len(dec) < len(enc):
+            raise ValueError("decoder must have at least as many entries as the encoder")
+        self.inshape = tuple(int(s) for s in inshape)
+        self.enc, self.dec = enc, dec
+        self.int_steps, self.int_resolution, self.svf_resolution = int(int_steps), int_resolution, svf_resolution
+        self.fill_value = fill_value
+        self.input_model = input_model
+        self.name = name
+        self.device = torch.device(device)
+        if compute_dtype in ("bf16", torch.bfloat16):
+            self.dtype = torch.bfloat16
+        elif compute_dtype in ("fp32", "float32", torch.float32):
+            self.dtype = torch.float32
+        else:
+            raise ValueError("compute_dtype must be 'bf16' or 'fp32'")
+        nlev = len(enc)
+        if any(s % (2 ** nlev) for s in self.inshape):
+            raise ValueError(f"inshape {self.inshape} must be divisible by 2**{nlev} (U-Net skip concat)")
+        self._config = dict(inshape=list(self.inshape), nb_unet_features=[enc, dec], int_steps=self.int_steps,
+                            svf_resolution=svf_resolution, int_resolution=int_resolution, fill_value=fill_value)
+        self.plan = _plan(enc, dec)
+        self._kc = ops.conv_kc(self.dtype)
+        for name_, cin, cout in self.plan[1:]:
+            if any(c % self._kc for c in cin):
+                raise NotImplementedError(
+                    f"layer {name_}: channel counts {cin} must be multiples of {self._kc} for "
+                    f"{compute_dtype} (the reference configs use 64 and 256)")
+        c0 = self.plan[0][2]
+        if not ((c0 <= 256 and 256 % c0 == 0) or c0 % 256 == 0):
+            raise NotImplementedError("first layer width must divide 256 or be a multiple of 256")
+        self._init_weights(seed)
+        self.references = types.SimpleNamespace(
+            unet_model=None, source=None, target=None, svf=None, preint_flow=None, postint_flow=None,
+            pos_flow=None, neg_flow=None, y_source=None, y_target=None, hyp_input=None)
+        self._losses = []
+
+    # ------------------------------------------------------------------ weights
+    def _init_weights(self, seed):
+        g = torch.Generator(device="cpu").manual_seed(int(seed))
+        self._w = []
+        for name_, cin, cout in self.plan:
+            ci = sum(cin)
+            if name_ == "flow":
+                std = 1e-5  # RandomNormal(0, 1e-5)
+                w = torch.randn((3, 3, 3, ci, cout), generator=g) * std
+            else:  # he_normal = truncated normal, stddev sqrt(2/fan_in)/0.8796
+                std = math.sqrt(2.0 / (27 * ci)) / 0.87962566103423978
+                w = torch.empty((3, 3, 3, ci, cout))
+                torch.nn.init.trunc_normal_(w, 0.0, std, -2 * std, 2 * std, generator=g)
+            self._w.append(w.to(self.device).contiguous())
+            self._w.append(torch.zeros(cout, device=self.device))
+        self._packed = None
+
+    def get_weights(self):
+        return [w.detach().cpu().numpy() for w in self._w]
+
+    def set_weights(self, weights):
+        if len(weights) != len(self._w):
+            raise ValueError(f"expected {len(self._w)} arrays, got {len(weights)}")
+        new = []
+        for cur, w in zip(self._w, weights):
+            w = to_device(np.asarray(w) if not isinstance(w, torch.Tensor) else w, device=self.device)
+            if tuple(w.shape) != tuple(cur.shape):
+                raise ValueError(f"weight shape {tuple(w.shape)} does not match {tuple(cur.shape)}")
+            new.append(w)
+        self._w = new
+        self._packed = None
+
+    def _pack(self):
+        if self._packed is None:
+            self._packed = [None] + [ops.pack_conv_weights(self._w[2 * i], self.dtype) for i in range(1, len(self.plan))]
+        return self._packed
+
+    def count_params(self):
+        return sum(int(w.numel()) for w in self._w)
+
+    def summary(self):
+        print(f'Model: "{self.name}"  inshape={self.inshape}  compute_dtype={self.dtype}')
+        for i, (n, cin, cout) in enumerate(self.plan):
+            print(f"  {n:28s} Conv3D 3x3x3 {sum(cin):4d} -> {cout:4d}   params {self._w[2*i].numel() + cout}")
+        print(f"Total params: {self.count_params():,}")
+
+    # ------------------------------------------------------------------ save / load
+    def get_config(self):
+        return dict(self._config)
+
+    def save(self, path):
+        from safetensors.torch import save_file
+        tensors = {f"w{i:02d}": w.detach().cpu().contiguous() for i, w in enumerate(self._w)}
+        save_file(tensors, path, metadata={"config": json.dumps(self._config), "format": "mmr-vxmdense-1"})
+
+    def load_weights(self, path):
+        from safetensors.torch import load_file
+        t = load_file(path)
+        self.set_weights([t[f"w{i:02d}"] for i in range(len(self._w))])
+
+    @classmethod
+    def load(cls, path, input_model=None, **kwargs):
+        from safetensors import safe_open
+        with safe_open(path, framework="pt") as f:
+            cfg = json.loads(f.metadata()["config"])
+        m = cls(input_model=input_model, **cfg, **kwargs)
+        m.load_weights(path)
+        return m
+
+    # ------------------------------------------------------------------ forward
+    def unet(self, src, trg):
+        """[B,X,Y,Z,1] x2 (f32) -> flow [B,X,Y,Z,3] f32."""
+        pk = self._pack()
+        w, nlev = self._w, len(self.enc)
+        li = 0
+        last = ops.conv3d_k3_cin2(src, trg, w[0], w[1], self.dtype)
+        skips = [last]
+        li = 1
+        for _ in range(1, nlev):
+            last = ops.maxpool3d2(last)
+            last = ops.conv3d_k3(last, pk[li], w[2 * li + 1], self.plan[li][2])
+            skips.append(last)
+            li += 1
+        last = ops.maxpool3d2(last)
+        skip = None
+        for _ in range(nlev):
+            last = ops.conv3d_k3(last, pk[li], w[2 * li + 1], self.plan[li][2], in1=skip, up0=skip is not None)
+            skip = skips.pop()
+            li += 1
+        for _ in self.dec[nlev:]:
+            last = ops.conv3d_k3(last, pk[li], w[2 * li + 1], self.plan[li][2], in1=skip, up0=skip is not None)
+            skip = None
+            li += 1
+        if skip is not None:  # no final convs: flow head sees the concat
+            return ops.conv3d_k3(last, pk[li], w[2 * li + 1], 3, in1=skip, up0=True, leaky=False, out_f32=True)
+        return ops.conv3d_k3(last, pk[li], w[2 * li + 1], 3, leaky=False, out_f32=True)
+
+    def forward(self, source, target):
+        """Device tensors [B,X,Y,Z,1] f32 -> dict(y_source, preint_flow, pos_flow, flow)."""
+        if tuple(source.shape[1:4]) != self.inshape:
+            raise ValueError(f"input shape {tuple(source.shape[1:4])} != model inshape {self.inshape}")
+        flow = self.unet(source, target)
+        svf = flow
+        if self.svf_resolution != 1:
+            svf = ops.rescale_transform(flow, 1.0 / self.svf_resolution)
+        preint = svf
+        if self.int_steps > 0 and self.int_resolution > 1 and self.int_resolution != self.svf_resolution:
+            preint = ops.rescale_transform(svf, self.svf_resolution / self.int_resolution)
+        pos = preint
+        if self.int_steps > 0:
+            pos = ops.vecint(preint, self.int_steps)
+            if self.int_resolution > 1:
+                pos = ops.resize_trilinear(pos, self.inshape, mul=float(self.int_resolution), pre_scale=True)
+        y = ops.warp3d(source, pos, "linear", self.fill_value)
+        r = self.references
+        r.source, r.target, r.svf, r.preint_flow, r.postint_flow, r.pos_flow, r.y_source = \
+            source, target, svf, preint, pos, pos, y
+        return dict(y_source=y, preint_flow=preint, pos_flow=pos, flow=flow)
+
+    __call__ = forward
+
+    def predict(self, inputs, batch_size=None, verbose=0):
+        """``model.predict([moving, fixed])`` -> [moved, preint_flow] as NumPy fp32 (3d_reg.py:310-314)."""
+        src, trg = inputs
+        out_m, out_f = [], []
+        n = np.asarray(src).shape[0] if not isinstance(src, torch.Tensor) else src.shape[0]
+        for b in range(n):  # Keras predicts in batches; one pair at a time bounds activation memory
+            s = to_device(src[b:b + 1], device=self.device)
+            t = to_device(trg[b:b + 1], device=self.device)
+            o = self.forward(s, t)
+            out_m.append(o["y_source"].cpu().numpy())
+            out_f.append(o["preint_flow"].cpu().numpy())
+        return [np.concatenate(out_m), np.concatenate(out_f)]
+
+
+class Transform:
+    """``vxm.networks.Transform(inshape, interp_method=, rescale=None, nb_feats=1)`` (3d_reg.py:331-334).
+
+    ``predict([vol, trf])``: trf is at ``inshape / rescale`` when ``rescale`` is given and is
+    brought to full resolution with RescaleTransform first (also for rescale == 1)."""
+
+    def __init__(self, inshape, affine=False, interp_method="linear", rescale=None, fill_value=None, nb_feats=1,
+                 device="cuda"):
+        if affine:
+            raise NotImplementedError("affine Transform is not used by the reference")
+        ops.interp_code(interp_method)
+        self.inshape = tuple(int(s) for s in inshape)
+        self.interp_method, self.rescale, self.fill_value, self.nb_feats = interp_method, rescale, fill_value, nb_feats
+        self.device = torch.device(device)
+
+    def predict(self, inputs, batch_size=None, verbose=0):
+        vol, trf = inputs
+        v = to_device(vol, device=self.device)
+        t = to_device(trf, device=self.device)
+        if v.dim() == 4:
+            v = v[..., None].contiguous()
+        if tuple(v.shape[1:4]) != self.inshape or v.shape[-1] != self.nb_feats:
+            raise ValueError(f"volume shape {tuple(v.shape)} does not match Transform{self.inshape + (self.nb_feats,)}")
+        if self.rescale is not None:
+            t = ops.resize_trilinear(t, self.inshape, mul=float(self.rescale), pre_scale=self.rescale >= 1)
+        return ops.warp3d(v, t, self.interp_method, self.fill_value).cpu().numpy()

@@ -1,0 +1,243 @@
+"""Device-tensor wrappers over the C-ABI (include/mmr.h).
+
+torch is used for device memory and streams only; every arithmetic operation
+below is a call into libmmr_hip.so.  Shapes are channels-last.  All functions
+raise on CPU tensors: there is no CPU path in the product.
+"""
+import torch
+
+from . import _lib
+
+F32, BF16 = 0, 1
+LINEAR, NEAREST = 0, 1
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, dtype=None, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.MmrError(f"{name} must be a CUDA/HIP tensor (no CPU fallback in this package)")
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.MmrError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.MmrError(f"{name} must be contiguous")
+    return t
+
+
+def interp_code(method):
+    if method == "linear":
+        return LINEAR
+    if method == "nearest":
+        return NEAREST
+    raise ValueError(f"interp_method must be 'linear' or 'nearest', got {method!r}")
+
+
+def warp3d(vol, flow, interp_method="linear", fill_value=None):
+    """vol [B,X,Y,Z,C] f32, flow [B,X,Y,Z,3] (or [B,X,Y,Z,C,3] channel-wise) -> [B,X,Y,Z,C]."""
+    _chk(vol, torch.float32, "vol")
+    _chk(flow, torch.float32, "flow")
+    B, X, Y, Z, C = vol.shape
+    cw = 0
+    if flow.dim() == 6:
+        cw = 1
+        if tuple(flow.shape) != (B, X, Y, Z, C, 3):
+            raise _lib.MmrError(f"channel-wise flow shape {tuple(flow.shape)} != {(B, X, Y, Z, C, 3)}")
+    elif tuple(flow.shape) != (B, X, Y, Z, 3):
+        raise _lib.MmrError(f"flow shape {tuple(flow.shape)} does not match vol {tuple(vol.shape)}")
+    out = torch.empty_like(vol)
+    rc = _lib.load().mmr_warp3d_f32(vol.data_ptr(), flow.data_ptr(), out.data_ptr(), B, X, Y, Z, C,
+                                    interp_code(interp_method), int(fill_value is not None),
+                                    float(fill_value or 0.0), cw, _stream())
+    _lib.check(rc, "mmr_warp3d_f32")
+    return out
+
+
+def warp3d_nearest_u8(vol, flow, fill_value=None):
+    _chk(vol, torch.uint8, "vol")
+    _chk(flow, torch.float32, "flow")
+    B, X, Y, Z, C = vol.shape
+    if tuple(flow.shape) != (B, X, Y, Z, 3):
+        raise _lib.MmrError("flow shape mismatch")
+    out = torch.empty_like(vol)
+    rc = _lib.load().mmr_warp3d_nearest_u8(vol.data_ptr(), flow.data_ptr(), out.data_ptr(), B, X, Y, Z, C,
+                                           int(fill_value is not None), int(fill_value or 0), _stream())
+    _lib.check(rc, "mmr_warp3d_nearest_u8")
+    return out
+
+
+def resize_trilinear(x, out_shape, mul=1.0, pre_scale=False):
+    """Align-corners trilinear resize of [B,X,Y,Z,C] to out_shape=(Xo,Yo,Zo), values * mul."""
+    _chk(x, torch.float32, "x")
+    B, X, Y, Z, C = x.shape
+    Xo, Yo, Zo = (int(s) for s in out_shape)
+    out = torch.empty((B, Xo, Yo, Zo, C), dtype=torch.float32, device=x.device)
+    rc = _lib.load().mmr_resize_trilinear_f32(x.data_ptr(), out.data_ptr(), B, X, Y, Z, C, Xo, Yo, Zo,
+                                              float(mul), int(pre_scale), _stream())
+    _lib.check(rc, "mmr_resize_trilinear_f32")
+    return out
+
+
+def rescale_transform(trf, factor):
+    """vxm RescaleTransform / rescale_dense_transform on a batched field [B,X,Y,Z,3]."""
+    B, X, Y, Z, _ = trf.shape
+    new = (int(X * factor), int(Y * factor), int(Z * factor))
+    return resize_trilinear(trf, new, mul=factor, pre_scale=factor >= 1)
+
+
+def compose(a, b):
+    """out = b + a o (id + b), fields [B,X,Y,Z,3]."""
+    _chk(a, torch.float32, "a")
+    _chk(b, torch.float32, "b")
+    if a.shape != b.shape or a.shape[-1] != 3:
+        raise _lib.MmrError("compose needs two [B,X,Y,Z,3] fields of equal shape")
+    B, X, Y, Z, _ = a.shape
+    out = torch.empty_like(a)
+    rc = _lib.load().mmr_compose_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), B, X, Y, Z, _stream())
+    _lib.check(rc, "mmr_compose_f32")
+    return out
+
+
+def vecint(vel, nsteps):
+    _chk(vel, torch.float32, "vel")
+    if vel.shape[-1] != 3:
+        raise _lib.MmrError("vecint needs [B,X,Y,Z,3]")
+    B, X, Y, Z, _ = vel.shape
+    out = torch.empty_like(vel)
+    tmp = torch.empty_like(vel)
+    rc = _lib.load().mmr_vecint_f32(vel.data_ptr(), out.data_ptr(), tmp.data_ptr(), B, X, Y, Z, int(nsteps), _stream())
+    _lib.check(rc, "mmr_vecint_f32")
+    return out
+
+
+# ------------------------------- U-Net ---------------------------------- #
+def conv_kc(dtype):
+    return 64 if dtype == torch.bfloat16 else 32
+
+
+def pack_conv_weights(w_keras, dtype, transpose_flip=False):
+    """w_keras [3,3,3,Cin,Cout] f32 (device) -> packed MFMA operand image (uint8 tensor)."""
+    _chk(w_keras, torch.float32, "w_keras")
+    cin, cout = int(w_keras.shape[3]), int(w_keras.shape[4])
+    if transpose_flip:
+        cin, cout = cout, cin
+    lib = _lib.load()
+    nbytes = lib.mmr_conv3d_k3_packed_bytes(cin, cout, _DT[dtype])
+    if nbytes < 0:
+        raise _lib.MmrError(f"cannot pack conv weights Cin={cin} Cout={cout} for {dtype}")
+    out = torch.empty(nbytes, dtype=torch.uint8, device=w_keras.device)
+    rc = lib.mmr_conv3d_k3_pack(w_keras.data_ptr(), out.data_ptr(), cin, cout, _DT[dtype], int(transpose_flip), _stream())
+    _lib.check(rc, "mmr_conv3d_k3_pack")
+    return out
+
+
+def conv3d_k3(in0, w_packed, bias, cout, in1=None, up0=False, leaky=True, alpha=0.2, out_f32=False):
+    """Conv3D(cout,3,'same')(concat([up2(in0) if up0 else in0, in1])) + bias (+LeakyReLU)."""
+    dtype = in0.dtype
+    _chk(in0, dtype, "in0")
+    B, X, Y, Z, C0 = in0.shape
+    if up0:
+        X, Y, Z = 2 * X, 2 * Y, 2 * Z
+    C1 = 0
+    if in1 is not None:
+        _chk(in1, dtype, "in1")
+        if tuple(in1.shape[:4]) != (B, X, Y, Z):
+            raise _lib.MmrError(f"skip shape {tuple(in1.shape)} does not match {(B, X, Y, Z)}")
+        C1 = in1.shape[4]
+    odt = torch.float32 if (out_f32 or dtype == torch.float32) else torch.bfloat16
+    out = torch.empty((B, X, Y, Z, cout), dtype=odt, device=in0.device)
+    rc = _lib.load().mmr_conv3d_k3_fwd(
+        in0.data_ptr(), C0, int(up0), in1.data_ptr() if in1 is not None else None, C1,
+        w_packed.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), None,
+        B, X, Y, Z, int(cout), int(leaky), float(alpha), _DT[dtype], int(out_f32), _stream())
+    _lib.check(rc, "mmr_conv3d_k3_fwd")
+    return out
+
+
+def conv3d_k3_cin2(src, trg, w_keras, bias, out_dtype, leaky=True, alpha=0.2):
+    """First U-Net layer on concat([src, trg]) ([B,X,Y,Z,1] each, f32)."""
+    _chk(src, torch.float32, "src")
+    _chk(trg, torch.float32, "trg")
+    _chk(w_keras, torch.float32, "w_keras")
+    B, X, Y, Z = src.shape[:4]
+    cout = int(w_keras.shape[-1])
+    out = torch.empty((B, X, Y, Z, cout), dtype=out_dtype, device=src.device)
+    rc = _lib.load().mmr_conv3d_k3_cin2_fwd(src.data_ptr(), trg.data_ptr(), w_keras.data_ptr(),
+                                            bias.data_ptr() if bias is not None else None, out.data_ptr(), None,
+                                            B, X, Y, Z, cout, int(leaky), float(alpha), _DT[out_dtype], _stream())
+    _lib.check(rc, "mmr_conv3d_k3_cin2_fwd")
+    return out
+
+
+def maxpool3d2(x):
+    _chk(x, x.dtype, "x")
+    B, X, Y, Z, C = x.shape
+    out = torch.empty((B, X // 2, Y // 2, Z // 2, C), dtype=x.dtype, device=x.device)
+    rc = _lib.load().mmr_maxpool3d2_fwd(x.data_ptr(), out.data_ptr(), B, X, Y, Z, C, _DT[x.dtype], _stream())
+    _lib.check(rc, "mmr_maxpool3d2_fwd")
+    return out
+
+
+# ------------------------------- losses --------------------------------- #
+def _ws(nbytes, device):
+    if nbytes < 0:
+        raise _lib.MmrError("invalid workspace request")
+    return torch.empty(max(int(nbytes), 8), dtype=torch.uint8, device=device)
+
+
+def dice_loss(y_true, y_pred, return_parts=False):
+    """-mean_{b,l} divide_no_nan(2 sum(t*p), sum(t+p)); inputs [B,*S,L] f32 -> scalar tensor."""
+    _chk(y_true, torch.float32, "y_true")
+    _chk(y_pred, torch.float32, "y_pred")
+    if y_true.shape != y_pred.shape:
+        raise _lib.MmrError("dice: shape mismatch")
+    B, L = y_true.shape[0], y_true.shape[-1]
+    nvox = y_true.numel() // (B * L)
+    lib = _lib.load()
+    ws = _ws(lib.mmr_dice_ws_bytes(B, nvox, L), y_true.device)
+    loss = torch.empty(1, dtype=torch.float32, device=y_true.device)
+    tb = torch.empty((B, L, 2), dtype=torch.float32, device=y_true.device)
+    rc = lib.mmr_dice_fwd_f32(y_true.data_ptr(), y_pred.data_ptr(), loss.data_ptr(), tb.data_ptr(), ws.data_ptr(),
+                              B, nvox, L, _stream())
+    _lib.check(rc, "mmr_dice_fwd_f32")
+    return (loss[0], tb) if return_parts else loss[0]
+
+
+def grad_l2_loss(flow, loss_mult=1.0):
+    _chk(flow, torch.float32, "flow")
+    B, X, Y, Z, C = flow.shape
+    lib = _lib.load()
+    ws = _ws(lib.mmr_grad_l2_ws_bytes(B, X, Y, Z, C), flow.device)
+    out = torch.empty(B, dtype=torch.float32, device=flow.device)
+    rc = lib.mmr_grad_l2_fwd_f32(flow.data_ptr(), out.data_ptr(), ws.data_ptr(), B, X, Y, Z, C, float(loss_mult), _stream())
+    _lib.check(rc, "mmr_grad_l2_fwd_f32")
+    return out
+
+
+def ncc_loss(I, J, win=9, eps=1e-5):
+    _chk(I, torch.float32, "I")
+    _chk(J, torch.float32, "J")
+    if I.shape != J.shape or I.shape[-1] != 1:
+        raise _lib.MmrError("ncc: inputs must be [B,X,Y,Z,1] of equal shape")
+    B, X, Y, Z, _ = I.shape
+    lib = _lib.load()
+    ws = _ws(lib.mmr_ncc_ws_bytes(B, X, Y, Z), I.device)
+    out = torch.empty(B, dtype=torch.float32, device=I.device)
+    rc = lib.mmr_ncc_fwd_f32(I.data_ptr(), J.data_ptr(), out.data_ptr(), ws.data_ptr(), B, X, Y, Z, int(win), float(eps), _stream())
+    _lib.check(rc, "mmr_ncc_fwd_f32")
+    return out
+
+
+def bending_energy(flow):
+    _chk(flow, torch.float32, "flow")
+    B, X, Y, Z, C = flow.shape
+    if C != 3:
+        raise _lib.MmrError("bending energy needs [B,X,Y,Z,3]")
+    lib = _lib.load()
+    ws = _ws(lib.mmr_bending_ws_bytes(B, X, Y, Z), flow.device)
+    out = torch.empty(B, dtype=torch.float32, device=flow.device)
+    rc = lib.mmr_bending_fwd_f32(flow.data_ptr(), out.data_ptr(), ws.data_ptr(), B, X, Y, Z, _stream())
+    _lib.check(rc, "mmr_bending_fwd_f32")
+    return out

@@ -1,0 +1,89 @@
+"""MFMA implicit-GEMM Conv3D (+ first layer, pooling) vs the C oracle.
+
+fp32 path: tolerance 1e-4 relative to the output scale (north_star's fp32 bar;
+the MFMA is an exact fp32 FMA chain, the oracle accumulates in double).
+bf16 path: compared with the oracle fed the SAME bf16-rounded inputs/weights
+(fp32 accumulate both sides), tolerance 2e-3 of the output scale for the
+final bf16 store rounding.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _scale_err(got, ref):
+    return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
+
+
+CASES = [
+    # (shape, C0, C1, up0, Cout)
+    ((8, 8, 8), 64, 0, False, 64),
+    ((4, 8, 8), 64, 0, False, 256),
+    ((6, 10, 12), 128, 0, False, 128),      # ragged tiles
+    ((8, 16, 8), 64, 64, True, 64),         # upsample + skip concat
+    ((4, 8, 16), 256, 256, True, 256),      # the dec_final_0 shape class
+    ((5, 9, 7), 64, 0, False, 3),           # flow head (Cout padded to 32), odd sizes
+    ((2, 2, 2), 64, 0, False, 64),          # deepest level of a 32^3 volume
+]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape,C0,C1,up0,Cout", CASES)
+def test_conv_matches_oracle(dev, dtype, shape, C0, C1, up0, Cout):
+    import mmr
+    from oracle.cbind import conv3d_same
+    from oracle.net_np import bf16_round
+    from oracle import ops_np as O
+    rng = np.random.default_rng(hash((shape, C0, C1, Cout)) % 2 ** 31)
+    B = 2 if np.prod(shape) < 600 else 1
+    X, Y, Z = shape
+    s0 = (B, X // 2, Y // 2, Z // 2, C0) if up0 else (B, X, Y, Z, C0)
+    a0 = rng.standard_normal(s0).astype(np.float32)
+    a1 = rng.standard_normal((B, X, Y, Z, C1)).astype(np.float32) if C1 else None
+    w = (rng.standard_normal((3, 3, 3, C0 + C1, Cout)) * np.sqrt(2.0 / (27 * (C0 + C1)))).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32) * 0.1
+    tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
+    if dtype == "bf16":
+        a0, w = bf16_round(a0), bf16_round(w)
+        a1 = bf16_round(a1) if a1 is not None else None
+    full = O.upsample2(a0) if up0 else a0
+    if a1 is not None:
+        full = np.concatenate([full, a1], -1)
+    leaky = Cout != 3
+    ref = conv3d_same(full, w, bias, leaky=leaky, alpha=0.2)
+    wp = mmr.ops.pack_conv_weights(torch.from_numpy(w).to(dev), tdt)
+    got = mmr.ops.conv3d_k3(torch.from_numpy(a0).to(dev).to(tdt), wp, torch.from_numpy(bias).to(dev), Cout,
+                            in1=None if a1 is None else torch.from_numpy(a1).to(dev).to(tdt), up0=up0,
+                            leaky=leaky, out_f32=(Cout == 3))
+    got = got.float().cpu().numpy()
+    assert got.shape == ref.shape
+    tol = 1e-4 if dtype == "fp32" else (1e-5 if Cout == 3 else 4e-3)
+    assert _scale_err(got, ref) < tol
+
+
+@pytest.mark.parametrize("shape,Cout,odt", [((8, 8, 16), 64, "fp32"), ((5, 6, 19), 256, "fp32"), ((8, 8, 16), 256, "bf16")])
+def test_first_layer(dev, shape, Cout, odt):
+    import mmr
+    from oracle.cbind import conv3d_same
+    rng = np.random.default_rng(11)
+    src = rng.random((2,) + shape + (1,)).astype(np.float32)
+    trg = rng.random((2,) + shape + (1,)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, 2, Cout)) * 0.2).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32) * 0.1
+    ref = conv3d_same(np.concatenate([src, trg], -1), w, bias, leaky=True)
+    tdt = torch.float32 if odt == "fp32" else torch.bfloat16
+    got = mmr.ops.conv3d_k3_cin2(torch.from_numpy(src).to(dev), torch.from_numpy(trg).to(dev),
+                                 torch.from_numpy(w).to(dev), torch.from_numpy(bias).to(dev), tdt)
+    assert _scale_err(got.float().cpu().numpy(), ref) < (1e-5 if odt == "fp32" else 4e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_maxpool(dev, dtype):
+    import mmr
+    from oracle import ops_np as O
+    rng = np.random.default_rng(12)
+    x = torch.from_numpy(rng.standard_normal((2, 6, 8, 10, 64)).astype(np.float32)).to(dev).to(dtype)
+    got = mmr.ops.maxpool3d2(x).float().cpu().numpy()
+    assert np.array_equal(got, O.maxpool2(x.float().cpu().numpy()))

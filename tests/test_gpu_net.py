@@ -1,0 +1,73 @@
+"""End-to-end VxmDense forward (HIP) vs the oracle assembly of the same graph."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(rng, shape):
+    """Smooth-ish random image pair in [0,1]."""
+    import scipy.ndimage as ndi
+    a = ndi.gaussian_filter(rng.random(shape), 2.0)
+    b = ndi.gaussian_filter(rng.random(shape), 2.0)
+    n = lambda v: ((v - v.min()) / (v.max() - v.min())).astype(np.float32)
+    return n(a)[None, ..., None], n(b)[None, ..., None]
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 3e-2)])
+def test_vxmdense_forward_matches_oracle(dev, dtype, tol):
+    import mmr
+    from oracle import net_np
+    shape, enc, dec = (32, 32, 48), [64] * 4, [64] * 6
+    rng = np.random.default_rng(0)
+    mov, fix = _pair(rng, shape)
+    # flow-head std large enough for voxel-scale displacements (the Keras init 1e-5 gives ~0 flow)
+    weights = net_np.init_weights(enc, dec, seed=1, flow_std=2e-2)
+    for i in range(1, len(weights), 2):
+        weights[i] = (rng.standard_normal(weights[i].shape) * 0.05).astype(np.float32)
+    model = mmr.networks.VxmDense(shape, nb_unet_features=(enc, dec), int_steps=5, int_resolution=2,
+                                  svf_resolution=2, compute_dtype=dtype)
+    model.set_weights(weights)
+    moved, preint = model.predict([mov, fix])
+    pos = model.references.pos_flow.cpu().numpy()
+    quant = net_np.bf16_round if dtype == "bf16" else None
+    ref = net_np.vxm_dense_forward(mov, fix, weights, enc, dec, 5, 2, 2, quant=quant)
+    assert preint.shape == (1, 16, 16, 24, 3) and moved.shape == (1,) + shape + (1,)
+    assert np.abs(ref["pos_flow"]).max() > 0.5, "test flow too small to be meaningful"
+    for name, got, exp in (("preint_flow", preint, ref["preint_flow"]), ("pos_flow", pos, ref["pos_flow"]),
+                           ("moved", moved, ref["moved"])):
+        err = np.abs(got - exp).max() / np.abs(exp).max()
+        assert err < tol, f"{name}: rel-to-scale err {err:.3e} >= {tol}"
+
+
+def test_weight_transplant_is_shape_agnostic(dev):
+    """3d_reg.py:305-306: rebuild at the runtime shape, then set_weights(get_weights())."""
+    import mmr
+    feats = ([64] * 4, [64] * 6)
+    m1 = mmr.networks.VxmDense((16, 16, 16), nb_unet_features=feats, int_steps=5, int_resolution=2, svf_resolution=2,
+                               compute_dtype="fp32", seed=3)
+    m2 = mmr.networks.VxmDense((32, 16, 48), nb_unet_features=feats, int_steps=5, int_resolution=2, svf_resolution=2,
+                               compute_dtype="fp32", seed=4)
+    w = m1.get_weights()
+    assert len(w) == 22 and w[0].shape == (3, 3, 3, 2, 64) and w[-2].shape == (3, 3, 3, 64, 3)
+    m2.set_weights(w)
+    for a, b in zip(m2.get_weights(), w):
+        assert np.array_equal(a, b)
+    rng = np.random.default_rng(0)
+    moved, warp = m2.predict([rng.random((1, 32, 16, 48, 1)), rng.random((1, 32, 16, 48, 1))])
+    assert moved.shape == (1, 32, 16, 48, 1) and warp.shape == (1, 16, 8, 24, 3)
+    assert moved.dtype == np.float32
+
+
+def test_transform_network(dev):
+    import mmr
+    from oracle import ops_np as O
+    rng = np.random.default_rng(5)
+    vol = rng.random((1, 8, 12, 10, 1))
+    trf = (rng.standard_normal((1, 4, 6, 5, 3)) * 1.5).astype(np.float32)
+    for method in ("linear", "nearest"):
+        got = mmr.networks.Transform((8, 12, 10), interp_method=method, rescale=2, nb_feats=1).predict([vol, trf])
+        full = O.rescale_dense_transform(trf[0], 2)
+        ref = O.transform(vol[0].astype(np.float32), full, method)[None]
+        np.testing.assert_allclose(got, ref, atol=2e-6)
