@@ -159,11 +159,11 @@ def test_dice_grad(dev):
     flow = _rand_flow(rng, (2, 12, 10, 14), 2.0)
     got = _np(mmr.losses.Grad("l2", loss_mult=0.7).loss(None, flow))
     np.testing.assert_allclose(got, O.grad_l2_loss(flow, 0.7), rtol=1e-5)
-    s = 0.3  # ramp with slope s along one axis -> s^2/3 * loss_mult
+    s = 0.3  # ramp of slope s along x in 1 of 3 channels: axis-x mean = s^2/3, mean over 3 axes = s^2/9
     ramp = np.zeros((1, 8, 8, 8, 3), np.float32)
     ramp[..., 0] = s * np.arange(8, dtype=np.float32)[None, :, None, None]
     got = _np(mmr.losses.Grad("l2", loss_mult=2.0).loss(None, ramp))
-    np.testing.assert_allclose(got, [s * s / 3 * 2.0], rtol=1e-5)
+    np.testing.assert_allclose(got, [s * s / 9 * 2.0], rtol=1e-5)
 
 
 @pytest.mark.parametrize("shape", [(20, 18, 40), (9, 33, 12)])
@@ -178,8 +178,9 @@ def test_ncc_bending(dev, shape):
     same = _np(mmr.losses.NCC(win=9).loss(I, I))
     np.testing.assert_allclose(same, O.ncc_loss(I, I, 9), rtol=2e-4)
     assert np.all(same < -0.99)
-    aff = _np(mmr.losses.NCC().loss(I, (2.0 * I + 0.5).astype(np.float32)))  # invariant to affine intensity change
-    np.testing.assert_allclose(aff, same, rtol=1e-3)
+    # affine intensity change: invariant away from the zero-padded border only, so compare with the oracle
+    J2 = (2.0 * I + 0.5).astype(np.float32)
+    np.testing.assert_allclose(_np(mmr.losses.NCC().loss(I, J2)), O.ncc_loss(I, J2, 9), rtol=2e-4)
     flow = _rand_flow(rng, (2,) + shape, 2.0)
     np.testing.assert_allclose(_np(mmr.losses.BendingEnergy().loss(None, flow)), O.bending_energy(flow), rtol=1e-5)
     lin = np.zeros((1,) + shape + (3,), np.float32)
