@@ -99,6 +99,7 @@ class VxmDense:
             unet_model=None, source=None, target=None, svf=None, preint_flow=None, postint_flow=None,
             pos_flow=None, neg_flow=None, y_source=None, y_target=None, hyp_input=None)
         self._losses = []
+        self.layer_events = None  # bench.py sets a list to collect (name, ev0, ev1, flops)
 
     # ------------------------------------------------------------------ weights
     def _init_weights(self, seed):
@@ -170,32 +171,43 @@ class VxmDense:
         return m
 
     # ------------------------------------------------------------------ forward
+    def _conv(self, li, x, **kw):
+        """Layer li of the plan on the MFMA kernel; optional per-launch event pair for bench.py."""
+        name, cin, cout = self.plan[li]
+        ev = self.layer_events
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        out = ops.conv3d_k3(x, self._packed[li], self._w[2 * li + 1], cout, **kw)
+        if ev is not None:
+            e1.record()
+            nvox = out.shape[0] * out.shape[1] * out.shape[2] * out.shape[3]
+            ev.append((name, e0, e1, 2.0 * 27 * sum(cin) * cout * nvox))
+        return out
+
     def unet(self, src, trg):
         """[B,X,Y,Z,1] x2 (f32) -> flow [B,X,Y,Z,3] f32."""
-        pk = self._pack()
+        self._pack()
         w, nlev = self._w, len(self.enc)
-        li = 0
         last = ops.conv3d_k3_cin2(src, trg, w[0], w[1], self.dtype)
         skips = [last]
         li = 1
         for _ in range(1, nlev):
             last = ops.maxpool3d2(last)
-            last = ops.conv3d_k3(last, pk[li], w[2 * li + 1], self.plan[li][2])
+            last = self._conv(li, last)
             skips.append(last)
             li += 1
         last = ops.maxpool3d2(last)
         skip = None
         for _ in range(nlev):
-            last = ops.conv3d_k3(last, pk[li], w[2 * li + 1], self.plan[li][2], in1=skip, up0=skip is not None)
+            last = self._conv(li, last, in1=skip, up0=skip is not None)
             skip = skips.pop()
             li += 1
         for _ in self.dec[nlev:]:
-            last = ops.conv3d_k3(last, pk[li], w[2 * li + 1], self.plan[li][2], in1=skip, up0=skip is not None)
+            last = self._conv(li, last, in1=skip, up0=skip is not None)
             skip = None
             li += 1
-        if skip is not None:  # no final convs: flow head sees the concat
-            return ops.conv3d_k3(last, pk[li], w[2 * li + 1], 3, in1=skip, up0=True, leaky=False, out_f32=True)
-        return ops.conv3d_k3(last, pk[li], w[2 * li + 1], 3, leaky=False, out_f32=True)
+        return self._conv(li, last, in1=skip, up0=skip is not None, leaky=False, out_f32=True)
 
     def forward(self, source, target):
         """Device tensors [B,X,Y,Z,1] f32 -> dict(y_source, preint_flow, pos_flow, flow)."""

@@ -1,0 +1,156 @@
+"""Pins the CPU oracle: analytic known-answer tests + cross-checks against independent
+torch-CPU implementations of the same maths.  The reference ships
+no golden vectors for these operators, so this is all the pinning available (PARITY UNPINNED)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import net_np
+from oracle import ops_np as O
+from oracle.cbind import conv3d_same, warp3d_linear
+
+rng = np.random.default_rng(0)
+
+
+def test_interp_kats():
+    vol = rng.standard_normal((6, 7, 8, 2)).astype(np.float32)
+    z = np.zeros((6, 7, 8, 3), np.float32)
+    for m in ("linear", "nearest"):
+        assert np.array_equal(O.transform(vol, z, m), vol)
+    s = z.copy(); s[..., 1] = -2
+    assert np.array_equal(O.transform(vol, s), np.concatenate([vol[:, :1], vol[:, :1], vol[:, :-2]], 1))
+    ramp = np.broadcast_to(np.arange(8, dtype=np.float32), (6, 7, 8)).copy()
+    h = z.copy(); h[..., 2] = 0.5
+    assert np.array_equal(O.transform(ramp, h)[..., 0], np.minimum(ramp + 0.5, 7))
+    far = z.copy(); far[..., 0] = -50
+    assert np.array_equal(O.transform(vol, far), np.broadcast_to(vol[:1], vol.shape))
+    assert np.all(O.transform(vol, far, fill_value=2.5) == 2.5)
+    hx = z.copy(); hx[..., 0] = 0.5  # tf.round is half-to-even: 0.5->0, 1.5->2, 2.5->2, 3.5->4
+    assert np.array_equal(O.transform(vol, hx, "nearest"), vol[[0, 2, 2, 4, 4, 5]])
+
+
+def test_warp_vs_grid_sample():
+    vol = rng.standard_normal((1, 6, 7, 8, 3)).astype(np.float32)
+    flow = (rng.standard_normal((1, 6, 7, 8, 3)) * 2).astype(np.float32)
+    ref = O.spatial_transformer(vol, flow)
+    g = O._grid((6, 7, 8)) + flow[0]
+    gn = np.stack([2 * g[..., 2] / 7 - 1, 2 * g[..., 1] / 6 - 1, 2 * g[..., 0] / 5 - 1], -1)[None]
+    t = F.grid_sample(torch.from_numpy(vol).permute(0, 4, 1, 2, 3), torch.from_numpy(gn).float(), mode="bilinear",
+                      padding_mode="border", align_corners=True).permute(0, 2, 3, 4, 1).numpy()
+    np.testing.assert_allclose(ref, t, atol=5e-6)
+    np.testing.assert_allclose(warp3d_linear(vol, flow), ref, atol=1e-6)
+
+
+def test_resize_vs_interpolate():
+    x = rng.standard_normal((8, 6, 10, 3)).astype(np.float32)
+    xt = torch.from_numpy(x).permute(3, 0, 1, 2)[None]
+    up = F.interpolate(xt, scale_factor=2, mode="trilinear", align_corners=True)[0].permute(1, 2, 3, 0).numpy()
+    np.testing.assert_allclose(O.resize(x, 2), up, atol=5e-6)
+    dn = F.interpolate(xt, size=(4, 3, 5), mode="trilinear", align_corners=True)[0].permute(1, 2, 3, 0).numpy()
+    np.testing.assert_allclose(O.resize(x, 0.5), dn, atol=5e-6)
+    assert np.array_equal(O.rescale_dense_transform(x, 1), x)
+    np.testing.assert_allclose(O.rescale_dense_transform(x, 2), 2 * up, atol=1e-5)
+
+
+def test_vecint_compose_kats():
+    a = (rng.standard_normal((8, 8, 8, 3))).astype(np.float32)
+    z = np.zeros_like(a)
+    assert np.array_equal(O.compose(a, z), a) and np.array_equal(O.compose(z, a), a)
+    assert np.all(O.vecint(z, 5) == 0)
+    c = np.broadcast_to(np.array([0.5, -0.25, 1.0], np.float32), (8, 8, 8, 3)).copy()
+    np.testing.assert_allclose(O.vecint(c, 5), c, atol=1e-6)
+    # VecInt(v, n) = VecInt(v/2, n-1) composed with itself
+    half = O.vecint(a / 2, 4)
+    np.testing.assert_allclose(O.vecint(a, 5), O.compose(half, half), atol=1e-5)
+
+
+def test_losses_kats():
+    lab = rng.integers(0, 5, (2, 6, 6, 6))
+    t = np.eye(5, dtype=np.float32)[lab]
+    assert abs(O.dice_loss(t, t) + 1) < 1e-12
+    assert O.dice_loss(t, np.zeros_like(t)) == 0
+    ramp = np.zeros((1, 8, 8, 8, 1), np.float32)
+    ramp[..., 0] = 0.3 * np.arange(8)[None, :, None, None]
+    np.testing.assert_allclose(O.grad_l2_loss(ramp, 2.0), [0.3 ** 2 / 3 * 2.0], rtol=1e-6)  # single channel: s^2/3
+    I = rng.random((1, 12, 10, 14, 1)).astype(np.float32)
+    J = rng.random((1, 12, 10, 14, 1)).astype(np.float32)
+
+    def box(a):
+        return F.conv3d(torch.from_numpy(a).double().permute(0, 4, 1, 2, 3), torch.ones(1, 1, 9, 9, 9).double(),
+                        padding=4).numpy()[0, 0]
+    Is, Js, I2, J2, IJ = box(I), box(J), box(I * I), box(J * J), box(I * J)
+    ws = 729.0
+    uI, uJ = Is / ws, Js / ws
+    cross = IJ - uJ * Is - uI * Js + uI * uJ * ws
+    Iv = I2 - 2 * uI * Is + uI * uI * ws
+    Jv = J2 - 2 * uJ * Js + uJ * uJ * ws
+    np.testing.assert_allclose(O.ncc_loss(I, J)[0], -np.mean(cross * cross / (Iv * Jv + 1e-5)), rtol=1e-7)
+    assert O.ncc_loss(I, I)[0] < -0.999
+    aff = np.zeros((1, 6, 6, 6, 3)); aff[..., 0] = np.arange(6)[None, :, None, None] * 0.5
+    assert O.bending_energy(aff)[0] < 1e-20
+    q = np.zeros((1, 6, 6, 6, 3)); q[..., 0] = (np.arange(6) ** 2)[None, :, None, None]
+    np.testing.assert_allclose(O.bending_energy(q), [4.0 / 3.0])  # dxx = 2 in one of three channels
+
+
+def test_conv_pool_vs_torch():
+    x = rng.standard_normal((1, 5, 6, 7, 8)).astype(np.float32)
+    w = rng.standard_normal((3, 3, 3, 8, 4)).astype(np.float32)
+    b = rng.standard_normal(4).astype(np.float32)
+    t = F.conv3d(torch.from_numpy(x).permute(0, 4, 1, 2, 3).double(), torch.from_numpy(w).permute(4, 3, 0, 1, 2).double(),
+                 torch.from_numpy(b).double(), padding=1)
+    np.testing.assert_allclose(conv3d_same(x, w, b), t.permute(0, 2, 3, 4, 1).numpy(), atol=1e-5)
+    np.testing.assert_allclose(conv3d_same(x, w, b, f32acc=True), t.permute(0, 2, 3, 4, 1).numpy(), atol=1e-4)
+    np.testing.assert_allclose(O.conv3d_same_np(x, w, b), t.permute(0, 2, 3, 4, 1).numpy(), atol=1e-12)
+    lt = F.leaky_relu(t, 0.2).permute(0, 2, 3, 4, 1).numpy()
+    np.testing.assert_allclose(conv3d_same(x, w, b, leaky=True), lt, atol=1e-5)
+    xp = rng.standard_normal((1, 6, 8, 4, 3)).astype(np.float32)
+    tp = F.max_pool3d(torch.from_numpy(xp).permute(0, 4, 1, 2, 3), 2).permute(0, 2, 3, 4, 1).numpy()
+    assert np.array_equal(O.maxpool2(xp), tp)
+    tu = F.interpolate(torch.from_numpy(xp).permute(0, 4, 1, 2, 3), scale_factor=2, mode="nearest").permute(0, 2, 3, 4, 1).numpy()
+    assert np.array_equal(O.upsample2(xp), tu)
+
+
+def test_full_forward_vs_torch_assembly():
+    """16^3 forward with seeded weights vs an independent torch-CPU assembly of the same graph."""
+    enc, dec = [8, 8], [8, 8, 8]
+    shape = (16, 16, 16)
+    ws = net_np.init_weights(enc, dec, seed=3, flow_std=5e-2)
+    mov = rng.random((1,) + shape + (1,)).astype(np.float32)
+    fix = rng.random((1,) + shape + (1,)).astype(np.float32)
+    out = net_np.vxm_dense_forward(mov, fix, ws, enc, dec, int_steps=3, int_resolution=2, svf_resolution=2)
+
+    def conv(x, i, act=True):
+        y = F.conv3d(x, torch.from_numpy(ws[i]).permute(4, 3, 0, 1, 2).double(), torch.from_numpy(ws[i + 1]).double(), padding=1)
+        return F.leaky_relu(y, 0.2) if act else y
+    x = torch.from_numpy(np.concatenate([mov, fix], -1)).permute(0, 4, 1, 2, 3).double()
+    e0 = conv(x, 0); e1 = conv(F.max_pool3d(e0, 2), 2)
+    d0 = conv(F.max_pool3d(e1, 2), 4)
+    d1 = conv(torch.cat([F.interpolate(d0, scale_factor=2), e1], 1), 6)
+    f0 = conv(torch.cat([F.interpolate(d1, scale_factor=2), e0], 1), 8)
+    flow = conv(f0, 10, act=False)
+    svf = 0.5 * F.interpolate(flow, size=(8, 8, 8), mode="trilinear", align_corners=True)
+
+    def warp(v, u):  # v,u [1,C,8,8,8]; border grid_sample in voxel units
+        S = v.shape[2:]
+        g = torch.stack(torch.meshgrid(*[torch.arange(s, dtype=torch.float64) for s in S], indexing="ij"), 0)[None] + u
+        gn = torch.stack([2 * g[:, 2] / (S[2] - 1) - 1, 2 * g[:, 1] / (S[1] - 1) - 1, 2 * g[:, 0] / (S[0] - 1) - 1], -1)
+        return F.grid_sample(v, gn, mode="bilinear", padding_mode="border", align_corners=True)
+    v = svf / 8
+    for _ in range(3):
+        v = v + warp(v, v)
+    pos = F.interpolate(2 * v, size=shape, mode="trilinear", align_corners=True)
+    moved = warp(torch.from_numpy(mov).permute(0, 4, 1, 2, 3).double(), pos)
+    np.testing.assert_allclose(out["preint_flow"], svf.permute(0, 2, 3, 4, 1).numpy(), atol=2e-5)
+    np.testing.assert_allclose(out["pos_flow"], pos.permute(0, 2, 3, 4, 1).numpy(), atol=5e-5)
+    np.testing.assert_allclose(out["moved"], moved.permute(0, 2, 3, 4, 1).numpy(), atol=5e-5)
+
+
+def test_layer_plan_matches_keras_order():
+    plan = net_np.layer_plan([64] * 4, [64] * 6)
+    assert [p[0] for p in plan] == ["enc_conv_0", "enc_conv_1", "enc_conv_2", "enc_conv_3", "dec_conv_3", "dec_conv_2",
+                                    "dec_conv_1", "dec_conv_0", "dec_final_0", "dec_final_1", "flow"]
+    assert [p[1] for p in plan] == [2, 64, 64, 64, 64, 128, 128, 128, 128, 64, 64]
+    n = sum(27 * ci * co + co for _, ci, co in plan)
+    assert n == 1_454_211 or abs(n - 1.45e6) < 1e4  # SURVEY: 1.45 M params at 64 features
+    p256 = net_np.layer_plan([256] * 4, [256] * 6)
+    assert abs(sum(27 * ci * co + co for _, ci, co in p256) - 23.04e6) < 5e4
