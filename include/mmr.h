@@ -110,6 +110,28 @@ int64_t mmr_bending_ws_bytes(int B, int X, int Y, int Z);
 int mmr_bending_fwd_f32(const float* flow, float* out, void* ws,
                         int B, int X, int Y, int Z, void* stream);
 
+/* ---- SynthMorph generator (ne.models.labels_to_image / ne.utils.augment.draw_perlin,
+ * train_synthmorph.py:57-64,258-268,288-291; stages SURVEY.md Appendix A9/A10) ---- */
+/* Counter-based Philox4x32-10: out[i] depends only on (seed, stream_id, i). */
+int mmr_philox_normal_f32(float* out, int64_t n, uint64_t seed, uint32_t stream_id, float mean, float std, void* stream);
+int mmr_philox_uniform_f32(float* out, int64_t n, uint64_t seed, uint32_t stream_id, float lo, float hi, void* stream);
+/* label look-up (in_label_list -> 0..L-1), lut256 on device */
+int mmr_lut_u8(const uint8_t* in, uint8_t* out, const uint8_t* lut256, int64_t n, void* stream);
+/* image = mean[b,label] + std[b,label] * N(0,1); `noise` (optional, [B,nvox]) overrides the Philox draw */
+int mmr_gmm_sample_f32(const uint8_t* labels, const float* means, const float* stds, const float* noise, float* out,
+                       int B, int64_t nvox, int L, uint64_t seed, uint32_t stream_id, void* stream);
+/* one axis of the separable Gaussian blur, per-item kernel [B][W], 'SAME' zero padding */
+int mmr_blur_axis_f32(const float* in, float* out, const float* kern, int B, int X, int Y, int Z, int axis, int W,
+                      void* stream);
+/* x <- ((clip(x*exp(bias), lo, hi) - min_b)/(max_b - min_b)) ** exp(gamma[b]), in place; bias, gamma optional */
+int64_t mmr_intensity_ws_bytes(int B);
+int mmr_bias_clip_norm_gamma_f32(float* x, const float* bias, const float* gamma, void* ws, int B, int64_t nvox,
+                                 float lo, float hi, void* stream);
+int mmr_onehot_f32(const uint8_t* labels, float* out, int64_t n, int L, void* stream);
+/* tf.argmax(axis=-1) -> uint8 (generate_label_maps, train_synthmorph.py:68-69) */
+int mmr_argmax_u8(const float* x, uint8_t* out, int64_t n, int C, void* stream);
+int mmr_axpy_f32(float* y, const float* x, float a, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

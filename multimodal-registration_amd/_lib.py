@@ -5,7 +5,7 @@ and every entry point raises ``MmrError`` on a non-zero return code.
 """
 import ctypes
 import os
-from ctypes import c_float, c_int, c_int64, c_uint8, c_void_p
+from ctypes import c_float, c_int, c_int64, c_uint8, c_uint32, c_uint64, c_void_p
 
 from . import build as _build
 
@@ -38,6 +38,16 @@ SIGNATURES = {
     "mmr_ncc_fwd_f32": (I, [P, P, P, P, I, I, I, I, I, F, P]),
     "mmr_bending_ws_bytes": (c_int64, [I, I, I, I]),
     "mmr_bending_fwd_f32": (I, [P, P, P, I, I, I, I, P]),
+    "mmr_philox_normal_f32": (I, [P, c_int64, c_uint64, c_uint32, F, F, P]),
+    "mmr_philox_uniform_f32": (I, [P, c_int64, c_uint64, c_uint32, F, F, P]),
+    "mmr_lut_u8": (I, [P, P, P, c_int64, P]),
+    "mmr_gmm_sample_f32": (I, [P, P, P, P, P, I, c_int64, I, c_uint64, c_uint32, P]),
+    "mmr_blur_axis_f32": (I, [P, P, P, I, I, I, I, I, I, P]),
+    "mmr_intensity_ws_bytes": (c_int64, [I]),
+    "mmr_bias_clip_norm_gamma_f32": (I, [P, P, P, P, I, c_int64, F, F, P]),
+    "mmr_onehot_f32": (I, [P, P, c_int64, I, P]),
+    "mmr_argmax_u8": (I, [P, P, c_int64, I, P]),
+    "mmr_axpy_f32": (I, [P, P, F, c_int64, P]),
 }
 
 

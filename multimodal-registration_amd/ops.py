@@ -241,3 +241,107 @@ def bending_energy(flow):
     rc = lib.mmr_bending_fwd_f32(flow.data_ptr(), out.data_ptr(), ws.data_ptr(), B, X, Y, Z, _stream())
     _lib.check(rc, "mmr_bending_fwd_f32")
     return out
+
+
+# ------------------------------- generator ------------------------------ #
+def philox_normal(shape, seed, stream_id=0, mean=0.0, std=1.0, device="cuda"):
+    out = torch.empty(tuple(int(s) for s in shape), dtype=torch.float32, device=device)
+    rc = _lib.load().mmr_philox_normal_f32(out.data_ptr(), out.numel(), int(seed) & (2 ** 64 - 1), int(stream_id),
+                                           float(mean), float(std), _stream())
+    _lib.check(rc, "mmr_philox_normal_f32")
+    return out
+
+
+def philox_uniform(shape, seed, stream_id=0, lo=0.0, hi=1.0, device="cuda"):
+    out = torch.empty(tuple(int(s) for s in shape), dtype=torch.float32, device=device)
+    rc = _lib.load().mmr_philox_uniform_f32(out.data_ptr(), out.numel(), int(seed) & (2 ** 64 - 1), int(stream_id),
+                                            float(lo), float(hi), _stream())
+    _lib.check(rc, "mmr_philox_uniform_f32")
+    return out
+
+
+def lut_u8(labels, lut256):
+    _chk(labels, torch.uint8, "labels")
+    _chk(lut256, torch.uint8, "lut")
+    if lut256.numel() != 256:
+        raise _lib.MmrError("lut must have 256 entries")
+    out = torch.empty_like(labels)
+    rc = _lib.load().mmr_lut_u8(labels.data_ptr(), out.data_ptr(), lut256.data_ptr(), labels.numel(), _stream())
+    _lib.check(rc, "mmr_lut_u8")
+    return out
+
+
+def gmm_sample(labels, means, stds, seed=0, stream_id=0, noise=None):
+    """labels u8 [B,...], means/stds f32 [B,L] -> image f32 of labels' shape."""
+    _chk(labels, torch.uint8, "labels")
+    _chk(means, torch.float32, "means")
+    _chk(stds, torch.float32, "stds")
+    B, L = means.shape
+    nvox = labels.numel() // B
+    if noise is not None:
+        _chk(noise, torch.float32, "noise")
+        if noise.numel() != labels.numel():
+            raise _lib.MmrError("noise size mismatch")
+    out = torch.empty(labels.shape, dtype=torch.float32, device=labels.device)
+    rc = _lib.load().mmr_gmm_sample_f32(labels.data_ptr(), means.data_ptr(), stds.data_ptr(),
+                                        noise.data_ptr() if noise is not None else None, out.data_ptr(), B, nvox, L,
+                                        int(seed) & (2 ** 64 - 1), int(stream_id), _stream())
+    _lib.check(rc, "mmr_gmm_sample_f32")
+    return out
+
+
+def blur_separable(x, kernels):
+    """x f32 [B,X,Y,Z] (or [...,1]); kernels f32 [B,W] applied along x, y, z ('SAME' zero padding)."""
+    _chk(x, torch.float32, "x")
+    _chk(kernels, torch.float32, "kernels")
+    B, X, Y, Z = x.shape[:4]
+    W = kernels.shape[1]
+    a, b = x, torch.empty_like(x)
+    lib = _lib.load()
+    for axis in range(3):
+        rc = lib.mmr_blur_axis_f32(a.data_ptr(), b.data_ptr(), kernels.data_ptr(), B, X, Y, Z, axis, W, _stream())
+        _lib.check(rc, "mmr_blur_axis_f32")
+        a, b = b, (torch.empty_like(x) if axis == 0 else a)
+    return a
+
+
+def bias_clip_norm_gamma_(x, bias=None, gamma=None, lo=0.0, hi=255.0):
+    """In place: x <- ((clip(x*exp(bias), lo, hi) - min_b)/(max_b - min_b)) ** exp(gamma[b])."""
+    _chk(x, torch.float32, "x")
+    B = x.shape[0]
+    nvox = x.numel() // B
+    lib = _lib.load()
+    ws = _ws(lib.mmr_intensity_ws_bytes(B), x.device)
+    rc = lib.mmr_bias_clip_norm_gamma_f32(x.data_ptr(), _chk(bias, torch.float32, "bias").data_ptr() if bias is not None else None,
+                                          _chk(gamma, torch.float32, "gamma").data_ptr() if gamma is not None else None,
+                                          ws.data_ptr(), B, nvox, float(lo), float(hi), _stream())
+    _lib.check(rc, "mmr_bias_clip_norm_gamma_f32")
+    return x
+
+
+def onehot(labels, L):
+    _chk(labels, torch.uint8, "labels")
+    shp = labels.shape[:-1] if labels.shape[-1] == 1 else labels.shape
+    out = torch.empty(tuple(shp) + (int(L),), dtype=torch.float32, device=labels.device)
+    rc = _lib.load().mmr_onehot_f32(labels.data_ptr(), out.data_ptr(), labels.numel(), int(L), _stream())
+    _lib.check(rc, "mmr_onehot_f32")
+    return out
+
+
+def argmax_u8(x):
+    _chk(x, torch.float32, "x")
+    C = x.shape[-1]
+    out = torch.empty(x.shape[:-1], dtype=torch.uint8, device=x.device)
+    rc = _lib.load().mmr_argmax_u8(x.data_ptr(), out.data_ptr(), out.numel(), C, _stream())
+    _lib.check(rc, "mmr_argmax_u8")
+    return out
+
+
+def axpy_(y, x, a=1.0):
+    _chk(y, torch.float32, "y")
+    _chk(x, torch.float32, "x")
+    if y.numel() != x.numel():
+        raise _lib.MmrError("axpy size mismatch")
+    rc = _lib.load().mmr_axpy_f32(y.data_ptr(), x.data_ptr(), float(a), y.numel(), _stream())
+    _lib.check(rc, "mmr_axpy_f32")
+    return y

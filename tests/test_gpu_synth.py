@@ -1,0 +1,101 @@
+"""SynthMorph generator on device vs the NumPy restatement, same injected draws."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cpu(x):
+    return x.cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+def test_philox_statistics_and_determinism(dev):
+    import mmr
+    a = mmr.ops.philox_normal((1 << 20,), seed=123, stream_id=1)
+    b = mmr.ops.philox_normal((1 << 20,), seed=123, stream_id=1)
+    c = mmr.ops.philox_normal((1 << 20,), seed=124, stream_id=1)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    x = a.cpu().numpy().astype(np.float64)
+    assert abs(x.mean()) < 5e-3 and abs(x.std() - 1) < 5e-3
+    assert abs((x ** 3).mean()) < 2e-2 and abs((x ** 4).mean() - 3) < 5e-2
+    assert abs(np.corrcoef(x[:-1], x[1:])[0, 1]) < 5e-3
+    u = mmr.ops.philox_uniform((1 << 20,), seed=5, lo=2.0, hi=4.0).cpu().numpy()
+    assert u.min() >= 2 and u.max() <= 4 and abs(u.mean() - 3) < 5e-3 and abs(u.var() - 4 / 12) < 5e-3
+    # prefix property: element i does not depend on n or launch geometry
+    short = mmr.ops.philox_normal((1000,), seed=123, stream_id=1)
+    assert torch.equal(short, a[:1000])
+
+
+@pytest.mark.parametrize("out_shape,scales", [((16, 12, 20, 3), [4, 8]), ((16, 16, 16, 5, 3), [2, 4, 8]), ((8, 8, 8, 2), [1, 4])])
+def test_draw_perlin_matches_oracle(dev, out_shape, scales):
+    import mmr
+    from mmr import synth
+    from oracle import synth_np
+    got = synth.draw_perlin(out_shape, scales, max_std=2.0, seed=3)
+    rec = synth.draw_perlin.last_draws
+    ref = synth_np.perlin(out_shape, scales, rec["stds"], [_cpu(n) for n in rec["noise"]])
+    assert tuple(got.shape) == tuple(out_shape)
+    np.testing.assert_allclose(_cpu(got), ref, atol=2e-5)
+    assert np.abs(ref).max() > 0.1
+
+
+def test_labels_to_image_matches_oracle(dev):
+    from mmr import synth
+    from oracle import synth_np
+    shape, L, B = (32, 32, 48), 6, 2
+    rng = np.random.default_rng(0)
+    coarse = rng.integers(0, L, (B, 8, 8, 12))
+    lab = np.repeat(np.repeat(np.repeat(coarse, 4, 1), 4, 2), 4, 3).astype(np.uint8)[..., None]
+    gen = synth.labels_to_image(in_shape=shape, in_label_list=np.arange(L), out_label_list=np.arange(L), warp_std=3,
+                                warp_res=16, blur_std=1, bias_std=0.3, bias_res=40, gamma_std=0.25, id=0, seed=1)
+    draws = gen.draw(B)
+    draws["gmm_noise"] = rng.standard_normal((B,) + shape).astype(np.float32)
+    out = gen.generate(lab, draws=draws)
+    rec = gen.last_draws
+    d = dict(draws)
+    d["vel_noise"] = [[_cpu(n) for n in per_b] for per_b in rec["vel_noise"]]
+    d["bias_noise"] = [[_cpu(n) for n in per_b] for per_b in rec["bias_noise"]]
+    img, labs, onehot = synth_np.labels_to_image(lab, L, d, warp_res=[16], bias_res=[40], blur_std=1)
+    got_lab = _cpu(out["labels"])
+    assert got_lab.dtype == np.uint8
+    mism = (got_lab != labs).mean()
+    assert mism == 0, f"label mismatch fraction {mism}"  # nearest-neighbour label resampling is bit-exact
+    assert np.array_equal(_cpu(out["onehot"]), onehot)
+    assert (got_lab != lab).mean() > 0.05, "warp should move labels"
+    gi = _cpu(out["image"])
+    assert gi.shape == (B,) + shape + (1,) and gi.min() >= 0 and gi.max() <= 1
+    np.testing.assert_allclose(gi, img, atol=2e-4)
+
+
+def test_labels_to_image_philox_path_and_label_lut(dev):
+    from mmr import synth
+    shape = (16, 16, 32)
+    rng = np.random.default_rng(1)
+    vals = np.array([0, 3, 7, 200])
+    lab = vals[rng.integers(0, 4, (1,) + shape)].astype(np.uint8)[..., None]
+    gen = synth.labels_to_image(in_shape=shape, in_label_list=vals, out_label_list=vals, warp_std=0, blur_std=0,
+                                bias_std=0, gamma_std=0, zero_background=0, seed=2)
+    img, onehot = gen(lab)
+    assert tuple(onehot.shape) == (1,) + shape + (4,)
+    idx = np.searchsorted(vals, lab[..., 0])
+    assert np.array_equal(onehot.cpu().numpy().argmax(-1), idx)
+    i1 = img.cpu().numpy()
+    assert i1.min() == 0 and i1.max() == 1 and np.isfinite(i1).all()
+    # per-label statistics follow the drawn GMM parameters (before min-max normalisation ordering is monotone)
+    d = gen.last_draws
+    order_true = np.argsort(d["means"][0])
+    means_img = np.array([i1[0, ..., 0][idx[0] == k].mean() for k in range(4)])
+    assert np.array_equal(np.argsort(means_img), order_true)
+
+
+def test_generate_label_maps(dev):
+    from mmr import synth
+    maps = synth.generate_label_maps((32, 32, 32), 6, 2, [8, 16], [4, 8], 1, 3, seed=0)
+    assert len(maps) == 2 and maps[0].shape == (32, 32, 32) and maps[0].dtype == np.uint8
+    assert maps[0].max() <= 5 and len(np.unique(maps[0])) >= 4
+    assert not np.array_equal(maps[0], maps[1])
+    again = synth.generate_label_maps((32, 32, 32), 6, 2, [8, 16], [4, 8], 1, 3, seed=0)
+    assert np.array_equal(maps[0], again[0])
+    shard1 = synth.generate_label_maps((32, 32, 32), 6, 2, [8, 16], [4, 8], 1, 3, seed=0, shard=(1, 2))
+    assert len(shard1) == 1 and np.array_equal(shard1[0], maps[1])
