@@ -132,6 +132,55 @@ int mmr_onehot_f32(const uint8_t* labels, float* out, int64_t n, int L, void* st
 int mmr_argmax_u8(const float* x, uint8_t* out, int64_t n, int C, void* stream);
 int mmr_axpy_f32(float* y, const float* x, float a, int64_t n, void* stream);
 
+/* ---- training: backward kernels + Adam (train_synthmorph.py:296-308,335-344), all fp32 ---- */
+/* Dice(one_hot(lab2), SpatialTransformer('linear')(one_hot(lab1), flow)) computed from the uint8 label
+ * volumes (never materialising the L-channel tensors): loss[0], top_bot[B][L][2] = (2 sum tp, sum t+p). */
+int64_t mmr_dice_labels_ws_bytes(int B, int64_t nvox, int L);
+int mmr_dice_labels_fwd(const uint8_t* lab1, const uint8_t* lab2, const float* flow, float* loss, float* top_bot,
+                        void* ws, int B, int X, int Y, int Z, int L, void* stream);
+/* dflow (+)= scale * d loss / d flow */
+int mmr_dice_labels_bwd(const uint8_t* lab1, const uint8_t* lab2, const float* flow, const float* top_bot,
+                        float* dflow, int B, int X, int Y, int Z, int L, float scale, int accumulate, void* stream);
+/* dflow (+)= scale * d/dflow sum_b Grad('l2', loss_mult)(flow)[b] */
+int mmr_grad_l2_bwd_f32(const float* flow, float* dflow, int B, int X, int Y, int Z, int C, float loss_mult,
+                        float scale, int accumulate, void* stream);
+/* adjoint of mmr_resize_trilinear_f32 (din is overwritten) */
+int mmr_resize_trilinear_bwd_f32(const float* dout, float* din, int B, int X, int Y, int Z, int C,
+                                 int Xo, int Yo, int Zo, float mul, void* stream);
+/* adjoint of mmr_compose_f32: da, db overwritten (da == db allowed when a == b) */
+int mmr_compose_bwd_f32(const float* a, const float* b, const float* dout, float* da, float* db,
+                        int B, int X, int Y, int Z, void* stream);
+/* VecInt forward keeping per-step inputs (steps: [nsteps-1][B,X,Y,Z,3]) and its adjoint */
+int mmr_vecint_save_f32(const float* vel, float* steps, float* out, int B, int X, int Y, int Z, int nsteps, void* stream);
+int mmr_vecint_bwd_f32(const float* vel, const float* steps, const float* dout, float* dvel, float* tmp,
+                       int B, int X, int Y, int Z, int nsteps, void* stream);
+/* SpatialTransformer('linear') gradients */
+int mmr_warp3d_bwd_flow_f32(const float* vol, const float* flow, const float* dout, float* dflow,
+                            int B, int X, int Y, int Z, int C, void* stream);
+int mmr_warp3d_bwd_vol_f32(const float* flow, const float* dout, float* dvol, int B, int X, int Y, int Z, int C, void* stream);
+/* dz = dy * LeakyReLU'(y) (y = activated output; in place allowed) and dbias (+)= sum_v dz */
+int64_t mmr_leaky_bwd_ws_bytes(int64_t nvox, int C);
+int mmr_leaky_bwd_bias_f32(const float* y, const float* dy, float* dz, float* dbias, void* ws, int64_t nvox, int C,
+                           int leaky, float alpha, int accumulate, void* stream);
+/* gradient of concatenate([UpSampling3D(2)(in0) | in0, in1]) split into its two sources */
+int mmr_upcat_bwd_f32(const float* dcat, float* d_in0, float* d_in1, int B, int X, int Y, int Z, int C0, int C1,
+                      int up0, int accumulate_in1, void* stream);
+int mmr_maxpool3d2_bwd_f32(const float* x, const float* dpool, float* dx, int B, int X, int Y, int Z, int C,
+                           int accumulate, void* stream);
+/* conv weight gradients, Keras layout [27][Cin][Cout]; MFMA over voxels, ordered slab reduction */
+int64_t mmr_conv3d_k3_wgrad_ws_bytes(int B, int X, int Y, int Z, int Cin, int Cout);
+int mmr_conv3d_k3_wgrad_f32(const float* in0, int C0, int up0, const float* in1, int C1, const float* dz, float* dw,
+                            void* ws, int B, int X, int Y, int Z, int Cout, int accumulate, void* stream);
+int64_t mmr_conv3d_k3_cin2_wgrad_ws_bytes(int Cout);
+int mmr_conv3d_k3_cin2_wgrad_f32(const float* src, const float* trg, const float* dz, float* dw, void* ws,
+                                 int B, int X, int Y, int Z, int Cout, int accumulate, void* stream);
+/* flow head (Cout = 3) input gradient */
+int mmr_conv3d_k3_cout3_dgrad_f32(const float* dy, const float* w_keras, float* dx, int B, int X, int Y, int Z, int Cin,
+                                  void* stream);
+/* Keras Adam on one flat parameter buffer: g is multiplied by grad_scale first (1/world after a SUM all-reduce) */
+int mmr_adam_step_f32(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                      float eps, int64_t step, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

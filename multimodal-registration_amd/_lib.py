@@ -48,6 +48,26 @@ SIGNATURES = {
     "mmr_onehot_f32": (I, [P, P, c_int64, I, P]),
     "mmr_argmax_u8": (I, [P, P, c_int64, I, P]),
     "mmr_axpy_f32": (I, [P, P, F, c_int64, P]),
+    "mmr_dice_labels_ws_bytes": (c_int64, [I, c_int64, I]),
+    "mmr_dice_labels_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
+    "mmr_dice_labels_bwd": (I, [P, P, P, P, P, I, I, I, I, I, F, I, P]),
+    "mmr_grad_l2_bwd_f32": (I, [P, P, I, I, I, I, I, F, F, I, P]),
+    "mmr_resize_trilinear_bwd_f32": (I, [P, P, I, I, I, I, I, I, I, I, F, P]),
+    "mmr_compose_bwd_f32": (I, [P, P, P, P, P, I, I, I, I, P]),
+    "mmr_vecint_save_f32": (I, [P, P, P, I, I, I, I, I, P]),
+    "mmr_vecint_bwd_f32": (I, [P, P, P, P, P, I, I, I, I, I, P]),
+    "mmr_warp3d_bwd_flow_f32": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "mmr_warp3d_bwd_vol_f32": (I, [P, P, P, I, I, I, I, I, P]),
+    "mmr_leaky_bwd_ws_bytes": (c_int64, [c_int64, I]),
+    "mmr_leaky_bwd_bias_f32": (I, [P, P, P, P, P, c_int64, I, I, F, I, P]),
+    "mmr_upcat_bwd_f32": (I, [P, P, P, I, I, I, I, I, I, I, I, P]),
+    "mmr_maxpool3d2_bwd_f32": (I, [P, P, P, I, I, I, I, I, I, P]),
+    "mmr_conv3d_k3_wgrad_ws_bytes": (c_int64, [I, I, I, I, I, I]),
+    "mmr_conv3d_k3_wgrad_f32": (I, [P, I, I, P, I, P, P, P, I, I, I, I, I, I, P]),
+    "mmr_conv3d_k3_cin2_wgrad_ws_bytes": (c_int64, [I]),
+    "mmr_conv3d_k3_cin2_wgrad_f32": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
+    "mmr_conv3d_k3_cout3_dgrad_f32": (I, [P, P, P, I, I, I, I, I, P]),
+    "mmr_adam_step_f32": (I, [P, P, P, P, c_int64, F, F, F, F, c_int64, F, P]),
 }
 
 

@@ -242,3 +242,30 @@ extern "C" int mmr_vecint_f32(const float* vel, float* out, float* tmp, int B, i
     }
     return MMR_OK;
 }
+
+// Forward scaling-and-squaring that keeps the input of every squaring step for the backward pass:
+// steps[k-1] = output of step k-1 (k = 1..nsteps-1), out = output of the last step.
+extern "C" int mmr_vecint_save_f32(const float* vel, float* steps, float* out, int B, int X, int Y, int Z, int nsteps,
+                                   void* stream)
+{
+    if (!vel || !out || B < 1 || X < 1 || Y < 1 || Z < 1 || nsteps < 0 || nsteps > 30) return MMR_EINVAL;
+    if (nsteps > 1 && !steps) return MMR_EINVAL;
+    const int64_t total = (int64_t)B * X * Y * Z * 3;
+    hipStream_t st = as_stream(stream);
+    if (nsteps == 0) {
+        if (hipMemcpyAsync(out, vel, total * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return MMR_EHIP;
+        return MMR_OK;
+    }
+    const int grid = stream_grid(total, 256);
+    const float* src = vel;
+    float s = 1.0f / (float)(1 << nsteps);
+    for (int k = 0; k < nsteps; ++k) {
+        float* dst = (k == nsteps - 1) ? out : steps + (int64_t)k * total;
+        hipLaunchKernelGGL(compose_kernel, dim3(grid), dim3(256), 0, st, src, src, dst, B, X, Y, Z, s);
+        int rc = check_launch();
+        if (rc) return rc;
+        src = dst;
+        s = 1.0f;
+    }
+    return MMR_OK;
+}

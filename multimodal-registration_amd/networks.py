@@ -103,19 +103,27 @@ class VxmDense:
 
     # ------------------------------------------------------------------ weights
     def _init_weights(self, seed):
+        """All 22 arrays live in ONE flat fp32 buffer (views in Keras order) so that Adam and the
+        data-parallel all-reduce are a single launch / a single collective."""
         g = torch.Generator(device="cpu").manual_seed(int(seed))
-        self._w = []
+        shapes = []
         for name_, cin, cout in self.plan:
+            shapes += [(3, 3, 3, sum(cin), cout), (cout,)]
+        sizes = [int(np.prod(s)) for s in shapes]
+        self._flat = torch.zeros(sum(sizes), dtype=torch.float32, device=self.device)
+        self._w, off = [], 0
+        for shp, n in zip(shapes, sizes):
+            self._w.append(self._flat[off:off + n].view(shp))
+            off += n
+        for i, (name_, cin, cout) in enumerate(self.plan):
             ci = sum(cin)
             if name_ == "flow":
-                std = 1e-5  # RandomNormal(0, 1e-5)
-                w = torch.randn((3, 3, 3, ci, cout), generator=g) * std
+                w = torch.randn((3, 3, 3, ci, cout), generator=g) * 1e-5  # RandomNormal(0, 1e-5)
             else:  # he_normal = truncated normal, stddev sqrt(2/fan_in)/0.8796
                 std = math.sqrt(2.0 / (27 * ci)) / 0.87962566103423978
                 w = torch.empty((3, 3, 3, ci, cout))
                 torch.nn.init.trunc_normal_(w, 0.0, std, -2 * std, 2 * std, generator=g)
-            self._w.append(w.to(self.device).contiguous())
-            self._w.append(torch.zeros(cout, device=self.device))
+            self._w[2 * i].copy_(w)
         self._packed = None
 
     def get_weights(self):
@@ -124,13 +132,18 @@ class VxmDense:
     def set_weights(self, weights):
         if len(weights) != len(self._w):
             raise ValueError(f"expected {len(self._w)} arrays, got {len(weights)}")
-        new = []
+        staged = []
         for cur, w in zip(self._w, weights):
             w = to_device(np.asarray(w) if not isinstance(w, torch.Tensor) else w, device=self.device)
             if tuple(w.shape) != tuple(cur.shape):
                 raise ValueError(f"weight shape {tuple(w.shape)} does not match {tuple(cur.shape)}")
-            new.append(w)
-        self._w = new
+            staged.append(w)
+        for cur, w in zip(self._w, staged):
+            cur.copy_(w)
+        self._packed = None
+
+    def invalidate_packed(self):
+        """Call after the flat parameter buffer was updated in place (optimizer step)."""
         self._packed = None
 
     def _pack(self):

@@ -345,3 +345,190 @@ def axpy_(y, x, a=1.0):
     rc = _lib.load().mmr_axpy_f32(y.data_ptr(), x.data_ptr(), float(a), y.numel(), _stream())
     _lib.check(rc, "mmr_axpy_f32")
     return y
+
+
+# ------------------------------- training ------------------------------- #
+def dice_labels_fwd(lab1, lab2, flow, L):
+    """Dice(one_hot(lab2), warp_linear(one_hot(lab1), flow)) from uint8 label maps [B,X,Y,Z(,1)]."""
+    _chk(lab1, torch.uint8, "lab1")
+    _chk(lab2, torch.uint8, "lab2")
+    _chk(flow, torch.float32, "flow")
+    B, X, Y, Z = flow.shape[:4]
+    if lab1.numel() != B * X * Y * Z or lab2.numel() != lab1.numel():
+        raise _lib.MmrError("label / flow shape mismatch")
+    lib = _lib.load()
+    ws = _ws(lib.mmr_dice_labels_ws_bytes(B, X * Y * Z, L), flow.device)
+    loss = torch.empty(1, dtype=torch.float32, device=flow.device)
+    tb = torch.empty((B, L, 2), dtype=torch.float32, device=flow.device)
+    rc = lib.mmr_dice_labels_fwd(lab1.data_ptr(), lab2.data_ptr(), flow.data_ptr(), loss.data_ptr(), tb.data_ptr(),
+                                 ws.data_ptr(), B, X, Y, Z, int(L), _stream())
+    _lib.check(rc, "mmr_dice_labels_fwd")
+    return loss[0], tb
+
+
+def dice_labels_bwd(lab1, lab2, flow, top_bot, L, scale=1.0, out=None):
+    B, X, Y, Z = flow.shape[:4]
+    acc = out is not None
+    if out is None:
+        out = torch.empty_like(flow)
+    rc = _lib.load().mmr_dice_labels_bwd(lab1.data_ptr(), lab2.data_ptr(), flow.data_ptr(), top_bot.data_ptr(),
+                                         out.data_ptr(), B, X, Y, Z, int(L), float(scale), int(acc), _stream())
+    _lib.check(rc, "mmr_dice_labels_bwd")
+    return out
+
+
+def grad_l2_bwd(flow, loss_mult=1.0, scale=1.0, out=None):
+    _chk(flow, torch.float32, "flow")
+    B, X, Y, Z, C = flow.shape
+    acc = out is not None
+    if out is None:
+        out = torch.empty_like(flow)
+    rc = _lib.load().mmr_grad_l2_bwd_f32(flow.data_ptr(), out.data_ptr(), B, X, Y, Z, C, float(loss_mult), float(scale),
+                                         int(acc), _stream())
+    _lib.check(rc, "mmr_grad_l2_bwd_f32")
+    return out
+
+
+def resize_trilinear_bwd(dout, in_shape, mul=1.0):
+    """Adjoint of resize_trilinear: dout [B,Xo,Yo,Zo,C] -> din [B,*in_shape,C]."""
+    _chk(dout, torch.float32, "dout")
+    B, Xo, Yo, Zo, C = dout.shape
+    X, Y, Z = (int(s) for s in in_shape)
+    din = torch.empty((B, X, Y, Z, C), dtype=torch.float32, device=dout.device)
+    rc = _lib.load().mmr_resize_trilinear_bwd_f32(dout.data_ptr(), din.data_ptr(), B, X, Y, Z, C, Xo, Yo, Zo, float(mul), _stream())
+    _lib.check(rc, "mmr_resize_trilinear_bwd_f32")
+    return din
+
+
+def compose_bwd(a, b, dout):
+    _chk(dout, torch.float32, "dout")
+    B, X, Y, Z, _ = a.shape
+    da, db = torch.empty_like(a), torch.empty_like(b)
+    rc = _lib.load().mmr_compose_bwd_f32(a.data_ptr(), b.data_ptr(), dout.data_ptr(), da.data_ptr(), db.data_ptr(), B, X, Y, Z, _stream())
+    _lib.check(rc, "mmr_compose_bwd_f32")
+    return da, db
+
+
+def vecint_save(vel, nsteps):
+    """-> (out, steps) with steps [max(nsteps-1,0), B,X,Y,Z,3] = inputs of squaring steps 1..n-1."""
+    _chk(vel, torch.float32, "vel")
+    B, X, Y, Z, _ = vel.shape
+    out = torch.empty_like(vel)
+    steps = torch.empty((max(nsteps - 1, 0),) + tuple(vel.shape), dtype=torch.float32, device=vel.device)
+    rc = _lib.load().mmr_vecint_save_f32(vel.data_ptr(), steps.data_ptr() if nsteps > 1 else None, out.data_ptr(),
+                                         B, X, Y, Z, int(nsteps), _stream())
+    _lib.check(rc, "mmr_vecint_save_f32")
+    return out, steps
+
+
+def vecint_bwd(vel, steps, dout, nsteps):
+    B, X, Y, Z, _ = vel.shape
+    dvel, tmp = torch.empty_like(vel), torch.empty_like(vel)
+    rc = _lib.load().mmr_vecint_bwd_f32(vel.data_ptr(), steps.data_ptr() if nsteps > 1 else None, dout.data_ptr(),
+                                        dvel.data_ptr(), tmp.data_ptr(), B, X, Y, Z, int(nsteps), _stream())
+    _lib.check(rc, "mmr_vecint_bwd_f32")
+    return dvel
+
+
+def warp3d_bwd(vol, flow, dout, need_vol=True, need_flow=True):
+    """Gradients of warp3d(vol, flow, 'linear') -> (dvol | None, dflow | None)."""
+    _chk(vol, torch.float32, "vol")
+    _chk(flow, torch.float32, "flow")
+    _chk(dout, torch.float32, "dout")
+    B, X, Y, Z, C = vol.shape
+    lib = _lib.load()
+    dvol = dflow = None
+    if need_flow:
+        dflow = torch.empty_like(flow)
+        _lib.check(lib.mmr_warp3d_bwd_flow_f32(vol.data_ptr(), flow.data_ptr(), dout.data_ptr(), dflow.data_ptr(),
+                                               B, X, Y, Z, C, _stream()), "mmr_warp3d_bwd_flow_f32")
+    if need_vol:
+        dvol = torch.empty_like(vol)
+        _lib.check(lib.mmr_warp3d_bwd_vol_f32(flow.data_ptr(), dout.data_ptr(), dvol.data_ptr(), B, X, Y, Z, C, _stream()),
+                   "mmr_warp3d_bwd_vol_f32")
+    return dvol, dflow
+
+
+def leaky_bwd_bias_(y, dy, dbias, leaky=True, alpha=0.2, accumulate=False):
+    """In place: dy <- dy * LeakyReLU'(y); dbias (+)= sum over voxels."""
+    _chk(dy, torch.float32, "dy")
+    C = dy.shape[-1]
+    nvox = dy.numel() // C
+    lib = _lib.load()
+    ws = _ws(lib.mmr_leaky_bwd_ws_bytes(nvox, C), dy.device)
+    rc = lib.mmr_leaky_bwd_bias_f32(y.data_ptr() if y is not None else None, dy.data_ptr(), dy.data_ptr(),
+                                    dbias.data_ptr(), ws.data_ptr(), nvox, C, int(leaky), float(alpha), int(accumulate), _stream())
+    _lib.check(rc, "mmr_leaky_bwd_bias_f32")
+    return dy
+
+
+def upcat_bwd(dcat, C0, C1, up0, d_in1=None):
+    """Split d concat([up2(in0)|in0, in1]) -> (d_in0, d_in1); accumulates into d_in1 when given."""
+    _chk(dcat, torch.float32, "dcat")
+    B, X, Y, Z, C = dcat.shape
+    s0 = (B, X // 2, Y // 2, Z // 2, C0) if up0 else (B, X, Y, Z, C0)
+    d0 = torch.empty(s0, dtype=torch.float32, device=dcat.device)
+    acc = d_in1 is not None
+    if C1 > 0 and d_in1 is None:
+        d_in1 = torch.empty((B, X, Y, Z, C1), dtype=torch.float32, device=dcat.device)
+    rc = _lib.load().mmr_upcat_bwd_f32(dcat.data_ptr(), d0.data_ptr(), d_in1.data_ptr() if C1 > 0 else None,
+                                       B, X, Y, Z, C0, C1, int(up0), int(acc), _stream())
+    _lib.check(rc, "mmr_upcat_bwd_f32")
+    return d0, d_in1
+
+
+def maxpool3d2_bwd(x, dpool, dx=None):
+    _chk(x, torch.float32, "x")
+    _chk(dpool, torch.float32, "dpool")
+    B, X, Y, Z, C = x.shape
+    acc = dx is not None
+    if dx is None:
+        dx = torch.empty_like(x)
+    rc = _lib.load().mmr_maxpool3d2_bwd_f32(x.data_ptr(), dpool.data_ptr(), dx.data_ptr(), B, X, Y, Z, C, int(acc), _stream())
+    _lib.check(rc, "mmr_maxpool3d2_bwd_f32")
+    return dx
+
+
+def conv3d_k3_wgrad(in0, dz, dw, in1=None, up0=False, accumulate=False):
+    """dw [3,3,3,C0+C1,Cout] (+)= weight gradient of conv3d_k3(in0, .., in1=in1, up0=up0) given dz."""
+    _chk(in0, torch.float32, "in0")
+    _chk(dz, torch.float32, "dz")
+    _chk(dw, torch.float32, "dw")
+    B, X, Y, Z, Cout = dz.shape
+    C0 = in0.shape[-1]
+    C1 = in1.shape[-1] if in1 is not None else 0
+    lib = _lib.load()
+    ws = _ws(lib.mmr_conv3d_k3_wgrad_ws_bytes(B, X, Y, Z, C0 + C1, Cout), dz.device)
+    rc = lib.mmr_conv3d_k3_wgrad_f32(in0.data_ptr(), C0, int(up0), in1.data_ptr() if in1 is not None else None, C1,
+                                     dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, X, Y, Z, Cout, int(accumulate), _stream())
+    _lib.check(rc, "mmr_conv3d_k3_wgrad_f32")
+    return dw
+
+
+def conv3d_k3_cin2_wgrad(src, trg, dz, dw, accumulate=False):
+    B, X, Y, Z, Cout = dz.shape
+    lib = _lib.load()
+    ws = _ws(lib.mmr_conv3d_k3_cin2_wgrad_ws_bytes(Cout), dz.device)
+    rc = lib.mmr_conv3d_k3_cin2_wgrad_f32(src.data_ptr(), trg.data_ptr(), dz.data_ptr(), dw.data_ptr(), ws.data_ptr(),
+                                          B, X, Y, Z, Cout, int(accumulate), _stream())
+    _lib.check(rc, "mmr_conv3d_k3_cin2_wgrad_f32")
+    return dw
+
+
+def conv3d_k3_cout3_dgrad(dy, w_keras):
+    _chk(dy, torch.float32, "dy")
+    B, X, Y, Z, _ = dy.shape
+    Cin = w_keras.shape[3]
+    dx = torch.empty((B, X, Y, Z, Cin), dtype=torch.float32, device=dy.device)
+    rc = _lib.load().mmr_conv3d_k3_cout3_dgrad_f32(dy.data_ptr(), w_keras.data_ptr(), dx.data_ptr(), B, X, Y, Z, Cin, _stream())
+    _lib.check(rc, "mmr_conv3d_k3_cout3_dgrad_f32")
+    return dx
+
+
+def adam_step_(w, g, m, v, step, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+    for t, n in ((w, "w"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, torch.float32, n)
+    rc = _lib.load().mmr_adam_step_f32(w.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), w.numel(), float(lr),
+                                       float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _stream())
+    _lib.check(rc, "mmr_adam_step_f32")
+    return w

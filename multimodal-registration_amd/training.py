@@ -1,0 +1,291 @@
+"""SynthMorph training step on MI355X: generators -> VxmDense forward -> Dice + Grad-l2 ->
+hand-written backward -> (RCCL all-reduce) -> Adam.
+
+Behaviour reproduced (train_synthmorph.py:284-344):
+  * per-replica loss vector [b] = (Dice(map_2, pred) + 1) + Grad('l2', reg_param)(flow)[b];
+    Keras differentiates its SUM and scales by 1/num_replicas, the replicas' gradients are
+    SUM-all-reduced; the logged loss is the vector's mean;
+  * Adam(lr) with Keras defaults beta1 .9, beta2 .999, eps 1e-7;
+  * ModelCheckpoint('{epoch:04d}') every save_freq epochs, initial save, init_weights / init_epoch.
+The autograd graph is not used: the backward pass is an explicit reverse walk over a tape of
+kernel launches (all HIP, fp32).  One process per GPU; batch sharded by rank.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import ops
+from .layers import to_device
+
+
+class Adam:
+    """Keras-style Adam over ONE flat parameter buffer (single fused launch)."""
+
+    def __init__(self, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        self.lr, self.b1, self.b2, self.eps = learning_rate, beta_1, beta_2, epsilon
+        self.t = 0
+        self.m = self.v = None
+
+    def apply(self, flat_w, flat_g, grad_scale=1.0):
+        if self.m is None:
+            self.m, self.v = torch.zeros_like(flat_w), torch.zeros_like(flat_w)
+        self.t += 1
+        ops.adam_step_(flat_w, flat_g, self.m, self.v, self.t, self.lr, self.b1, self.b2, self.eps, grad_scale)
+
+    def state_dict(self):
+        return {"t": self.t, "m": self.m, "v": self.v}
+
+
+class SynthMorphTrainer:
+    """model: fp32 VxmDense; gen_1/gen_2: synth.LabelsToImage (sharing the label list)."""
+
+    def __init__(self, model, gen_1, gen_2, reg_param=1.0, optimizer=None, zero_pad_dice=False,
+                 process_group=None, world_size=1, rank=0):
+        if model.dtype != torch.float32:
+            raise NotImplementedError("training runs the fp32 path (the reference trains in fp32)")
+        self.model, self.gen_1, self.gen_2 = model, gen_1, gen_2
+        self.L = gen_1.L
+        self.reg_param = float(reg_param)
+        self.opt = optimizer or Adam(1e-4)
+        self.zero_pad_dice = zero_pad_dice
+        self.pg, self.world, self.rank = process_group, int(world_size), int(rank)
+        self.gflat = torch.zeros_like(model._flat)
+        self.g, off = [], 0
+        for w in model._w:
+            n = w.numel()
+            self.g.append(self.gflat[off:off + n].view(w.shape))
+            off += n
+        self.timers = None
+
+    # ------------------------------------------------------------------ forward with tape
+    def _forward(self, src, trg, tape):
+        m = self.model
+        m._pack()
+        w, nlev = m._w, len(m.enc)
+        last = ops.conv3d_k3_cin2(src, trg, w[0], w[1], torch.float32)
+        tape.append(("conv0", 0, src, trg, last))
+        skips = [last]
+        li = 1
+
+        def conv(x, in1=None, up0=False, leaky=True, cout=None):
+            nonlocal li
+            y = ops.conv3d_k3(x, m._packed[li], w[2 * li + 1], m.plan[li][2] if cout is None else cout, in1=in1,
+                              up0=up0, leaky=leaky, out_f32=True)
+            tape.append(("conv", li, x, up0, in1, y, leaky))
+            li += 1
+            return y
+
+        for _ in range(1, nlev):
+            p = ops.maxpool3d2(last)
+            tape.append(("pool", last, p))
+            last = conv(p)
+            skips.append(last)
+        p = ops.maxpool3d2(last)
+        tape.append(("pool", last, p))
+        last, skip = p, None
+        for _ in range(nlev):
+            last = conv(last, in1=skip, up0=skip is not None)
+            skip = skips.pop()
+        for _ in m.dec[nlev:]:
+            last = conv(last, in1=skip, up0=skip is not None)
+            skip = None
+        return conv(last, in1=skip, up0=skip is not None, leaky=False, cout=3)
+
+    def _tail_forward(self, flow):
+        m = self.model
+        half = tuple(s // m.svf_resolution for s in m.inshape)
+        svf = ops.resize_trilinear(flow, half, mul=1.0 / m.svf_resolution) if m.svf_resolution != 1 else flow
+        if m.int_resolution != m.svf_resolution:
+            raise NotImplementedError("training path assumes int_resolution == svf_resolution (both shipped configs)")
+        pos_lo, steps = ops.vecint_save(svf, m.int_steps)
+        pos = ops.resize_trilinear(pos_lo, m.inshape, mul=float(m.int_resolution), pre_scale=True) \
+            if m.int_resolution != 1 else pos_lo
+        return svf, steps, pos_lo, pos
+
+    def _tail_backward(self, dpos, svf, steps):
+        m = self.model
+        half = tuple(svf.shape[1:4])
+        dpos_lo = ops.resize_trilinear_bwd(dpos, half, mul=float(m.int_resolution)) if m.int_resolution != 1 else dpos
+        dsvf = ops.vecint_bwd(svf, steps, dpos_lo, m.int_steps)
+        if m.svf_resolution != 1:
+            return ops.resize_trilinear_bwd(dsvf, m.inshape, mul=1.0 / m.svf_resolution)
+        return dsvf
+
+    # ------------------------------------------------------------------ backward over the tape
+    def _backward(self, tape, dflow):
+        m = self.model
+        grads = {}
+        first = tape[-1]
+        grads[id(first[5])] = dflow
+
+        def give(t, g_new_fn):
+            """g_new_fn(existing_or_None) -> tensor holding the (accumulated) gradient of t."""
+            grads[id(t)] = g_new_fn(grads.get(id(t)))
+
+        for rec in reversed(tape):
+            kind = rec[0]
+            if kind == "conv":
+                _, li, x, up0, in1, y, leaky = rec
+                dy = grads.pop(id(y))
+                dz = ops.leaky_bwd_bias_(y if leaky else None, dy, self.g[2 * li + 1], leaky=leaky)
+                ops.conv3d_k3_wgrad(x, dz, self.g[2 * li], in1=in1, up0=up0)
+                C0 = x.shape[-1]
+                C1 = in1.shape[-1] if in1 is not None else 0
+                if m.plan[li][0] == "flow":
+                    dcat = ops.conv3d_k3_cout3_dgrad(dz, m._w[2 * li])
+                else:
+                    wt = ops.pack_conv_weights(m._w[2 * li], torch.float32, transpose_flip=True)
+                    dcat = ops.conv3d_k3(dz, wt, None, C0 + C1, leaky=False, out_f32=True)
+                del dz, dy
+                if in1 is None and not up0:
+                    if id(x) in grads:
+                        ops.axpy_(grads[id(x)], dcat, 1.0)
+                    else:
+                        grads[id(x)] = dcat
+                else:
+                    d0, d1 = ops.upcat_bwd(dcat, C0, C1, up0, d_in1=grads.get(id(in1)) if in1 is not None else None)
+                    if id(x) in grads:
+                        ops.axpy_(grads[id(x)], d0, 1.0)
+                    else:
+                        grads[id(x)] = d0
+                    if in1 is not None:
+                        grads[id(in1)] = d1
+                    del dcat
+            elif kind == "pool":
+                _, x, p = rec
+                dp = grads.pop(id(p))
+                give(x, lambda ex: ops.maxpool3d2_bwd(x, dp, dx=ex))
+            elif kind == "conv0":
+                _, li, src, trg, y = rec
+                dy = grads.pop(id(y))
+                dz = ops.leaky_bwd_bias_(y, dy, self.g[1], leaky=True)
+                ops.conv3d_k3_cin2_wgrad(src, trg, dz, self.g[0])
+        return grads
+
+    # ------------------------------------------------------------------ one step
+    def forward_backward(self, src_labels, trg_labels, draws_1=None, draws_2=None, train=True):
+        """src/trg label maps uint8 [b,*S,1] of this rank's shard. Fills self.gflat (unreduced)."""
+        g1 = self.gen_1.generate(src_labels, draws=draws_1, want_onehot=False)
+        g2 = self.gen_2.generate(trg_labels, draws=draws_2, want_onehot=False)
+        ima_1, ima_2, lab1, lab2 = g1["image"], g2["image"], g1["labels"], g2["labels"]
+        b = ima_1.shape[0]
+        tape = []
+        flow = self._forward(ima_1, ima_2, tape)
+        svf, steps, pos_lo, pos = self._tail_forward(flow)
+        dice, top_bot = ops.dice_labels_fwd(lab1, lab2, pos, self.L)
+        gl = ops.grad_l2_loss(pos, self.reg_param)
+        out = {"dice": dice, "grad": gl, "loss": (dice + 1.0) + gl.mean(), "pos_flow": pos, "preint_flow": svf}
+        if not train:
+            return out
+        # d/dflow of sum_b [(dice + 1) + grad_b]   (Keras sums the per-replica loss vector)
+        dpos = ops.dice_labels_bwd(lab1, lab2, pos, top_bot, self.L, scale=float(b))
+        ops.grad_l2_bwd(pos, self.reg_param, scale=1.0, out=dpos)
+        dflow = self._tail_backward(dpos, svf, steps)
+        self._backward(tape, dflow)
+        return out
+
+    def train_step(self, src_labels, trg_labels, draws_1=None, draws_2=None):
+        out = self.forward_backward(src_labels, trg_labels, draws_1, draws_2, train=True)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.pg)  # one 5.8 MB (64f) message
+        self.opt.apply(self.model._flat, self.gflat, grad_scale=1.0 / self.world)
+        self.model.invalidate_packed()
+        return out
+
+    def test_step(self, src_labels, trg_labels):
+        return self.forward_backward(src_labels, trg_labels, train=False)
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, gen, validation_data=None, validation_steps=0, initial_epoch=0, epochs=1, steps_per_epoch=1,
+            save_name=None, save_freq=0, verbose=1, log=None):
+        """Keras-``fit``-like loop over a ``gen_synthmorph_eb`` generator (global batch per item;
+        this rank takes rows rank*b:(rank+1)*b)."""
+        history = []
+        for epoch in range(initial_epoch, epochs):
+            t0 = time.perf_counter()
+            losses = []
+            for _ in range(steps_per_epoch):
+                (src, trg), _void = next(gen)
+                b = src.shape[0] // self.world
+                sl = slice(self.rank * b, (self.rank + 1) * b)
+                o = self.train_step(src[sl], trg[sl])
+                losses.append(o["loss"])
+            mean_loss = float(torch.stack(losses).mean())
+            rec = {"epoch": epoch + 1, "loss": mean_loss, "s_per_step": (time.perf_counter() - t0) / steps_per_epoch}
+            if validation_data is not None and validation_steps:
+                vl = []
+                for _ in range(validation_steps):
+                    (src, trg), _void = next(validation_data)
+                    b = src.shape[0] // self.world
+                    sl = slice(self.rank * b, (self.rank + 1) * b)
+                    vl.append(self.test_step(src[sl], trg[sl])["loss"])
+                rec["val_loss"] = float(torch.stack(vl).mean())
+            history.append(rec)
+            if verbose and self.rank == 0:
+                print(f"Epoch {epoch + 1}/{epochs} - loss: {rec['loss']:.4f}"
+                      + (f" - val_loss: {rec['val_loss']:.4f}" if "val_loss" in rec else "")
+                      + f" - {rec['s_per_step'] * 1e3:.0f} ms/step", flush=True)
+            if log is not None and self.rank == 0:
+                log(rec)
+            if save_name and save_freq and (epoch + 1) % save_freq == 0 and self.rank == 0:
+                self.model.save(save_name.format(epoch=epoch + 1))
+        return history
+
+
+def run_training(config, label_maps=None, device="cuda", rank=0, world_size=1, process_group=None, seed=0):
+    """``train_synthmorph.py __main__`` driven by the reference's 44-key JSON config (config/config.json)."""
+    from . import data, networks, synth
+    data_cfg = config
+    if label_maps is None:
+        if data_cfg["gen_label"]:
+            label_maps = synth.generate_label_maps(data_cfg["in_shape"], data_cfg["num_labels"], data_cfg["num_maps"],
+                                                   data_cfg["im_scales"], data_cfg["def_scales"], data_cfg["im_max_std"],
+                                                   data_cfg["def_max_std"], data_cfg["save_label"], data_cfg["label_dir"],
+                                                   data_cfg["add_str"], seed=seed, device=device)
+        else:
+            label_maps = [np.load(os.path.join(data_cfg["label_dir"], f)) for f in sorted(os.listdir(data_cfg["label_dir"]))
+                          if f.endswith(".npy")]
+    labels_in = np.unique(label_maps)
+    np.random.seed(42)  # train_synthmorph.py:209
+    label_maps = list(label_maps)
+    np.random.shuffle(label_maps)
+    n_tr = int(len(label_maps) * data_cfg["train_frac"])
+    maps_tr, maps_val = label_maps[:n_tr], label_maps[n_tr:]
+    if data_cfg["gen_label_only"]:
+        return None
+    gen_tr = data.gen_synthmorph_eb(maps_tr, batch_size=data_cfg["batch_size"], same_subj=data_cfg["same_subj"], flip=True,
+                                    random_zero_borders=data_cfg["zero_borders_maps"],
+                                    scale_zero_borders=data_cfg["zero_bord_scale"], frac_zero_bord=data_cfg["zero_bord_frac"],
+                                    rng=np.random.default_rng(seed))
+    gen_val = data.gen_synthmorph_eb(maps_val, batch_size=data_cfg["batch_size_val"], same_subj=data_cfg["same_subj"],
+                                     flip=True, random_zero_borders=data_cfg["zero_borders_maps_val"],
+                                     scale_zero_borders=data_cfg["zero_bord_scale"],
+                                     frac_zero_bord=data_cfg["zero_bord_frac"], rng=np.random.default_rng(seed + 1)) if maps_val else None
+    in_shape = label_maps[0].shape
+    gen_args = dict(in_shape=in_shape, in_label_list=labels_in, out_label_list=labels_in, warp_std=data_cfg["vel_std"],
+                    warp_res=data_cfg["vel_res"], blur_std=data_cfg["blur_std"], bias_std=data_cfg["bias_std"],
+                    bias_res=data_cfg["bias_res"], gamma_std=data_cfg["gamma"], device=device)
+    g1 = synth.labels_to_image(**gen_args, id=0, seed=seed * 2 + 11 + rank * 1000)
+    g2 = synth.labels_to_image(**gen_args, id=1, seed=seed * 2 + 12 + rank * 1000)
+    model = networks.VxmDense(in_shape, int_steps=data_cfg["int_steps"], int_resolution=data_cfg["int_res"],
+                              svf_resolution=data_cfg["svf_res"], nb_unet_features=(data_cfg["enc"], data_cfg["dec"]),
+                              compute_dtype="fp32", device=device, seed=seed)
+    if data_cfg["bool_init_weights"]:
+        model.load_weights(data_cfg["init_weights"])
+    model_dir = os.path.join(data_cfg["model_dir"], data_cfg["sub_dir"]) if data_cfg["bool_sub_dir"] else data_cfg["model_dir"]
+    os.makedirs(model_dir, exist_ok=True)
+    save_name = os.path.join(model_dir, "{epoch:04d}.safetensors")
+    trainer = SynthMorphTrainer(model, g1, g2, reg_param=data_cfg["reg_param"], optimizer=Adam(data_cfg["lr"]),
+                                zero_pad_dice=data_cfg["zero_borders_maps"] or data_cfg["zero_borders_maps_val"],
+                                process_group=process_group, world_size=world_size, rank=rank)
+    if rank == 0:
+        model.save(save_name.format(epoch=data_cfg["init_epoch"]))
+    steps = max(len(maps_tr) // data_cfg["batch_size"], 1)
+    hist = trainer.fit(gen_tr, validation_data=gen_val,
+                       validation_steps=(len(maps_val) // data_cfg["batch_size_val"]) if maps_val else 0,
+                       initial_epoch=data_cfg["init_epoch"], epochs=data_cfg["epochs"], steps_per_epoch=steps,
+                       save_name=save_name, save_freq=data_cfg["save_freq"], verbose=data_cfg["verbose"])
+    return trainer, hist

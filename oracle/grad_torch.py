@@ -1,0 +1,123 @@
+"""Gradient oracle (TEST INFRASTRUCTURE ONLY, PARITY UNPINNED): the forward graph of the SynthMorph
+training step restated with differentiable torch-CPU float64 ops, so that torch.autograd supplies the
+reference gradients TF's autodiff would produce for the same formulas (SURVEY.md Appendix A1-A7, A11;
+call sites train_synthmorph.py:296-308).  ``interpn`` is the gather formulation of Appendix A3 (not
+grid_sample) so the clamp-to-edge gradient semantics (tf.clip_by_value passes gradient on [min, max],
+floor passes none) are the ones differentiated."""
+import itertools
+
+import torch
+import torch.nn.functional as F
+
+DT = torch.float64
+
+
+def interpn(vol, loc):
+    """vol [*S, C], loc [*O, 3] -> [*O, C]; linear, clamp-to-edge."""
+    S = vol.shape[:3]
+    idx, wts = [], []
+    for d in range(3):
+        mx = float(S[d] - 1)
+        l = loc[..., d]
+        clipped = torch.clamp(l, 0.0, mx)
+        l0 = torch.clamp(torch.floor(l.detach()), 0.0, mx)
+        l1 = torch.clamp(l0 + 1, 0.0, mx)
+        w0 = l1 - clipped
+        idx.append((l0.long(), l1.long()))
+        wts.append((w0, 1 - w0))
+    out = 0
+    for c in itertools.product([0, 1], repeat=3):
+        w = wts[0][c[0]] * wts[1][c[1]] * wts[2][c[2]]
+        out = out + w[..., None] * vol[idx[0][c[0]], idx[1][c[1]], idx[2][c[2]]]
+    return out
+
+
+def grid(shape):
+    return torch.stack(torch.meshgrid(*[torch.arange(s, dtype=DT) for s in shape], indexing="ij"), -1)
+
+
+def transform(vol, shift):
+    return interpn(vol, grid(shift.shape[:3]) + shift)
+
+
+def resize(vol, new_shape):
+    S = vol.shape[:3]
+    lin = [torch.arange(n, dtype=DT) * ((s - 1) / max(n - 1, 1)) for s, n in zip(S, new_shape)]
+    return interpn(vol, torch.stack(torch.meshgrid(*lin, indexing="ij"), -1))
+
+
+def vecint(v, nsteps):
+    v = v / (2 ** nsteps)
+    for _ in range(nsteps):
+        v = v + transform(v, v)
+    return v
+
+
+def dice_loss(t, p):
+    """[B,*S,L] -> scalar (-mean divide_no_nan)."""
+    top = 2 * (t * p).sum((1, 2, 3))
+    bot = (t + p).sum((1, 2, 3))
+    return -torch.where(bot != 0, top / torch.where(bot != 0, bot, torch.ones_like(bot)), torch.zeros_like(bot)).mean()
+
+
+def grad_l2(y, loss_mult):
+    """[B,*S,C] -> [B]."""
+    terms = []
+    for d in (1, 2, 3):
+        df = y.narrow(d, 1, y.shape[d] - 1) - y.narrow(d, 0, y.shape[d] - 1)
+        terms.append((df * df).reshape(y.shape[0], -1).mean(1))
+    return torch.stack(terms).mean(0) * loss_mult
+
+
+def conv(x, w, b, leaky=True):
+    """x [B,X,Y,Z,Cin], keras w [3,3,3,Cin,Cout]."""
+    y = F.conv3d(x.permute(0, 4, 1, 2, 3), w.permute(4, 3, 0, 1, 2), b, padding=1).permute(0, 2, 3, 4, 1)
+    return F.leaky_relu(y, 0.2) if leaky else y
+
+
+def pool(x):
+    return F.max_pool3d(x.permute(0, 4, 1, 2, 3), 2).permute(0, 2, 3, 4, 1)
+
+
+def up(x):
+    return x.repeat_interleave(2, 1).repeat_interleave(2, 2).repeat_interleave(2, 3)
+
+
+def unet(src, trg, ws, enc, dec):
+    nlev = len(enc)
+    it = iter(range(0, len(ws), 2))
+
+    def c(x, leaky=True):
+        i = next(it)
+        return conv(x, ws[i], ws[i + 1], leaky)
+    last = torch.cat([src, trg], -1)
+    skips = []
+    for _ in range(nlev):
+        last = c(last)
+        skips.append(last)
+        last = pool(last)
+    for _ in range(nlev):
+        last = c(last)
+        last = torch.cat([up(last), skips.pop()], -1)
+    for _ in dec[nlev:]:
+        last = c(last)
+    return c(last, leaky=False)
+
+
+def synthmorph_loss(src, trg, onehot1, onehot2, ws, enc, dec, int_steps, reg_param):
+    """Sum over the batch of (Dice + 1) + Grad-l2 (what Keras differentiates, Appendix A11).
+    Returns (total, dice, grad[B], pos_flow, flow)."""
+    flow = unet(src, trg, ws, enc, dec)
+    B = flow.shape[0]
+    half = tuple(s // 2 for s in flow.shape[1:4])
+    pos = []
+    for b in range(B):
+        svf = 0.5 * resize(flow[b], half)
+        v = vecint(svf, int_steps)
+        pos.append(resize(2 * v, flow.shape[1:4]))
+    pos = torch.stack(pos)
+    pred = torch.stack([transform(onehot1[b], pos[b]) for b in range(B)])
+    dice = dice_loss(onehot2, pred)
+    gl = grad_l2(pos, reg_param)
+    total = (dice + 1) * B + gl.sum()
+    return total, dice, gl, pos, flow

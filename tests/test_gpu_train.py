@@ -1,0 +1,265 @@
+"""Backward kernels, Adam and the full SynthMorph training step vs torch-CPU float64 autograd of the
+restated graph (oracle/grad_torch.py).  fp32 kernels vs fp64 oracle: tolerance 1e-4 of the gradient scale
+(float atomics in the gather adjoints make the last bits order-dependent, far below this)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _rel(got, ref):
+    got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    ref = ref.detach().cpu().double().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref, np.float64)
+    return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
+
+
+def test_dice_from_labels_matches_onehot_formulation(dev):
+    import mmr
+    from oracle import grad_torch as G
+    rng = np.random.default_rng(0)
+    B, S, L = 2, (10, 12, 9), 7
+    lab1 = rng.integers(0, L, (B,) + S).astype(np.uint8)
+    lab2 = rng.integers(0, L - 1, (B,) + S).astype(np.uint8)  # label L-1 absent from the target
+    flow = (rng.standard_normal((B,) + S + (3,)) * 2).astype(np.float32)
+    loss, tb = mmr.ops.dice_labels_fwd(_t(lab1, dev), _t(lab2, dev), _t(flow, dev), L)
+    # product's own one-hot path (materialised) must agree
+    oh1, oh2 = mmr.ops.onehot(_t(lab1, dev), L), mmr.ops.onehot(_t(lab2, dev), L)
+    pred = mmr.ops.warp3d(oh1, _t(flow, dev))
+    loss_oh = mmr.ops.dice_loss(oh2, pred)
+    assert abs(float(loss) - float(loss_oh)) < 1e-6
+    # gradient wrt flow vs autograd
+    f = torch.from_numpy(flow).double().requires_grad_(True)
+    e = torch.eye(L, dtype=torch.float64)
+    p = torch.stack([G.transform(e[torch.from_numpy(lab1[b]).long()], f[b]) for b in range(B)])
+    ref = G.dice_loss(e[torch.from_numpy(lab2).long()], p)
+    assert abs(float(loss) - float(ref)) < 1e-6
+    ref.backward()
+    got = mmr.ops.dice_labels_bwd(_t(lab1, dev), _t(lab2, dev), _t(flow, dev), tb, L, scale=1.0)
+    assert _rel(got, f.grad) < 1e-4
+    acc = torch.ones_like(got)
+    mmr.ops.dice_labels_bwd(_t(lab1, dev), _t(lab2, dev), _t(flow, dev), tb, L, scale=2.0, out=acc)
+    assert _rel(acc - 1, 2 * f.grad) < 1e-4
+
+
+def test_grad_l2_bwd(dev):
+    import mmr
+    from oracle import grad_torch as G
+    rng = np.random.default_rng(1)
+    flow = rng.standard_normal((2, 7, 9, 8, 3)).astype(np.float32)
+    f = torch.from_numpy(flow).double().requires_grad_(True)
+    G.grad_l2(f, 0.7).sum().backward()
+    assert _rel(mmr.ops.grad_l2_bwd(_t(flow, dev), 0.7), f.grad) < 1e-5
+
+
+@pytest.mark.parametrize("shape,new,mul", [((6, 8, 10), (12, 16, 20), 2.0), ((12, 16, 20), (6, 8, 10), 0.5), ((5, 7, 4), (9, 8, 11), 1.5)])
+def test_resize_bwd_is_adjoint(dev, shape, new, mul):
+    import mmr
+    from oracle import grad_torch as G
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal(shape + (3,)).astype(np.float32)
+    g = rng.standard_normal(new + (3,)).astype(np.float32)
+    xt = torch.from_numpy(x).double().requires_grad_(True)
+    (mul * G.resize(xt, new) * torch.from_numpy(g).double()).sum().backward()
+    got = mmr.ops.resize_trilinear_bwd(_t(g[None], dev), shape, mul=mul)[0]
+    assert _rel(got, xt.grad) < 1e-5
+
+
+def test_compose_vecint_warp_bwd(dev):
+    import mmr
+    from oracle import grad_torch as G
+    rng = np.random.default_rng(3)
+    S = (8, 9, 10)
+    a = (rng.standard_normal(S + (3,)) * 1.5).astype(np.float32)
+    b = (rng.standard_normal(S + (3,)) * 1.5).astype(np.float32)
+    g = rng.standard_normal(S + (3,)).astype(np.float32)
+    at, bt = torch.from_numpy(a).double().requires_grad_(True), torch.from_numpy(b).double().requires_grad_(True)
+    ((bt + G.transform(at, bt)) * torch.from_numpy(g).double()).sum().backward()
+    da, db = mmr.ops.compose_bwd(_t(a[None], dev), _t(b[None], dev), _t(g[None], dev))
+    assert _rel(da[0], at.grad) < 1e-5 and _rel(db[0], bt.grad) < 1e-5
+    for n in (0, 1, 5):
+        v = (rng.standard_normal(S + (3,)) * 3).astype(np.float32)
+        vt = torch.from_numpy(v).double().requires_grad_(True)
+        (G.vecint(vt, n) * torch.from_numpy(g).double()).sum().backward()
+        out, steps = mmr.ops.vecint_save(_t(v[None], dev), n)
+        assert _rel(out, mmr.ops.vecint(_t(v[None], dev), n)) == 0
+        dv = mmr.ops.vecint_bwd(_t(v[None], dev), steps, _t(g[None], dev), n)
+        assert _rel(dv[0], vt.grad) < 1e-5, n
+    vol = rng.standard_normal(S + (4,)).astype(np.float32)
+    go = rng.standard_normal(S + (4,)).astype(np.float32)
+    vt, ft = torch.from_numpy(vol).double().requires_grad_(True), torch.from_numpy(a).double().requires_grad_(True)
+    (G.transform(vt, ft) * torch.from_numpy(go).double()).sum().backward()
+    dvol, dflow = mmr.ops.warp3d_bwd(_t(vol[None], dev), _t(a[None], dev), _t(go[None], dev))
+    assert _rel(dvol[0], vt.grad) < 1e-5 and _rel(dflow[0], ft.grad) < 1e-5
+
+
+@pytest.mark.parametrize("shape,C0,C1,up0,Cout", [((8, 8, 8), 32, 0, False, 64), ((6, 10, 12), 64, 0, False, 32),
+                                                    ((8, 16, 8), 32, 32, True, 64), ((4, 8, 8), 64, 64, True, 128),
+                                                    ((5, 9, 7), 64, 0, False, 3)])
+def test_conv_backward_pieces(dev, shape, C0, C1, up0, Cout):
+    import mmr
+    from oracle import grad_torch as G
+    rng = np.random.default_rng(4)
+    B = 2
+    X, Y, Z = shape
+    s0 = (B, X // 2, Y // 2, Z // 2, C0) if up0 else (B, X, Y, Z, C0)
+    a0 = rng.standard_normal(s0).astype(np.float32)
+    a1 = rng.standard_normal((B, X, Y, Z, C1)).astype(np.float32) if C1 else None
+    w = (rng.standard_normal((3, 3, 3, C0 + C1, Cout)) * 0.05).astype(np.float32)
+    bias = (rng.standard_normal(Cout) * 0.1).astype(np.float32)
+    gy = rng.standard_normal((B, X, Y, Z, Cout)).astype(np.float32)
+    leaky = Cout != 3
+    t0 = torch.from_numpy(a0).double().requires_grad_(True)
+    t1 = torch.from_numpy(a1).double().requires_grad_(True) if C1 else None
+    wt, bt = torch.from_numpy(w).double().requires_grad_(True), torch.from_numpy(bias).double().requires_grad_(True)
+    xin = G.up(t0) if up0 else t0
+    if C1:
+        xin = torch.cat([xin, t1], -1)
+    y = G.conv(xin, wt, bt, leaky)
+    (y * torch.from_numpy(gy).double()).sum().backward()
+    # product
+    d0 = _t(a0, dev)
+    d1 = _t(a1, dev) if C1 else None
+    wp = mmr.ops.pack_conv_weights(_t(w, dev), torch.float32)
+    yk = mmr.ops.conv3d_k3(d0, wp, _t(bias, dev), Cout, in1=d1, up0=up0, leaky=leaky, out_f32=True)
+    assert _rel(yk, y) < 1e-5
+    dy = _t(gy, dev).clone()
+    db = torch.zeros(Cout, device=dev)
+    dz = mmr.ops.leaky_bwd_bias_(yk if leaky else None, dy, db, leaky=leaky)
+    assert _rel(db, bt.grad) < 1e-4
+    dw = torch.zeros((3, 3, 3, C0 + C1, Cout), device=dev)
+    mmr.ops.conv3d_k3_wgrad(d0, dz, dw, in1=d1, up0=up0)
+    assert _rel(dw, wt.grad) < 1e-4
+    if Cout == 3:
+        dcat = mmr.ops.conv3d_k3_cout3_dgrad(dz, _t(w, dev))
+    else:
+        wtp = mmr.ops.pack_conv_weights(_t(w, dev), torch.float32, transpose_flip=True)
+        dcat = mmr.ops.conv3d_k3(dz, wtp, None, C0 + C1, leaky=False, out_f32=True)
+    if C1 or up0:
+        g0, g1 = mmr.ops.upcat_bwd(dcat, C0, C1, up0)
+        assert _rel(g0, t0.grad) < 1e-4
+        if C1:
+            assert _rel(g1, t1.grad) < 1e-4
+    else:
+        assert _rel(dcat, t0.grad) < 1e-4
+
+
+def test_first_layer_wgrad_and_maxpool_bwd(dev):
+    import mmr
+    from oracle import grad_torch as G
+    rng = np.random.default_rng(5)
+    S = (6, 8, 18)
+    src = rng.random((2,) + S + (1,)).astype(np.float32)
+    trg = rng.random((2,) + S + (1,)).astype(np.float32)
+    gz = rng.standard_normal((2,) + S + (64,)).astype(np.float32)
+    wt = torch.zeros((3, 3, 3, 2, 64), dtype=torch.float64, requires_grad=True)
+    y = G.conv(torch.cat([torch.from_numpy(src), torch.from_numpy(trg)], -1).double(), wt, None, leaky=False)
+    (y * torch.from_numpy(gz).double()).sum().backward()
+    dw = torch.zeros((3, 3, 3, 2, 64), device=dev)
+    mmr.ops.conv3d_k3_cin2_wgrad(_t(src, dev), _t(trg, dev), _t(gz, dev), dw)
+    assert _rel(dw, wt.grad) < 1e-4
+    x = rng.standard_normal((2, 6, 8, 10, 32)).astype(np.float32)
+    gp = rng.standard_normal((2, 3, 4, 5, 32)).astype(np.float32)
+    xt = torch.from_numpy(x).double().requires_grad_(True)
+    (G.pool(xt) * torch.from_numpy(gp).double()).sum().backward()
+    got = mmr.ops.maxpool3d2_bwd(_t(x, dev), _t(gp, dev))
+    assert _rel(got, xt.grad) == 0
+    acc = torch.ones_like(got)
+    mmr.ops.maxpool3d2_bwd(_t(x, dev), _t(gp, dev), dx=acc)
+    assert _rel(acc - 1, xt.grad) < 1e-6
+
+
+def test_adam_matches_keras_formula(dev):
+    import mmr
+    rng = np.random.default_rng(6)
+    w = rng.standard_normal(1000).astype(np.float32)
+    m = np.zeros_like(w); v = np.zeros_like(w)
+    wt, mt, vt = _t(w, dev), _t(m, dev), _t(v, dev)
+    ref = w.astype(np.float64)
+    for t in range(1, 4):
+        g = rng.standard_normal(1000).astype(np.float32)
+        mmr.ops.adam_step_(wt, _t(g, dev), mt, vt, t, lr=1e-2, grad_scale=0.5)
+        gs = g.astype(np.float64) * 0.5
+        m = 0.9 * m + 0.1 * gs
+        v = 0.999 * v + 0.001 * gs * gs
+        lr_t = 1e-2 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        ref = ref - lr_t * m / (np.sqrt(v) + 1e-7)
+    np.testing.assert_allclose(wt.cpu().numpy(), ref, rtol=2e-5, atol=1e-6)
+
+
+def test_full_training_step_gradients(dev):
+    """One SynthMorph step on a tiny U-Net: every one of the 22 gradient tensors vs autograd."""
+    import mmr
+    from mmr import synth, training
+    from oracle import grad_torch as G
+    from oracle import net_np
+    shape, enc, dec, L, B = (16, 16, 32), [32, 32], [32, 32, 32], 5, 2
+    rng = np.random.default_rng(7)
+    coarse = rng.integers(0, L, (B, 4, 4, 8))
+    lab_s = np.repeat(np.repeat(np.repeat(coarse, 4, 1), 4, 2), 4, 3).astype(np.uint8)[..., None]
+    coarse = rng.integers(0, L, (B, 4, 4, 8))
+    lab_t = np.repeat(np.repeat(np.repeat(coarse, 4, 1), 4, 2), 4, 3).astype(np.uint8)[..., None]
+    kw = dict(in_shape=shape, in_label_list=np.arange(L), out_label_list=np.arange(L), warp_std=2, warp_res=8, blur_std=1,
+              bias_std=0.3, bias_res=8, gamma_std=0.25)
+    g1, g2 = synth.labels_to_image(**kw, id=0, seed=1), synth.labels_to_image(**kw, id=1, seed=2)
+    model = mmr.networks.VxmDense(shape, nb_unet_features=(enc, dec), int_steps=3, int_resolution=2, svf_resolution=2,
+                                  compute_dtype="fp32")
+    ws = net_np.init_weights(enc, dec, seed=3, flow_std=3e-2)
+    for i in range(1, len(ws), 2):
+        ws[i] = (rng.standard_normal(ws[i].shape) * 0.05).astype(np.float32)
+    model.set_weights(ws)
+    tr = training.SynthMorphTrainer(model, g1, g2, reg_param=0.8, optimizer=training.Adam(1e-3))
+    out = tr.forward_backward(lab_s, lab_t)
+    assert torch.isfinite(out["loss"]) and float(out["loss"]) > 0
+    # deterministic comparison: run the trainer's kernels on fixed generator outputs
+    gen1 = g1.generate(lab_s, want_onehot=True)
+    gen2 = g2.generate(lab_t, want_onehot=True)
+    ima1, ima2 = gen1["image"], gen2["image"]
+    lab1, lab2 = gen1["labels"], gen2["labels"]
+    tape = []
+    tr.gflat.zero_()
+    flow = tr._forward(ima1, ima2, tape)
+    svf, steps, pos_lo, pos = tr._tail_forward(flow)
+    dice, tb = mmr.ops.dice_labels_fwd(lab1, lab2, pos, L)
+    gl = mmr.ops.grad_l2_loss(pos, 0.8)
+    dpos = mmr.ops.dice_labels_bwd(lab1, lab2, pos, tb, L, scale=float(B))
+    mmr.ops.grad_l2_bwd(pos, 0.8, 1.0, out=dpos)
+    tr._backward(tape, tr._tail_backward(dpos, svf, steps))
+    wt = [torch.from_numpy(w).double().requires_grad_(True) for w in ws]
+    total, rdice, rgl, rpos, rflow = G.synthmorph_loss(ima1.cpu().double(), ima2.cpu().double(), gen1["onehot"].cpu().double(),
+                                                      gen2["onehot"].cpu().double(), wt, enc, dec, 3, 0.8)
+    total.backward()
+    assert np.abs(rpos.detach().numpy()).max() > 0.3, "flow too small to exercise the warp"
+    assert _rel(flow, rflow) < 1e-4 and _rel(pos, rpos) < 1e-4
+    assert abs(float(dice) - float(rdice)) < 1e-5 and _rel(gl, rgl) < 1e-4
+    names = [p[0] for p in model.plan]
+    for i, (g, w) in enumerate(zip(tr.g, wt)):
+        err = _rel(g, w.grad)
+        assert err < 2e-4, f"{names[i // 2]} {'bias' if i % 2 else 'kernel'}: {err:.2e}"
+
+
+def test_training_lowers_loss_and_is_reproducible(dev):
+    import mmr
+    from mmr import synth, training
+    shape, enc, dec, L = (16, 16, 32), [32, 32], [32, 32, 32], 4
+    rng = np.random.default_rng(8)
+    mk = lambda: np.repeat(np.repeat(np.repeat(rng.integers(0, L, (1, 4, 4, 8)), 4, 1), 4, 2), 4, 3).astype(np.uint8)[..., None]
+    lab_s, lab_t = mk(), mk()
+    kw = dict(in_shape=shape, in_label_list=np.arange(L), out_label_list=np.arange(L), warp_std=1, warp_res=8, blur_std=1,
+              bias_std=0.3, bias_res=8, gamma_std=0.25)
+
+    def run():
+        g1, g2 = synth.labels_to_image(**kw, id=0, seed=1), synth.labels_to_image(**kw, id=1, seed=2)
+        d1, d2 = g1.draw(1), g2.draw(1)
+        model = mmr.networks.VxmDense(shape, nb_unet_features=(enc, dec), int_steps=3, int_resolution=2,
+                                      svf_resolution=2, compute_dtype="fp32", seed=5)
+        tr = training.SynthMorphTrainer(model, g1, g2, reg_param=0.1, optimizer=training.Adam(1e-3))
+        return [float(tr.train_step(lab_s, lab_t, d1, d2)["loss"]) for _ in range(25)], model.get_weights()
+    l1, w1 = run()
+    assert l1[-1] < l1[0] - 0.02, l1
+    l2, w2 = run()
+    assert np.allclose(l1, l2, rtol=1e-4, atol=1e-5)  # float atomics in the gather adjoints: not bit-identical
