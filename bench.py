@@ -1,13 +1,15 @@
 #!/usr/bin/env python
 """Benchmark of the hot path (see DESIGN.md "Measurement").
 
-python bench.py --gpus N --steps K --warmup W [--workload infer|ncc]
+python bench.py --gpus N --steps K --warmup W [--workload infer|train|ncc]
 
-Default workload = BASELINE.json configs[1]: 3d_reg.py-style inference, one
-VxmDense forward (enc/dec = 256, int_steps 5, half-res SVF) on a 160x160x192
-pair, bf16 MFMA with fp32 accumulate, inputs resident in HBM.  A "step" is one
-pair.  N > 1 = independent replicas (one process per GPU, weak scaling, no
-data-path collective: single-pair inference does not shard).
+infer (default) = BASELINE.json configs[1]: 3d_reg.py-style inference, one VxmDense forward
+  (enc/dec = 256, int_steps 5, half-res SVF) on a 160x160x192 pair, bf16 MFMA / fp32 accumulate,
+  inputs resident in HBM.  A step = one pair.  N > 1 = independent replicas (single-pair inference
+  does not shard), weak scaling, no data-path collective.
+train = configs[2]: SynthMorph training step at 160^3, enc/dec = 64 (config/config.json), fp32, 1 pair per
+  GPU, Dice + Grad-l2, generators on device, RCCL SUM all-reduce of the flat gradient buffer + Adam.
+ncc   = configs[4]: local NCC (win 9) + bending energy forward on 256^3 fp32 volumes.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -23,9 +25,8 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_BF16_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md chip table
+PEAKS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
-DOMINANT_KERNEL = "conv3d_k3_kernel<bf16, WM=2, WN=4, MT=4, NT=2> (all 256-wide U-Net convs)"
 
 
 def synth_pair(shape, device, seed=0):
@@ -42,19 +43,16 @@ def synth_pair(shape, device, seed=0):
 
 
 def cpu_baseline_infer(enc, dec, full_shape):
-    """Oracle (CPU restatement, 'port') on a bounded sample of the same workload: the same network
-    on a 32x32x48 crop-sized pair, all host cores (OpenMP C conv + NumPy tail)."""
+    """Oracle (CPU restatement, 'port') on a bounded sample of the same workload."""
     from oracle import net_np
     from oracle import cbind
-    import oracle.ops_np as O
     sample = (32, 32, 48)
     rng = np.random.default_rng(0)
     mov = rng.random((1,) + sample + (1,)).astype(np.float32)
     fix = rng.random((1,) + sample + (1,)).astype(np.float32)
     w = net_np.init_weights(enc, dec, seed=0)
     real = cbind.conv3d_same
-    cbind_fast = lambda x, w_, b=None, leaky=False, alpha=0.2: real(x, w_, b, leaky=leaky, alpha=alpha, f32acc=True)
-    net_np.conv3d_same = cbind_fast
+    net_np.conv3d_same = lambda x, w_, b=None, leaky=False, alpha=0.2: real(x, w_, b, leaky=leaky, alpha=alpha, f32acc=True)
     try:
         t0 = time.perf_counter()
         net_np.vxm_dense_forward(mov, fix, w, enc, dec, 5, 2, 2)
@@ -63,9 +61,59 @@ def cpu_baseline_infer(enc, dec, full_shape):
         net_np.conv3d_same = real
     frac = float(np.prod(sample)) / float(np.prod(full_shape))
     return {"value": frac / dt, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"one VxmDense forward (enc/dec=256) on a {sample[0]}x{sample[1]}x{sample[2]} pair = "
-                      f"{frac:.5f} of the 160x160x192 voxels, {dt:.1f} s wall; value = that fraction / wall "
-                      f"(pairs/s-equivalent, work is linear in voxels); oracle/conv_c.c f32-accumulate + NumPy tail"}
+            "sample": f"one VxmDense forward (enc/dec={enc[0]}) on a {sample[0]}x{sample[1]}x{sample[2]} pair = "
+                      f"{frac:.5f} of the {'x'.join(map(str, full_shape))} voxels, {dt:.1f} s wall; value = that fraction / "
+                      f"wall (pairs/s-equivalent, work is linear in voxels); oracle/conv_c.c f32-accumulate + NumPy tail"}
+
+
+def cpu_baseline_train(enc, dec, full_shape, L):
+    """Oracle training step ('port'): torch-CPU float64 autograd of the restated graph on a small crop."""
+    from oracle import grad_torch as G
+    from oracle import net_np
+    sample = (16, 16, 32)
+    rng = np.random.default_rng(0)
+    ws = [torch.from_numpy(w).double().requires_grad_(True) for w in net_np.init_weights(enc, dec, seed=0, flow_std=1e-2)]
+    src = torch.from_numpy(rng.random((1,) + sample + (1,)))
+    trg = torch.from_numpy(rng.random((1,) + sample + (1,)))
+    e = torch.eye(L, dtype=torch.float64)
+    o1 = e[torch.from_numpy(rng.integers(0, L, (1,) + sample))]
+    o2 = e[torch.from_numpy(rng.integers(0, L, (1,) + sample))]
+    t0 = time.perf_counter()
+    total = G.synthmorph_loss(src, trg, o1, o2, ws, enc, dec, 5, 1.0)[0]
+    total.backward()
+    dt = time.perf_counter() - t0
+    frac = float(np.prod(sample)) / float(np.prod(full_shape))
+    return {"value": frac / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"one fwd+bwd of the restated SynthMorph step (oracle/grad_torch.py, torch-CPU float64 autograd, "
+                      f"enc/dec={enc[0]}, no generator, no Adam) on a {sample[0]}x{sample[1]}x{sample[2]} pair = {frac:.6f} of "
+                      f"the voxels, {dt:.1f} s wall; value = fraction / wall"}
+
+
+def roofline_from_profile(prof, steps, dtype, traffic_file):
+    fam = {}
+    for f, tag, e0, e1, fl in prof:
+        a = fam.setdefault(f, [0.0, 0.0, 0])
+        a[0] += e0.elapsed_time(e1)
+        a[1] += fl
+        a[2] += 1
+    if not fam:
+        return None, {}
+    dom = max(fam, key=lambda k: fam[k][0])
+    ms, fl, n = fam[dom]
+    peak = PEAKS["bf16" if "bf16" in dom else "fp32"]
+    achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", traffic_file)
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "traffic": traffic, "kernel": dom, "launches_per_step": n // max(steps, 1), "avg_launch_ms": ms / max(n, 1),
+            "algorithmic_tflop_per_step": fl / max(steps, 1) / 1e12}
+    fam_ms = {k: round(v[0] / steps, 3) for k, v in fam.items()}
+    return roof, fam_ms
 
 
 def main():
@@ -73,89 +121,118 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="infer", choices=["infer"])
-    ap.add_argument("--features", type=int, default=256)
-    ap.add_argument("--shape", type=int, nargs=3, default=[160, 160, 192])
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--workload", default="infer", choices=["infer", "train", "ncc"])
+    ap.add_argument("--features", type=int, default=None)
+    ap.add_argument("--shape", type=int, nargs=3, default=None)
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
 
     import mmr
-    shape = tuple(args.shape)
-    enc, dec = [args.features] * 4, [args.features] * 6
-    model = mmr.networks.VxmDense(shape, nb_unet_features=(enc, dec), int_steps=5, int_resolution=2,
-                                  svf_resolution=2, compute_dtype=args.dtype, device=dev, seed=0)
-    mov, fix = synth_pair(shape, dev, seed=rank)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    extra = {}
+    if args.workload == "infer":
+        shape = tuple(args.shape or (160, 160, 192))
+        feats = args.features or 256
+        dtype = args.dtype or "bf16"
+        enc, dec = [feats] * 4, [feats] * 6
+        model = mmr.networks.VxmDense(shape, nb_unet_features=(enc, dec), int_steps=5, int_resolution=2,
+                                      svf_resolution=2, compute_dtype=dtype, device=dev, seed=0)
+        mov, fix = synth_pair(shape, dev, seed=rank)
+        step = lambda: model.forward(mov, fix)["y_source"]
+        workload = (f"3d_reg.py inference (BASELINE configs[1]): VxmDense forward {shape[0]}x{shape[1]}x{shape[2]}, "
+                    f"enc/dec={feats}, int_steps=5, svf/int_res=2, inputs resident in HBM, 1 pair/step")
+        par = f"replicas x{world} (single-pair inference does not shard)"
+        cpu_fn = lambda: cpu_baseline_infer(enc, dec, shape)
+        metric, unit, pairs_per_step = "volume-pairs/sec", "pairs/s", 1
+    elif args.workload == "train":
+        from mmr import synth, training
+        shape = tuple(args.shape or (160, 160, 160))
+        feats = args.features or 64
+        dtype = "fp32"
+        L = 26
+        enc, dec = [feats] * 4, [feats] * 6
+        maps = synth.generate_label_maps(shape, L, 2, [16, 32, 64], [8, 16, 32], 1, 3, seed=100 + rank, device=dev)
+        labels_in = np.arange(L)
+        kw = dict(in_shape=shape, in_label_list=labels_in, out_label_list=labels_in, warp_std=3, warp_res=16, blur_std=1,
+                  bias_std=0.3, bias_res=40, gamma_std=0.25, device=dev)
+        g1 = synth.labels_to_image(**kw, id=0, seed=11 + rank)
+        g2 = synth.labels_to_image(**kw, id=1, seed=12 + rank)
+        model = mmr.networks.VxmDense(shape, nb_unet_features=(enc, dec), int_steps=5, int_resolution=2, svf_resolution=2,
+                                      compute_dtype="fp32", device=dev, seed=0)
+        tr = training.SynthMorphTrainer(model, g1, g2, reg_param=1.0, optimizer=training.Adam(1e-4),
+                                        world_size=world, rank=rank)
+        src = torch.from_numpy(maps[0][None, ..., None]).to(dev)
+        trg = torch.from_numpy(maps[1][None, ..., None]).to(dev)
+        step = lambda: tr.train_step(src, trg)["loss"]
+        workload = (f"train_synthmorph.py step (BASELINE configs[2]): {shape[0]}^3, enc/dec={feats}, {L} labels, Dice + "
+                    f"Grad-l2(reg 1), generators + fwd + bwd + all-reduce + Adam, 1 pair per GPU, label maps resident in HBM")
+        par = f"dp{world} (batch sharded by rank, one SUM all-reduce of {model._flat.numel() * 4 / 1e6:.1f} MB over RCCL)"
+        cpu_fn = lambda: cpu_baseline_train(enc, dec, shape, L)
+        metric, unit, pairs_per_step = "volume-pairs/sec", "pairs/s", 1
+    else:  # ncc
+        shape = tuple(args.shape or (256, 256, 256))
+        dtype = "fp32"
+        g = torch.Generator(device="cpu").manual_seed(rank)
+        I = torch.rand((1,) + shape + (1,), generator=g).to(dev)
+        J = torch.rand((1,) + shape + (1,), generator=g).to(dev)
+        flow = torch.randn((1,) + shape + (3,), generator=g).to(dev)
+
+        def step():
+            return mmr.ops.ncc_loss(I, J, 9) + mmr.ops.bending_energy(flow)
+        workload = f"local NCC(win 9) + bending energy forward on {shape[0]}^3 fp32 (BASELINE configs[4])"
+        par = f"replicas x{world}"
+        cpu_fn = None
+        metric, unit, pairs_per_step = "volume-pairs/sec", "pairs/s", 1
+        extra["algorithmic_bytes_per_step"] = int(np.prod(shape)) * 4 * 5
+
     for _ in range(args.warmup):
-        model.forward(mov, fix)
+        step()
     barrier()
-    model.layer_events = []
+    mmr.ops.PROFILE = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = model.forward(mov, fix)
+        last = step()
     barrier()
     dt = time.perf_counter() - t0
-    events = model.layer_events
-    model.layer_events = None
+    prof = mmr.ops.PROFILE
+    mmr.ops.PROFILE = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    assert torch.isfinite(out["y_source"]).all()
+    assert torch.isfinite(last).all()
 
     if rank == 0:
-        # dominant kernel = the BN=256 MFMA conv instantiation: every layer with Cout = features
-        dom = [(n, e0.elapsed_time(e1), fl) for (n, e0, e1, fl) in events if n != "flow"]
-        dom_ms = sum(d[1] for d in dom)
-        dom_flops = sum(d[2] for d in dom)
-        n_launch = len(dom)
-        achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        per_layer = {}
-        for n, ms, fl in [(n, e0.elapsed_time(e1), fl) for (n, e0, e1, fl) in events]:
-            a = per_layer.setdefault(n, [0.0, 0.0])
-            a[0] += ms
-            a[1] += fl
-        res = {
-            "metric": "volume-pairs/sec", "value": world * args.steps / dt, "unit": "pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"3d_reg.py inference (BASELINE configs[1]): VxmDense forward "
-                                   f"{shape[0]}x{shape[1]}x{shape[2]}, enc/dec={args.features}, int_steps=5, "
-                                   f"svf/int_res=2, inputs resident in HBM, 1 pair/step",
-                       "parallelism": f"replicas x{world} (single-pair inference does not shard)"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
-                         "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3),
-                         "traffic": traffic, "kernel": DOMINANT_KERNEL,
-                         "launches_per_step": n_launch // max(args.steps, 1),
-                         "avg_launch_ms": dom_ms / max(n_launch, 1),
-                         "algorithmic_tflop_per_step": dom_flops / max(args.steps, 1) / 1e12},
-            "layer_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in per_layer.items()},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline_infer(enc, dec, shape)
+        res = {"metric": metric, "value": world * pairs_per_step * args.steps / dt, "unit": unit, "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+               "config": {"workload": workload, "parallelism": par}}
+        roof, fam_ms = roofline_from_profile(prof, args.steps, dtype, f"traffic_{args.workload}.json")
+        if args.workload == "ncc":
+            gbs = extra["algorithmic_bytes_per_step"] / (dt / args.steps) / 1e9
+            roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                    "traffic": None, "kernel": "ncc_partial_kernel + bending_partial_kernel (2+3 volumes read once)"}
+        if roof:
+            res["roofline"] = roof
+        if fam_ms:
+            res["kernel_family_ms_per_step"] = fam_ms
+        if world == 1 and not args.no_cpu_baseline and cpu_fn is not None:
+            res["cpu_baseline"] = cpu_fn()
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

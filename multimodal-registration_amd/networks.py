@@ -99,7 +99,6 @@ class VxmDense:
             unet_model=None, source=None, target=None, svf=None, preint_flow=None, postint_flow=None,
             pos_flow=None, neg_flow=None, y_source=None, y_target=None, hyp_input=None)
         self._losses = []
-        self.layer_events = None  # bench.py sets a list to collect (name, ev0, ev1, flops)
 
     # ------------------------------------------------------------------ weights
     def _init_weights(self, seed):
@@ -185,18 +184,8 @@ class VxmDense:
 
     # ------------------------------------------------------------------ forward
     def _conv(self, li, x, **kw):
-        """Layer li of the plan on the MFMA kernel; optional per-launch event pair for bench.py."""
-        name, cin, cout = self.plan[li]
-        ev = self.layer_events
-        if ev is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        out = ops.conv3d_k3(x, self._packed[li], self._w[2 * li + 1], cout, **kw)
-        if ev is not None:
-            e1.record()
-            nvox = out.shape[0] * out.shape[1] * out.shape[2] * out.shape[3]
-            ev.append((name, e0, e1, 2.0 * 27 * sum(cin) * cout * nvox))
-        return out
+        """Layer li of the plan on the MFMA kernel."""
+        return ops.conv3d_k3(x, self._packed[li], self._w[2 * li + 1], self.plan[li][2], **kw)
 
     def unet(self, src, trg):
         """[B,X,Y,Z,1] x2 (f32) -> flow [B,X,Y,Z,3] f32."""

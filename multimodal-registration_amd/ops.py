@@ -17,6 +17,27 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# bench.py sets PROFILE to a list to collect (kernel family, tag, ev0, ev1, algorithmic flops) per launch,
+# timed with events on the stream the kernels are launched on (torch's current stream).
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, family, tag, flops):
+        self.rec = None
+        if PROFILE is not None:
+            self.rec = (family, tag, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), flops)
+
+    def __enter__(self):
+        if self.rec:
+            self.rec[2].record()
+
+    def __exit__(self, *a):
+        if self.rec:
+            self.rec[3].record()
+            PROFILE.append(self.rec)
+
+
 def _chk(t, dtype=None, name="tensor"):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise _lib.MmrError(f"{name} must be a CUDA/HIP tensor (no CPU fallback in this package)")
@@ -148,10 +169,12 @@ def conv3d_k3(in0, w_packed, bias, cout, in1=None, up0=False, leaky=True, alpha=
         C1 = in1.shape[4]
     odt = torch.float32 if (out_f32 or dtype == torch.float32) else torch.bfloat16
     out = torch.empty((B, X, Y, Z, cout), dtype=odt, device=in0.device)
-    rc = _lib.load().mmr_conv3d_k3_fwd(
-        in0.data_ptr(), C0, int(up0), in1.data_ptr() if in1 is not None else None, C1,
-        w_packed.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), None,
-        B, X, Y, Z, int(cout), int(leaky), float(alpha), _DT[dtype], int(out_f32), _stream())
+    fam = f"conv3d_k3_mfma_{'bf16' if dtype == torch.bfloat16 else 'f32'}_bn{256 if cout % 256 == 0 else 128 if cout % 128 == 0 else 64 if cout % 64 == 0 else 32}"
+    with _Timed(fam, (C0 + C1, int(cout), X, Y, Z), 2.0 * 27 * (C0 + C1) * cout * B * X * Y * Z):
+        rc = _lib.load().mmr_conv3d_k3_fwd(
+            in0.data_ptr(), C0, int(up0), in1.data_ptr() if in1 is not None else None, C1,
+            w_packed.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), None,
+            B, X, Y, Z, int(cout), int(leaky), float(alpha), _DT[dtype], int(out_f32), _stream())
     _lib.check(rc, "mmr_conv3d_k3_fwd")
     return out
 
@@ -499,8 +522,9 @@ def conv3d_k3_wgrad(in0, dz, dw, in1=None, up0=False, accumulate=False):
     C1 = in1.shape[-1] if in1 is not None else 0
     lib = _lib.load()
     ws = _ws(lib.mmr_conv3d_k3_wgrad_ws_bytes(B, X, Y, Z, C0 + C1, Cout), dz.device)
-    rc = lib.mmr_conv3d_k3_wgrad_f32(in0.data_ptr(), C0, int(up0), in1.data_ptr() if in1 is not None else None, C1,
-                                     dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, X, Y, Z, Cout, int(accumulate), _stream())
+    with _Timed("conv3d_k3_wgrad_mfma_f32", (C0 + C1, Cout, X, Y, Z), 2.0 * 27 * (C0 + C1) * Cout * B * X * Y * Z):
+        rc = lib.mmr_conv3d_k3_wgrad_f32(in0.data_ptr(), C0, int(up0), in1.data_ptr() if in1 is not None else None, C1,
+                                         dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, X, Y, Z, Cout, int(accumulate), _stream())
     _lib.check(rc, "mmr_conv3d_k3_wgrad_f32")
     return dw
 
