@@ -16,7 +16,7 @@ import time
 import numpy as np
 import torch
 
-from . import ops
+from . import ops, parallel
 from .layers import to_device
 
 
@@ -57,7 +57,8 @@ class SynthMorphTrainer:
             n = w.numel()
             self.g.append(self.gflat[off:off + n].view(w.shape))
             off += n
-        self.timers = None
+        if self.world > 1:
+            parallel.broadcast_(model._flat, 0, self.pg)
 
     # ------------------------------------------------------------------ forward with tape
     def _forward(self, src, trg, tape):
@@ -189,8 +190,7 @@ class SynthMorphTrainer:
     def train_step(self, src_labels, trg_labels, draws_1=None, draws_2=None):
         out = self.forward_backward(src_labels, trg_labels, draws_1, draws_2, train=True)
         if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.pg)  # one 5.8 MB (64f) message
+            parallel.allreduce_sum_(self.gflat, self.pg)  # one 5.8 MB (64f) message
         self.opt.apply(self.model._flat, self.gflat, grad_scale=1.0 / self.world)
         self.model.invalidate_packed()
         return out
@@ -209,8 +209,7 @@ class SynthMorphTrainer:
             losses = []
             for _ in range(steps_per_epoch):
                 (src, trg), _void = next(gen)
-                b = src.shape[0] // self.world
-                sl = slice(self.rank * b, (self.rank + 1) * b)
+                sl = parallel.shard_rows(src.shape[0], self.rank, self.world)
                 o = self.train_step(src[sl], trg[sl])
                 losses.append(o["loss"])
             mean_loss = float(torch.stack(losses).mean())
@@ -219,8 +218,7 @@ class SynthMorphTrainer:
                 vl = []
                 for _ in range(validation_steps):
                     (src, trg), _void = next(validation_data)
-                    b = src.shape[0] // self.world
-                    sl = slice(self.rank * b, (self.rank + 1) * b)
+                    sl = parallel.shard_rows(src.shape[0], self.rank, self.world)
                     vl.append(self.test_step(src[sl], trg[sl])["loss"])
                 rec["val_loss"] = float(torch.stack(vl).mean())
             history.append(rec)
