@@ -25,7 +25,8 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAKS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
+PEAKS = {"bf16": 2500.0, "fp32": 157.3, "f32x3": 2500.0 / 3}   # dense MFMA TFLOP/s (MI355X_MICROARCH.md chip table);
+# f32x3 = fp32-grade products as 3 bf16 MFMAs: its algorithmic-flop ceiling is a third of the bf16 peak
 PEAK_HBM_GBS = 8000.0
 
 
@@ -100,7 +101,7 @@ def roofline_from_profile(prof, steps, dtype, traffic_file):
         return None, {}
     dom = max(fam, key=lambda k: fam[k][0])
     ms, fl, n = fam[dom]
-    peak = PEAKS["bf16" if "bf16" in dom else "fp32"]
+    peak = PEAKS["bf16" if "bf16" in dom else ("f32x3" if "f32x3" in dom else "fp32")]
     achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", traffic_file)
@@ -124,7 +125,7 @@ def main():
     ap.add_argument("--workload", default="infer", choices=["infer", "train", "ncc"])
     ap.add_argument("--features", type=int, default=None)
     ap.add_argument("--shape", type=int, nargs=3, default=None)
-    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32", "fp32x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -163,7 +164,9 @@ def main():
         from mmr import synth, training
         shape = tuple(args.shape or (160, 160, 160))
         feats = args.features or 64
-        dtype = "fp32"
+        dtype = args.dtype or "fp32"
+        if dtype == "bf16":
+            raise SystemExit("training runs fp32 or fp32x3 (fp32 tensors; bf16 hi/lo split inside the convs)")
         L = 26
         enc, dec = [feats] * 4, [feats] * 6
         maps = synth.generate_label_maps(shape, L, 2, [16, 32, 64], [8, 16, 32], 1, 3, seed=100 + rank, device=dev)
@@ -173,7 +176,7 @@ def main():
         g1 = synth.labels_to_image(**kw, id=0, seed=11 + rank)
         g2 = synth.labels_to_image(**kw, id=1, seed=12 + rank)
         model = mmr.networks.VxmDense(shape, nb_unet_features=(enc, dec), int_steps=5, int_resolution=2, svf_resolution=2,
-                                      compute_dtype="fp32", device=dev, seed=0)
+                                      compute_dtype=dtype, device=dev, seed=0)
         tr = training.SynthMorphTrainer(model, g1, g2, reg_param=1.0, optimizer=training.Adam(1e-4),
                                         world_size=world, rank=rank)
         src = torch.from_numpy(maps[0][None, ..., None]).to(dev)

@@ -31,6 +31,7 @@ extern "C" {
 
 #define MMR_DT_F32 0
 #define MMR_DT_BF16 1
+#define MMR_DT_F32X3 2  /* fp32 tensors, bf16 hi/lo split inside the conv (3 bf16 MFMAs per product) */
 
 int mmr_version(void);
 const char* mmr_error_string(int code);

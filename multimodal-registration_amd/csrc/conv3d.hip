@@ -24,6 +24,8 @@
 //     4 fp32 consecutive input channels), so one kernel template serves both.
 #include "common.hpp"
 
+#include <stdlib.h>
+
 namespace mmr {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -33,7 +35,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 constexpr int TX = 4, TY = 8, TZ = 8;                 // output tile
 constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2;  // halo tile
 constexpr int HROWS = HX * HY * HZ;                   // 600
-constexpr int ROWB = 144;                             // 128 B of channels + 16 B pad
+constexpr int ROWB = 128;                             // 128 B of channels, XOR-swizzled chunks (no pad)
 constexpr int A_BYTES = HROWS * ROWB;                 // 86400
 constexpr int CONV_THREADS = 512;
 
@@ -55,23 +57,62 @@ struct ConvParams {
 template <int DT> struct Elt;
 template <> struct Elt<MMR_DT_BF16> { static constexpr int size = 2; static constexpr int kc = 64; };
 template <> struct Elt<MMR_DT_F32> { static constexpr int size = 4; static constexpr int kc = 32; };
+// fp32 tensors in HBM, split on the fly into bf16 (hi, lo) pairs: a*b ~ hi*hi + hi*lo + lo*hi on the bf16 MFMA
+// (3 MFMAs at 16x the fp32-MFMA rate, ~1e-5 relative error): LDS row = [32 ch hi | 32 ch lo] = 128 B.
+template <> struct Elt<MMR_DT_F32X3> { static constexpr int size = 4; static constexpr int kc = 32; };
 
-__device__ __forceinline__ void glds16(const char* g, char* l)
+// LDS-DMA (global_load_lds_dwordx4) issued through inline asm so that hipcc does NOT see an LDS write:
+// with the builtin it cannot prove that the DMA destination (B buffer cur^1) and the fragment reads (sA,
+// B buffer cur) are disjoint and puts `s_waitcnt vmcnt(0)` in front of the first ds_read of every tap,
+// which serialises the weight prefetch with the MFMAs (measured: 1.1 -> see DESIGN.md).  The DMA is
+// retired by the explicit vmcnt wait in front of the end-of-tap barrier.  `lds_off` = wave-uniform LDS
+// byte address of lane 0's 16 bytes; lane i lands at lds_off + 16 i.
+__device__ __forceinline__ void glds16(const char* g, unsigned lds_off)
 {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(lds_off)
+                 : "memory");
 }
 
-template <int DT, int WM, int WN, int MT, int NT>
+__device__ __forceinline__ unsigned lds_addr(const void* p)
+{
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+// XOR swizzle of the 16-B chunk index inside a 128-B LDS row, keyed on the halo coordinates.
+// A ds_read_b128 lane group covers 2 consecutive y x 8 consecutive z voxels (see row_perm), for which
+// (hz & 1, swz) takes 16 distinct values -> every tap's fragment read is bank-conflict free with
+// unpadded rows (rocprof before: SQ_LDS_BANK_CONFLICT = 56 % of SQ_LDS_IDX_ACTIVE with 144-B rows).
+__device__ __forceinline__ int swz(int hy, int hz) { return ((hz >> 1) & 3) | ((hy & 1) << 2); }
+
+// MFMA A-row r (= lane & 31) -> voxel y_local*8 + z inside the 4(y) x 8(z) patch of an M-tile, chosen so
+// that the hardware's ds_read_b128 lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} each hold two
+// whole y-rows.
+__device__ __forceinline__ int row_perm(int r)
+{
+    const int q = r >> 2;  // 0..7
+    // q: 0 -> +0, 1,2 -> +12, 3 -> -8, 4 -> +8, 5,6 -> -12, 7 -> +0
+    const int d = (q == 0 || q == 7) ? 0 : (q <= 2 ? 12 : (q == 3 ? -8 : (q == 4 ? 8 : -12)));
+    return r + d;
+}
+
+// VAR bit 0: double-buffer the MFMA operand fragments inside a tap; bit 1: prefetch the next channel
+// slice of A into registers during tap 25 (both together exceed 256 VGPRs at the 128x64 wave tile).
+template <int DT, int WM, int WN, int MT, int NT, int VAR>
 __global__ void __launch_bounds__(CONV_THREADS, 2)
 conv3d_k3_kernel(const ConvParams p)
 {
+    constexpr bool FRAG_DB = VAR & 1, PREF_A = (VAR >> 1) & 1;
     static_assert(WM * WN == 8, "8 waves");
     static_assert(WM * MT * 32 == TX * TY * TZ, "M tile");
     constexpr int BN = WN * NT * 32;
     constexpr int ES = Elt<DT>::size;
     constexpr int KC = Elt<DT>::kc;
     constexpr int B_BYTES = BN * 128;
+    constexpr int B_ITERS = B_BYTES / (CONV_THREADS * 16);
+    constexpr int A_ITERS = ((DT == MMR_DT_F32X3 ? HROWS * 4 : HROWS * 8) + CONV_THREADS - 1) / CONV_THREADS;  // 10 (5 for fp32x3)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
@@ -81,6 +122,7 @@ conv3d_k3_kernel(const ConvParams p)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    const int h = lane >> 5;
 
     int bid = blockIdx.x;
     const int tzi = bid % p.ntz; bid /= p.ntz;
@@ -90,16 +132,17 @@ conv3d_k3_kernel(const ConvParams p)
     const int x0 = txi * TX, y0 = tyi * TY, z0 = tzi * TZ;
     const int ntile = blockIdx.y;
 
+    const int pv = row_perm(lane & 31);
+    const int vyl = pv >> 3, vz = pv & 7;  // y inside the M-tile's 4-row patch, z
     int a_off[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        const int v = (wm * MT + m) * 32 + (lane & 31);
-        const int vx = v >> 6, vy = (v >> 3) & 7, vz = v & 7;
-        a_off[m] = ((vx * HY + vy) * HZ + vz) * ROWB + (lane >> 5) * 16;
+        const int mt = wm * MT + m;  // M-tile index: x = mt >> 1, y base = (mt & 1) * 4
+        a_off[m] = (((mt >> 1) * HY + (mt & 1) * 4 + vyl) * HZ + vz) * ROWB;
     }
     int b_off[NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) b_off[n] = (((lane >> 5) * BN) + (wn * NT + n) * 32 + (lane & 31)) * 16;
+    for (int n = 0; n < NT; ++n) b_off[n] = ((h * BN) + (wn * NT + n) * 32 + (lane & 31)) * 16;
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -110,90 +153,199 @@ conv3d_k3_kernel(const ConvParams p)
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
     const int nslices = (p.C0 + p.C1) / KC;
-    const char* wtile = p.wp + (size_t)ntile * nslices * 27 * B_BYTES;
+    const int G = nslices * 27;
+    const char* wtile = p.wp + (size_t)ntile * G * B_BYTES;
     const int X2 = p.X >> 1, Y2 = p.Y >> 1, Z2 = p.Z >> 1;
 
-    int cur = 0;
-    for (int s = 0; s < nslices; ++s) {
-        __syncthreads();  // previous slice fully consumed
-        // ---- stage the haloed A tile for this channel slice ----
-        {
+    // global load of item `it` of this thread's share of the haloed tile of channel slice s.
+    // bf16 / fp32: item = (row, 16-B chunk); fp32x3: item = (row, 8-channel group) = 32 B of fp32.
+    constexpr bool X3 = (DT == MMR_DT_F32X3);
+    constexpr int A_ITEMS = X3 ? HROWS * 4 : HROWS * 8;
+    struct AItem { uint4 a, b; };
+    auto load_a = [&](int s, int it) -> AItem {
+        const int i = tid + it * CONV_THREADS;
+        AItem val;
+        val.a = make_uint4(0, 0, 0, 0);
+        val.b = make_uint4(0, 0, 0, 0);
+        if (i < A_ITEMS) {
             const int ch0 = s * KC;
             const bool first = ch0 < p.C0;
             const char* src = first ? p.in0 : p.in1;
             const int Cs = first ? p.C0 : p.C1;
             const int chs = first ? ch0 : ch0 - p.C0;
             const bool up = first && p.up0;
-            for (int i = tid; i < HROWS * 8; i += CONV_THREADS) {
-                const int row = i >> 3, chunk = i & 7;
-                const int hx = row / (HY * HZ), hy = (row / HZ) % HY, hz = row % HZ;
-                const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
-                uint4 val = make_uint4(0, 0, 0, 0);
-                if (gx >= 0 && gx < p.X && gy >= 0 && gy < p.Y && gz >= 0 && gz < p.Z) {
-                    size_t vox;
-                    if (up) vox = (((size_t)b * X2 + (gx >> 1)) * Y2 + (gy >> 1)) * Z2 + (gz >> 1);
-                    else vox = (((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz;
-                    val = *reinterpret_cast<const uint4*>(src + (vox * Cs + chs) * ES + chunk * 16);
-                }
-                *reinterpret_cast<uint4*>(sA + row * ROWB + chunk * 16) = val;
+            const int row = X3 ? (i >> 2) : (i >> 3), chunk = X3 ? (i & 3) : (i & 7);
+            const int hx = row / (HY * HZ), hy = (row / HZ) % HY, hz = row % HZ;
+            const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
+            if (gx >= 0 && gx < p.X && gy >= 0 && gy < p.Y && gz >= 0 && gz < p.Z) {
+                size_t vox;
+                if (up) vox = (((size_t)b * X2 + (gx >> 1)) * Y2 + (gy >> 1)) * Z2 + (gz >> 1);
+                else vox = (((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz;
+                const char* q = src + (vox * Cs + chs) * ES + chunk * (X3 ? 32 : 16);
+                val.a = *reinterpret_cast<const uint4*>(q);
+                if constexpr (X3) val.b = *reinterpret_cast<const uint4*>(q + 16);
             }
         }
-        const char* wslice = wtile + (size_t)s * 27 * B_BYTES;
-        // tap 0 weights
+        return val;
+    };
+    auto store_a = [&](int it, const AItem& val) {
+        const int i = tid + it * CONV_THREADS;
+        if (i < A_ITEMS) {
+            const int row = X3 ? (i >> 2) : (i >> 3), chunk = X3 ? (i & 3) : (i & 7);
+            const int hy = (row / HZ) % HY, hz = row % HZ;
+            const int sz_ = swz(hy, hz);
+            if constexpr (X3) {
+                const unsigned u[8] = {val.a.x, val.a.y, val.a.z, val.a.w, val.b.x, val.b.y, val.b.z, val.b.w};
+                unsigned hi[4], lo[4];
 #pragma unroll
-        for (int it = 0; it < B_BYTES / (CONV_THREADS * 16); ++it)
-            glds16(wslice + (it * CONV_THREADS + tid) * 16, sB + cur * B_BYTES + (it * CONV_THREADS + wave * 64) * 16);
+                for (int e = 0; e < 4; ++e) {
+                    const float f0 = __uint_as_float(u[2 * e]), f1 = __uint_as_float(u[2 * e + 1]);
+                    const bf16_t h0 = f32_to_bf16(f0), h1 = f32_to_bf16(f1);
+                    const bf16_t l0 = f32_to_bf16(f0 - bf16_to_f32(h0)), l1 = f32_to_bf16(f1 - bf16_to_f32(h1));
+                    hi[e] = (unsigned)h0 | ((unsigned)h1 << 16);
+                    lo[e] = (unsigned)l0 | ((unsigned)l1 << 16);
+                }
+                *reinterpret_cast<uint4*>(sA + row * ROWB + ((chunk ^ sz_) << 4)) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                *reinterpret_cast<uint4*>(sA + row * ROWB + (((chunk + 4) ^ sz_) << 4)) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            } else {
+                *reinterpret_cast<uint4*>(sA + row * ROWB + ((chunk ^ sz_) << 4)) = val.a;
+            }
+        }
+    };
+    const unsigned sB_lds = lds_addr(sB);
+    auto issue_b = [&](int g, int buf) {
+        const char* wt = wtile + (size_t)g * B_BYTES;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(sB_lds + buf * B_BYTES + wave * 1024);
+#pragma unroll
+        for (int it = 0; it < B_ITERS; ++it)
+            glds16(wt + (it * CONV_THREADS + tid) * 16, dst + it * CONV_THREADS * 16);
         if (B_BYTES < CONV_THREADS * 16) {
-            if (tid * 16 < B_BYTES) glds16(wslice + tid * 16, sB + cur * B_BYTES + wave * 64 * 16);
+            if (wave * 1024 < B_BYTES) glds16(wt + tid * 16, dst);
         }
-        __syncthreads();
+    };
 
-        for (int tap = 0; tap < 27; ++tap) {
-            if (tap + 1 < 27) {
-                const char* wt = wslice + (size_t)(tap + 1) * B_BYTES;
-                char* dst = sB + (cur ^ 1) * B_BYTES;
+    // ---- prologue: slice 0 of A, tap 0 of B ----
+    issue_b(0, 0);
 #pragma unroll
-                for (int it = 0; it < B_BYTES / (CONV_THREADS * 16); ++it)
-                    glds16(wt + (it * CONV_THREADS + tid) * 16, dst + (it * CONV_THREADS + wave * 64) * 16);
-                if (B_BYTES < CONV_THREADS * 16) {
-                    if (tid * 16 < B_BYTES) glds16(wt + tid * 16, dst + wave * 64 * 16);
+    for (int it = 0; it < A_ITERS; ++it) store_a(it, load_a(0, it));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    AItem pre[PREF_A ? A_ITERS : 1];
+    int cur = 0, tap = 0, s = 0;
+    for (int g = 0; g < G; ++g) {
+        const bool more = g + 1 < G;
+        if (more && !((VAR & 4) && g > 0)) issue_b(g + 1, cur ^ 1);  // VAR&4: timing-only diagnostic (stale B)
+        const bool prefetch = PREF_A && (tap == 25) && (s + 1 < nslices);
+        if constexpr (PREF_A) if (prefetch) {
+            asm volatile("" ::: "memory");  // keep the A loads younger than the LDS-DMA above (vmcnt is in issue order)
+#pragma unroll
+            for (int it = 0; it < A_ITERS; ++it) pre[it] = load_a(s + 1, it);
+        }
+        const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+        const int tapoff = (dx * (HY * HZ) + dy * HZ + dz) * ROWB;
+        const int sw = (swz(vyl + dy, vz + dz) ^ h) << 4;
+        const char* bA = sA + tapoff;
+        const char* bB = sB + cur * B_BYTES;
+        if constexpr (X3) {
+            // chunks 0..3 = hi of channels 8c..8c+7, chunks 4..7 = lo; two 16-channel k-steps per tap
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    ah[m] = *reinterpret_cast<const uint4*>(bA + a_off[m] + ((ks << 5) ^ sw));
+                    al[m] = *reinterpret_cast<const uint4*>(bA + a_off[m] + ((64 + (ks << 5)) ^ sw));
                 }
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    bh[n] = *reinterpret_cast<const uint4*>(bB + b_off[n] + ks * 2 * BN * 16);
+                    bl[n] = *reinterpret_cast<const uint4*>(bB + b_off[n] + (4 + ks * 2) * BN * 16);
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, al[m]), __builtin_bit_cast(bf16x8, bh[n]), acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, ah[m]), __builtin_bit_cast(bf16x8, bl[n]), acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, ah[m]), __builtin_bit_cast(bf16x8, bh[n]), acc[m][n], 0, 0, 0);
+                    }
             }
-            const int tapoff = ((tap / 9) * (HY * HZ) + ((tap / 3) % 3) * HZ + (tap % 3)) * ROWB;
-            const char* bA = sA + tapoff;
-            const char* bB = sB + cur * B_BYTES;
+        } else {
+        uint4 fa[2][MT], fb[2][NT];
+        if constexpr (FRAG_DB) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                uint4 fa[MT], fb[NT];
+            for (int m = 0; m < MT; ++m) fa[0][m] = *reinterpret_cast<const uint4*>(bA + a_off[m] + sw);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) fa[m] = *reinterpret_cast<const uint4*>(bA + a_off[m] + ks * 32);
+            for (int n = 0; n < NT; ++n) fb[0][n] = *reinterpret_cast<const uint4*>(bB + b_off[n]);
+        }
 #pragma unroll
-                for (int n = 0; n < NT; ++n) fb[n] = *reinterpret_cast<const uint4*>(bB + b_off[n] + ks * 2 * BN * 16);
-                if constexpr (DT == MMR_DT_BF16) {
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = FRAG_DB ? (ks & 1) : 0, nx = c ^ 1;
+            if constexpr (FRAG_DB) {
+                if (ks < 3) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        fa[nx][m] = *reinterpret_cast<const uint4*>(bA + a_off[m] + (((ks + 1) << 5) ^ sw));
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        fb[nx][n] = *reinterpret_cast<const uint4*>(bB + b_off[n] + (ks + 1) * 2 * BN * 16);
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    fa[0][m] = *reinterpret_cast<const uint4*>(bA + a_off[m] + ((ks << 5) ^ sw));
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    fb[0][n] = *reinterpret_cast<const uint4*>(bB + b_off[n] + ks * 2 * BN * 16);
+            }
+            if constexpr (DT == MMR_DT_BF16) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, fa[c][m]), __builtin_bit_cast(bf16x8, fb[c][n]), acc[m][n], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
                         for (int n = 0; n < NT; ++n)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                __builtin_bit_cast(bf16x8, fa[m]), __builtin_bit_cast(bf16x8, fb[n]), acc[m][n], 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int m = 0; m < MT; ++m)
-#pragma unroll
-                            for (int n = 0; n < NT; ++n)
-                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                                    __builtin_bit_cast(f32x4, fa[m])[j], __builtin_bit_cast(f32x4, fb[n])[j], acc[m][n], 0, 0, 0);
-                }
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                __builtin_bit_cast(f32x4, fa[c][m])[j], __builtin_bit_cast(f32x4, fb[c][n])[j], acc[m][n], 0, 0, 0);
             }
-            __syncthreads();  // drains the LDS-DMA of tap+1 and frees buffer `cur`
-            cur ^= 1;
+        }
+        }
+        if (prefetch) {
+            // retire this tap's LDS-DMA (older) but leave the A_ITERS register loads in flight across the barrier
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(X3 ? 2 * A_ITERS : A_ITERS) : "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA of tap g+1 has landed (this wave's share)
+            __syncthreads();                                  // ... everyone's has; buffer `cur` is free
+        }
+        cur ^= 1;
+        if (++tap == 27) {
+            tap = 0;
+            ++s;
+            if (s < nslices && !(VAR & 8)) {  // every wave is past its last read of sA: install the next slice (VAR&8: diagnostic)
+#pragma unroll
+                for (int it = 0; it < A_ITERS; ++it) {
+                    if constexpr (PREF_A) store_a(it, pre[it]);
+                    else store_a(it, load_a(s, it));
+                }
+                __syncthreads();
+            }
         }
     }
 
     // ---- epilogue: bias + LeakyReLU, store ----
-    const bool store_f32 = (DT == MMR_DT_F32) || p.out_f32;
+    const bool store_f32 = (DT != MMR_DT_BF16) || p.out_f32;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int co = ntile * BN + (wn * NT + n) * 32 + (lane & 31);
@@ -201,11 +353,11 @@ conv3d_k3_kernel(const ConvParams p)
         const float bv = (cok && p.bias) ? p.bias[co] : 0.f;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
+            const int mt = wm * MT + m;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int v = (wm * MT + m) * 32 + row;
-                const int gx = x0 + (v >> 6), gy = y0 + ((v >> 3) & 7), gz = z0 + (v & 7);
+                const int q = row_perm((r & 3) + 8 * (r >> 2) + 4 * h);
+                const int gx = x0 + (mt >> 1), gy = y0 + (mt & 1) * 4 + (q >> 3), gz = z0 + (q & 7);
                 if (cok && gx < p.X && gy < p.Y && gz < p.Z) {
                     float val = acc[m][n][r] + bv;
                     if (p.leaky && val < 0.f) val *= p.alpha;
@@ -231,9 +383,8 @@ template <int DT>
 __global__ void pack_kernel(const float* __restrict__ w, char* __restrict__ wp, int Cin, int Cout, int BN, int ntiles,
                             int transpose_flip)
 {
-    constexpr int ES = Elt<DT>::size;
     constexpr int KC = Elt<DT>::kc;
-    constexpr int EPC = 16 / ES;  // elements per 16-B chunk
+    constexpr int EPC = (DT == MMR_DT_F32) ? 4 : 8;  // elements per 16-B chunk (fp32x3 chunks hold 8 bf16)
     const int nslices = Cin / KC;
     const int64_t total = (int64_t)ntiles * nslices * 27 * 8 * BN;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -247,25 +398,31 @@ __global__ void pack_kernel(const float* __restrict__ w, char* __restrict__ wp, 
         char* dst = wp + i * 16;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            const int ci = s * KC + chunk * EPC + e;
+            const int cc = (DT == MMR_DT_F32X3) ? (chunk & 3) : chunk;
+            const int ci = s * KC + cc * EPC + e;
             float v = 0.f;
             if (co < Cout) {
                 if (transpose_flip) v = w[((int64_t)(26 - tap) * Cout + co) * Cin + ci];  // keras dims [27][Cout][Cin]
                 else v = w[((int64_t)tap * Cin + ci) * Cout + co];
             }
-            if (DT == MMR_DT_BF16) reinterpret_cast<bf16_t*>(dst)[e] = f32_to_bf16(v);
-            else reinterpret_cast<float*>(dst)[e] = v;
+            if (DT == MMR_DT_F32) {
+                reinterpret_cast<float*>(dst)[e] = v;
+            } else {
+                bf16_t hb = f32_to_bf16(v);
+                if (DT == MMR_DT_F32X3 && chunk >= 4) hb = f32_to_bf16(v - bf16_to_f32(hb));  // lo part
+                reinterpret_cast<bf16_t*>(dst)[e] = hb;
+            }
         }
     }
 }
 
-template <int DT, int WM, int WN, int MT, int NT>
+template <int DT, int WM, int WN, int MT, int NT, int VAR>
 int launch_conv(const ConvParams& p, int ntiles_n, hipStream_t st)
 {
     constexpr int BN = WN * NT * 32;
     constexpr int LDS = A_BYTES + 2 * BN * 128;
     static bool attr_set = false;
-    auto kern = conv3d_k3_kernel<DT, WM, WN, MT, NT>;
+    auto kern = conv3d_k3_kernel<DT, WM, WN, MT, NT, VAR>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -283,11 +440,22 @@ int dispatch_conv(const ConvParams& p, hipStream_t st)
 {
     const int BN = conv_bn(p.Cout);
     const int nt = (p.Cout + BN - 1) / BN;
+    static int var = -1;  // MMR_CONV_VARIANT: 0 plain, 1 fragment double-buffer, 2 A-slice register prefetch (A/B testing)
+    if (var < 0) {
+        const char* e = getenv("MMR_CONV_VARIANT");
+        var = e ? atoi(e) : 1;
+    }
     switch (BN) {
-        case 256: return launch_conv<DT, 2, 4, 4, 2>(p, nt, st);
-        case 128: return launch_conv<DT, 4, 2, 2, 2>(p, nt, st);
-        case 64: return launch_conv<DT, 8, 1, 1, 2>(p, nt, st);
-        default: return launch_conv<DT, 8, 1, 1, 1>(p, nt, st);
+        case 256:
+            if (var == 0) return launch_conv<DT, 2, 4, 4, 2, 0>(p, nt, st);
+            if (var == 2) return launch_conv<DT, 2, 4, 4, 2, 2>(p, nt, st);
+            if (var == 4) return launch_conv<DT, 2, 4, 4, 2, 4>(p, nt, st);
+            if (var == 8) return launch_conv<DT, 2, 4, 4, 2, 8>(p, nt, st);
+            if (var == 12) return launch_conv<DT, 2, 4, 4, 2, 12>(p, nt, st);
+            return launch_conv<DT, 2, 4, 4, 2, 1>(p, nt, st);
+        case 128: return launch_conv<DT, 4, 2, 2, 2, 3>(p, nt, st);
+        case 64: return launch_conv<DT, 8, 1, 1, 2, 3>(p, nt, st);
+        default: return launch_conv<DT, 8, 1, 1, 1, 3>(p, nt, st);
     }
 }
 
@@ -417,7 +585,7 @@ extern "C" int64_t mmr_conv3d_k3_packed_bytes(int Cin, int Cout, int dtype)
 {
     if (Cin < 1 || Cout < 1) return MMR_EINVAL;
     const int kc = (dtype == MMR_DT_BF16) ? 64 : 32;
-    if (dtype != MMR_DT_BF16 && dtype != MMR_DT_F32) return MMR_EINVAL;
+    if (dtype != MMR_DT_BF16 && dtype != MMR_DT_F32 && dtype != MMR_DT_F32X3) return MMR_EINVAL;
     if (Cin % kc) return MMR_EINVAL;
     const int BN = conv_bn(Cout);
     const int nt = (Cout + BN - 1) / BN;
@@ -435,6 +603,9 @@ extern "C" int mmr_conv3d_k3_pack(const float* w_keras, void* w_packed, int Cin,
     if (dtype == MMR_DT_BF16)
         hipLaunchKernelGGL(pack_kernel<MMR_DT_BF16>, dim3(grid), dim3(256), 0, as_stream(stream), w_keras,
                            (char*)w_packed, Cin, Cout, BN, nt, transpose_flip);
+    else if (dtype == MMR_DT_F32X3)
+        hipLaunchKernelGGL(pack_kernel<MMR_DT_F32X3>, dim3(grid), dim3(256), 0, as_stream(stream), w_keras,
+                           (char*)w_packed, Cin, Cout, BN, nt, transpose_flip);
     else
         hipLaunchKernelGGL(pack_kernel<MMR_DT_F32>, dim3(grid), dim3(256), 0, as_stream(stream), w_keras,
                            (char*)w_packed, Cin, Cout, BN, nt, transpose_flip);
@@ -446,7 +617,7 @@ extern "C" int mmr_conv3d_k3_fwd(const void* in0, int C0, int up0, const void* i
                                  int leaky, float alpha, int dtype, int out_f32, void* stream)
 {
     if (!in0 || !w_packed || !out || B < 1 || X < 1 || Y < 1 || Z < 1 || Cout < 1 || C0 < 1 || C1 < 0) return MMR_EINVAL;
-    if (dtype != MMR_DT_BF16 && dtype != MMR_DT_F32) return MMR_EINVAL;
+    if (dtype != MMR_DT_BF16 && dtype != MMR_DT_F32 && dtype != MMR_DT_F32X3) return MMR_EINVAL;
     if (C1 > 0 && !in1) return MMR_EINVAL;
     if (pool_out) return MMR_EUNSUPPORTED;  // fused pooling: planned; use mmr_maxpool3d2_fwd
     const int kc = (dtype == MMR_DT_BF16) ? 64 : 32;
@@ -459,6 +630,7 @@ extern "C" int mmr_conv3d_k3_fwd(const void* in0, int C0, int up0, const void* i
     p.leaky = leaky; p.alpha = alpha; p.out_f32 = out_f32;
     p.ntx = (X + TX - 1) / TX; p.nty = (Y + TY - 1) / TY; p.ntz = (Z + TZ - 1) / TZ;
     if (dtype == MMR_DT_BF16) return dispatch_conv<MMR_DT_BF16>(p, as_stream(stream));
+    if (dtype == MMR_DT_F32X3) return dispatch_conv<MMR_DT_F32X3>(p, as_stream(stream));
     return dispatch_conv<MMR_DT_F32>(p, as_stream(stream));
 }
 

@@ -382,13 +382,17 @@ leaky_bwd_bias_kernel(const float* __restrict__ y, const float* __restrict__ dy,
     }
 }
 
-__global__ void bias_final_kernel(const double* __restrict__ part, float* __restrict__ db, int C, int nblk, int accumulate)
+// one wave per channel: ordered strided partial sums, then a wave reduction
+__global__ void __launch_bounds__(64)
+bias_final_kernel(const double* __restrict__ part, float* __restrict__ db, int C, int nblk, int accumulate)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;
     double r = 0.0;
-    for (int k = 0; k < nblk; ++k) r += part[(int64_t)k * C + c];
-    if (accumulate) db[c] += (float)r; else db[c] = (float)r;
+    for (int k = threadIdx.x; k < nblk; k += 64) r += part[(int64_t)k * C + c];
+    r = wave_sum(r);
+    if (threadIdx.x == 0) {
+        if (accumulate) db[c] += (float)r; else db[c] = (float)r;
+    }
 }
 
 // split the gradient of concat([up2(in0), in1]): d_in0 = 2x2x2 sum-pool of dcat[..., :C0] ; d_in1 (+)= dcat[..., C0:]
@@ -487,9 +491,14 @@ struct WgradParams {
     int ntx, nty, ntz, ntiles;
 };
 
+// Wave w owns the accumulator tiles (tap = (w >> 1) + 4 j, co-tile = w & 1), j = 0..6 (units 54, 55 of the
+// 8 x 7 grid are padding and never stored) -> per k-step (2 voxels): ONE dZ read, 7 X reads, 7 MFMAs, no
+// branches.  The next voxel tile is prefetched into registers while the current one is consumed.
+template <int COT>  // co-tiles of 32 per 64-wide block: 2 (general) or 1 (Cout <= 32, e.g. the flow head)
 __global__ void __launch_bounds__(W_THREADS, 2)
 wgrad_kernel(const WgradParams p)
 {
+    constexpr int NU = (COT == 2) ? 7 : 4;  // accumulator tiles per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
     char* sB = smem + W_A_BYTES;
@@ -503,88 +512,128 @@ wgrad_kernel(const WgradParams p)
     const int chs = first ? ch0 : ch0 - p.C0;
     const bool up = first && p.up0;
     const int X2 = p.X >> 1, Y2 = p.Y >> 1, Z2 = p.Z >> 1;
+    constexpr int A_IT = (W_HROWS * 8 + W_THREADS - 1) / W_THREADS;  // 10
+    constexpr int B_IT = 256 * 16 / W_THREADS;                       // 8
 
-    f32x16 acc[W_UNITS];
-    int tapoff[W_UNITS], cotile[W_UNITS];
+    f32x16 acc[NU];
+    int tapoff[NU];
 #pragma unroll
-    for (int j = 0; j < W_UNITS; ++j) {
+    for (int j = 0; j < NU; ++j) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        const int u = wave + 8 * j;
-        const int tap = (u < 54) ? (u >> 1) : 0;
-        cotile[j] = u & 1;
+        int tap = (COT == 2) ? (wave >> 1) + 4 * j : wave + 8 * j;
+        if (tap > 26) tap = 26;  // padding unit: valid address, result discarded
         tapoff[j] = ((tap / 9) * (W_HY * W_HZ) + ((tap / 3) % 3) * W_HZ + (tap % 3)) * W_ROWB;
     }
     const int a_lane = (lane >> 5) * W_ROWB + (lane & 31) * 4;
-    const int b_lane = (lane >> 5) * W_DZROW + (lane & 31) * 4;
+    const int cot = (COT == 2) ? (wave & 1) : 0;
+    const int b_lane = (lane >> 5) * W_DZROW + (cot * 32 + (lane & 31)) * 4;
 
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    auto tile_origin = [&](int tile, int& b, int& x0, int& y0, int& z0) {
         int t = tile;
         const int tzi = t % p.ntz; t /= p.ntz;
         const int tyi = t % p.nty; t /= p.nty;
         const int txi = t % p.ntx;
-        const int b = t / p.ntx;
-        const int x0 = txi * W_TX, y0 = tyi * W_TY, z0 = tzi * W_TZ;
-        __syncthreads();
-        for (int i = tid; i < W_HROWS * 8; i += W_THREADS) {
+        b = t / p.ntx;
+        x0 = txi * W_TX; y0 = tyi * W_TY; z0 = tzi * W_TZ;
+    };
+    auto load_a = [&](int b, int x0, int y0, int z0, int it) -> float4 {
+        const int i = tid + it * W_THREADS;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < W_HROWS * 8) {
             const int row = i >> 3, chunk = i & 7;
             const int hx = row / (W_HY * W_HZ), hy = (row / W_HZ) % W_HY, hz = row % W_HZ;
             const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gx >= 0 && gx < p.X && gy >= 0 && gy < p.Y && gz >= 0 && gz < p.Z) {
                 size_t vox;
                 if (up) vox = (((size_t)b * X2 + (gx >> 1)) * Y2 + (gy >> 1)) * Z2 + (gz >> 1);
                 else vox = (((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz;
                 val = *reinterpret_cast<const float4*>(src + vox * Cs + chs + chunk * 4);
             }
-            *reinterpret_cast<float4*>(sA + row * W_ROWB + chunk * 16) = val;
         }
-        for (int i = tid; i < 256 * 16; i += W_THREADS) {
-            const int v = i >> 4, chunk = i & 15;
-            const int gx = x0 + (v >> 6), gy = y0 + ((v >> 3) & 7), gz = z0 + (v & 7);
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gx < p.X && gy < p.Y && gz < p.Z) {
-                const float* q = p.dz + ((((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz) * p.Cout;
-                const int co = cob * 64 + chunk * 4;
-                if (co + 3 < p.Cout) val = *reinterpret_cast<const float4*>(q + co);
-                else {
-                    if (co < p.Cout) val.x = q[co];
-                    if (co + 1 < p.Cout) val.y = q[co + 1];
-                    if (co + 2 < p.Cout) val.z = q[co + 2];
-                }
+        return val;
+    };
+    auto load_b = [&](int b, int x0, int y0, int z0, int it) -> float4 {
+        const int i = tid + it * W_THREADS;
+        const int v = i >> 4, chunk = i & 15;
+        const int gx = x0 + (v >> 6), gy = y0 + ((v >> 3) & 7), gz = z0 + (v & 7);
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gx < p.X && gy < p.Y && gz < p.Z) {
+            const float* q = p.dz + ((((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz) * p.Cout;
+            const int co = cob * 64 + chunk * 4;
+            if (co + 3 < p.Cout) val = *reinterpret_cast<const float4*>(q + co);
+            else {
+                if (co < p.Cout) val.x = q[co];
+                if (co + 1 < p.Cout) val.y = q[co + 1];
+                if (co + 2 < p.Cout) val.z = q[co + 2];
             }
-            *reinterpret_cast<float4*>(sB + v * W_DZROW + chunk * 16) = val;
         }
+        return val;
+    };
+    auto store_a = [&](int it, float4 val) {
+        const int i = tid + it * W_THREADS;
+        if (i < W_HROWS * 8) *reinterpret_cast<float4*>(sA + (i >> 3) * W_ROWB + (i & 7) * 16) = val;
+    };
+    auto store_b = [&](int it, float4 val) {
+        const int i = tid + it * W_THREADS;
+        *reinterpret_cast<float4*>(sB + (i >> 4) * W_DZROW + (i & 15) * 16) = val;
+    };
+
+    float4 pa[A_IT], pb[B_IT];
+    int tile = blockIdx.x;
+    if (tile < p.ntiles) {
+        int b, x0, y0, z0;
+        tile_origin(tile, b, x0, y0, z0);
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) pa[it] = load_a(b, x0, y0, z0, it);
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) pb[it] = load_b(b, x0, y0, z0, it);
+    }
+    for (; tile < p.ntiles; tile += gridDim.x) {
+        __syncthreads();  // everyone is done with the previous tile's LDS image
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) store_a(it, pa[it]);
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) store_b(it, pb[it]);
         __syncthreads();
+        const int nxt = tile + gridDim.x;
+        if (nxt < p.ntiles) {  // register prefetch of the next tile, hidden under this tile's MFMAs
+            int b, x0, y0, z0;
+            tile_origin(nxt, b, x0, y0, z0);
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) pa[it] = load_a(b, x0, y0, z0, it);
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it) pb[it] = load_b(b, x0, y0, z0, it);
+        }
         for (int vx = 0; vx < W_TX; ++vx)
             for (int vy = 0; vy < W_TY; ++vy) {
-                const int hbase = ((vx * W_HY + vy) * W_HZ) * W_ROWB;
-                const int vbase = ((vx << 6) | (vy << 3)) * W_DZROW;
+                const int hbase = ((vx * W_HY + vy) * W_HZ) * W_ROWB + a_lane;
+                const char* bp = sB + ((vx << 6) | (vy << 3)) * W_DZROW + b_lane;
+                const char* ap[NU];
+#pragma unroll
+                for (int j = 0; j < NU; ++j) ap[j] = sA + hbase + tapoff[j];
 #pragma unroll
                 for (int vz = 0; vz < W_TZ; vz += 2) {
-                    const float b0 = *reinterpret_cast<const float*>(sB + vbase + vz * W_DZROW + b_lane);
-                    const float b1 = *reinterpret_cast<const float*>(sB + vbase + vz * W_DZROW + b_lane + 128);
+                    const float bv = *reinterpret_cast<const float*>(bp + vz * W_DZROW);
+                    float av[NU];
 #pragma unroll
-                    for (int j = 0; j < W_UNITS; ++j) {
-                        if (wave + 8 * j < 54) {
-                            const float a = *reinterpret_cast<const float*>(sA + hbase + vz * W_ROWB + tapoff[j] + a_lane);
-                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, cotile[j] ? b1 : b0, acc[j], 0, 0, 0);
-                        }
-                    }
+                    for (int j = 0; j < NU; ++j) av[j] = *reinterpret_cast<const float*>(ap[j] + vz * W_ROWB);
+#pragma unroll
+                    for (int j = 0; j < NU; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv, acc[j], 0, 0, 0);
                 }
             }
     }
     // slab[blk][slice][cob][tap][ci 32][co 64]
     float* out = p.slab + (((size_t)blockIdx.x * gridDim.y + slice) * gridDim.z + cob) * (27 * 32 * 64);
 #pragma unroll
-    for (int j = 0; j < W_UNITS; ++j) {
-        const int u = wave + 8 * j;
-        if (u < 54) {
-            const int tap = u >> 1, ct = u & 1;
+    for (int j = 0; j < NU; ++j) {
+        const int tap = (COT == 2) ? (wave >> 1) + 4 * j : wave + 8 * j;
+        if (tap < 27) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ci = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                out[(tap * 32 + ci) * 64 + ct * 32 + (lane & 31)] = acc[j][r];
+                out[(tap * 32 + ci) * 64 + cot * 32 + (lane & 31)] = acc[j][r];
             }
         }
     }
@@ -682,9 +731,111 @@ sum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int
 }
 
 // flow head dgrad: dX[v][ci] = sum_tap sum_co dY[v - off(tap)][co] * W[tap][ci][co]   (Cout = 3)
+// Lanes = voxels: each lane gathers its 27 x 3 dY neighbourhood into registers once, then the wave loops
+// over the input channels with the 81 weights of that channel wave-uniform (scalar loads, K$-resident:
+// 27*Cin*3 floats), 81 v_fma per channel, 16-B stores of 4 channels per lane (a lane writes its whole
+// Cin row over the loop, so L2 merges the pieces into full lines).
 __global__ void __launch_bounds__(TB)
 dgrad_cout3_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int B, int X,
                    int Y, int Z, int Cin)
+{
+    const int64_t nvox = (int64_t)X * Y * Z;
+    const int64_t total = (int64_t)B * nvox;
+    const int64_t v = (int64_t)blockIdx.x * TB + threadIdx.x;
+    const bool live = v < total;
+    const int64_t vv = live ? v : 0;
+    const int64_t b = vv / nvox;
+    const int64_t r = vv - b * nvox;
+    const int z = (int)(r % Z), y = (int)((r / Z) % Y), x = (int)(r / ((int64_t)Z * Y));
+    float g[81];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+        const int sx = x - (t / 9 - 1), sy = y - ((t / 3) % 3 - 1), sz = z - (t % 3 - 1);
+        const bool ok = sx >= 0 && sx < X && sy >= 0 && sy < Y && sz >= 0 && sz < Z;
+        const float* q = dy + (b * nvox + ((int64_t)(ok ? sx : x) * Y + (ok ? sy : y)) * Z + (ok ? sz : z)) * 3;
+        g[t * 3] = ok ? q[0] : 0.f;
+        g[t * 3 + 1] = ok ? q[1] : 0.f;
+        g[t * 3 + 2] = ok ? q[2] : 0.f;
+    }
+    float* o = dx + vv * Cin;
+    for (int c4 = 0; c4 < Cin; c4 += 4) {
+        float a[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float* ww = w + (size_t)(c4 + k) * 3;  // w[(t*Cin + ci)*3 + co], wave-uniform
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < 27; ++t) {
+                const float* wt = ww + (size_t)t * Cin * 3;
+                acc = fmaf(g[t * 3], wt[0], acc);
+                acc = fmaf(g[t * 3 + 1], wt[1], acc);
+                acc = fmaf(g[t * 3 + 2], wt[2], acc);
+            }
+            a[k] = acc;
+        }
+        if (live) *reinterpret_cast<float4*>(o + c4) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+}
+
+// flow head wgrad: dW[t][ci][co] = sum_v X[v+off(t)][ci] * dY[v][co]  (Cout = 3).  Lanes = input channels;
+// a wave walks z-runs of voxels: X rows are coalesced 256-B loads (27x reuse through L1), dY[v][0..2] is
+// wave-uniform (scalar loads), 81 accumulators per lane; per-block partials are reduced in fixed order.
+constexpr int WG3_RUN = 32;
+__global__ void __launch_bounds__(TB)
+wgrad_cout3_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int B, int X,
+                   int Y, int Z, int Cin, int nzr, int64_t njobs)
+{
+    __shared__ float red[TB];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ncb = Cin / 64;
+    const int cb = blockIdx.y;
+    const int ci = cb * 64 + lane;
+    float acc[81];
+#pragma unroll
+    for (int k = 0; k < 81; ++k) acc[k] = 0.f;
+    const int64_t nvox = (int64_t)X * Y * Z;
+    for (int64_t job = (int64_t)blockIdx.x * (TB / 64) + wave; job < njobs; job += (int64_t)gridDim.x * (TB / 64)) {
+        int64_t j = job;
+        const int zr = (int)(j % nzr); j /= nzr;
+        const int y = (int)(j % Y); j /= Y;
+        const int xx = (int)(j % X);
+        const int b = (int)(j / X);
+        const int z0 = zr * WG3_RUN;
+        const int z1 = (z0 + WG3_RUN < Z) ? z0 + WG3_RUN : Z;
+        const float* xb = x + (size_t)b * nvox * Cin + ci;
+        const float* dyb = dy + (size_t)b * nvox * 3;
+        for (int z = z0; z < z1; ++z) {
+            const float* gq = dyb + (((size_t)xx * Y + y) * Z + z) * 3;
+            const float g0 = gq[0], g1 = gq[1], g2 = gq[2];
+#pragma unroll
+            for (int t = 0; t < 27; ++t) {
+                const int sx = xx + (t / 9 - 1), sy = y + ((t / 3) % 3 - 1), sz = z + (t % 3 - 1);
+                const bool ok = sx >= 0 && sx < X && sy >= 0 && sy < Y && sz >= 0 && sz < Z;  // wave-uniform
+                const float xv = ok ? xb[(((size_t)sx * Y + sy) * Z + sz) * Cin] : 0.f;
+                acc[t * 3] = fmaf(xv, g0, acc[t * 3]);
+                acc[t * 3 + 1] = fmaf(xv, g1, acc[t * 3 + 1]);
+                acc[t * 3 + 2] = fmaf(xv, g2, acc[t * 3 + 2]);
+            }
+        }
+    }
+    // combine the block's 4 waves, write partial [blk][27][Cin][3]
+    for (int k = 0; k < 81; ++k) {
+        __syncthreads();
+        red[threadIdx.x] = acc[k];
+        __syncthreads();
+        if (wave == 0) {
+            const float sum = red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane];
+            part[((size_t)blockIdx.x * 27 + k / 3) * Cin * 3 + (size_t)ci * 3 + (k % 3)] = sum;
+        }
+    }
+    (void)ncb;
+}
+
+// generic fallback (any Cin): one thread per (voxel, ci), weights in LDS
+__global__ void __launch_bounds__(TB)
+dgrad_cout3_generic_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int B,
+                           int X, int Y, int Z, int Cin)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sw = reinterpret_cast<float*>(smem);  // [27][Cin][3]
@@ -884,7 +1035,7 @@ extern "C" int mmr_leaky_bwd_bias_f32(const float* y, const float* dy, float* dz
                        (double*)ws, nvox, C, alpha, leaky, nblk);
     int rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(bias_final_kernel, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream), (const double*)ws, dbias,
+    hipLaunchKernelGGL(bias_final_kernel, dim3(C), dim3(64), 0, as_stream(stream), (const double*)ws, dbias,
                        C, nblk, accumulate);
     return check_launch();
 }
@@ -927,7 +1078,10 @@ extern "C" int64_t mmr_conv3d_k3_wgrad_ws_bytes(int B, int X, int Y, int Z, int 
     if (B < 1 || X < 1 || Y < 1 || Z < 1 || Cin < 32 || Cin % 32 || Cout < 1) return MMR_EINVAL;
     int ntx, nty, ntz, ntiles, nslices, ncob, gx;
     wgrad_geom(B, X, Y, Z, Cin, Cout, ntx, nty, ntz, ntiles, nslices, ncob, gx);
-    return (int64_t)gx * nslices * ncob * 27 * 32 * 64 * sizeof(float);
+    int64_t bytes = (int64_t)gx * nslices * ncob * 27 * 32 * 64 * sizeof(float);
+    const int64_t valu = (int64_t)1024 * 27 * Cin * 3 * sizeof(float);  // wgrad_cout3_kernel partials
+    if (Cout == 3 && valu > bytes) bytes = valu;
+    return bytes;
 }
 
 // dW (Keras layout [27][C0+C1][Cout]) (+)= wgrad of conv(concat([up2(in0)|in0, in1])) given dZ [B,X,Y,Z,Cout]
@@ -939,6 +1093,19 @@ extern "C" int mmr_conv3d_k3_wgrad_f32(const float* in0, int C0, int up0, const 
         C1 % 32 || (C1 > 0 && !in1))
         return MMR_EINVAL;
     if (up0 && ((X | Y | Z) & 1)) return MMR_EINVAL;
+    if (Cout == 3 && C1 == 0 && !up0 && C0 % 64 == 0) {  // flow head: VALU kernel, scalar dY, no padding waste
+        const int nzr = (Z + WG3_RUN - 1) / WG3_RUN;
+        const int64_t njobs = (int64_t)B * X * Y * nzr;
+        int nblk = (int)((njobs + 3) / 4 < 1024 ? (njobs + 3) / 4 : 1024);
+        if ((int64_t)nblk * 27 * C0 * 3 * (int64_t)sizeof(float) > mmr_conv3d_k3_wgrad_ws_bytes(B, X, Y, Z, C0, Cout)) nblk = 1;
+        hipLaunchKernelGGL(wgrad_cout3_kernel, dim3(nblk, C0 / 64), dim3(TB), 0, as_stream(stream), in0, dz, (float*)ws,
+                           B, X, Y, Z, C0, nzr, njobs);
+        int rc0 = check_launch();
+        if (rc0) return rc0;
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(stream_grid((int64_t)27 * C0 * 3, TB)), dim3(TB), 0,
+                           as_stream(stream), (const float*)ws, dw, (int64_t)27 * C0 * 3, nblk, accumulate);
+        return check_launch();
+    }
     WgradParams p;
     p.in0 = in0; p.in1 = in1; p.dz = dz; p.slab = (float*)ws;
     p.B = B; p.X = X; p.Y = Y; p.Z = Z; p.C0 = C0; p.C1 = C1; p.up0 = up0; p.Cout = Cout;
@@ -947,12 +1114,18 @@ extern "C" int mmr_conv3d_k3_wgrad_f32(const float* in0, int C0, int up0, const 
     constexpr int LDS = W_A_BYTES + W_B_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<2>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
         attr_set = true;
     }
-    hipLaunchKernelGGL(wgrad_kernel, dim3(gx, nslices, ncob), dim3(W_THREADS), LDS, as_stream(stream), p);
+    if (Cout <= 32)
+        hipLaunchKernelGGL(wgrad_kernel<1>, dim3(gx, nslices, ncob), dim3(W_THREADS), LDS, as_stream(stream), p);
+    else
+        hipLaunchKernelGGL(wgrad_kernel<2>, dim3(gx, nslices, ncob), dim3(W_THREADS), LDS, as_stream(stream), p);
     int rc = check_launch();
     if (rc) return rc;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(stream_grid((int64_t)27 * (C0 + C1) * Cout, TB)), dim3(TB), 0,
@@ -983,15 +1156,22 @@ extern "C" int mmr_conv3d_k3_cout3_dgrad_f32(const float* dy, const float* w_ker
                                              int Z, int Cin, void* stream)
 {
     if (!dy || !w_keras || !dx || B < 1 || X < 1 || Y < 1 || Z < 1 || Cin < 1 || Cin > 512) return MMR_EINVAL;
+    if (Cin % 4 == 0) {
+        const int64_t nblk = ((int64_t)B * X * Y * Z + TB - 1) / TB;
+        if (nblk > 0x7fffffff) return MMR_EINVAL;
+        hipLaunchKernelGGL(dgrad_cout3_kernel, dim3((unsigned)nblk), dim3(TB), 0, as_stream(stream), dy, w_keras, dx, B,
+                           X, Y, Z, Cin);
+        return check_launch();
+    }
     const size_t lds = (size_t)27 * Cin * 3 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_cout3_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_cout3_generic_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 27 * 512 * 3 * sizeof(float));
         if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
         attr_set = true;
     }
-    hipLaunchKernelGGL(dgrad_cout3_kernel, dim3(stream_grid((int64_t)B * X * Y * Z * Cin, TB)), dim3(TB), lds,
+    hipLaunchKernelGGL(dgrad_cout3_generic_kernel, dim3(stream_grid((int64_t)B * X * Y * Z * Cin, TB)), dim3(TB), lds,
                        as_stream(stream), dy, w_keras, dx, B, X, Y, Z, Cin);
     return check_launch();
 }

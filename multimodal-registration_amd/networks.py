@@ -73,12 +73,16 @@ class VxmDense:
         self.input_model = input_model
         self.name = name
         self.device = torch.device(device)
+        self.x3 = False
         if compute_dtype in ("bf16", torch.bfloat16):
             self.dtype = torch.bfloat16
         elif compute_dtype in ("fp32", "float32", torch.float32):
             self.dtype = torch.float32
+        elif compute_dtype == "fp32x3":  # fp32 tensors, bf16 hi/lo split inside the convs (fp32-grade accuracy)
+            self.dtype = torch.float32
+            self.x3 = True
         else:
-            raise ValueError("compute_dtype must be 'bf16' or 'fp32'")
+            raise ValueError("compute_dtype must be 'bf16', 'fp32' or 'fp32x3'")
         nlev = len(enc)
         if any(s % (2 ** nlev) for s in self.inshape):
             raise ValueError(f"inshape {self.inshape} must be divisible by 2**{nlev} (U-Net skip concat)")
@@ -147,7 +151,8 @@ class VxmDense:
 
     def _pack(self):
         if self._packed is None:
-            self._packed = [None] + [ops.pack_conv_weights(self._w[2 * i], self.dtype) for i in range(1, len(self.plan))]
+            self._packed = [None] + [ops.pack_conv_weights(self._w[2 * i], self.dtype, x3=self.x3)
+                                     for i in range(1, len(self.plan))]
         return self._packed
 
     def count_params(self):
@@ -185,7 +190,7 @@ class VxmDense:
     # ------------------------------------------------------------------ forward
     def _conv(self, li, x, **kw):
         """Layer li of the plan on the MFMA kernel."""
-        return ops.conv3d_k3(x, self._packed[li], self._w[2 * li + 1], self.plan[li][2], **kw)
+        return ops.conv3d_k3(x, self._packed[li], self._w[2 * li + 1], self.plan[li][2], x3=self.x3, **kw)
 
     def unet(self, src, trg):
         """[B,X,Y,Z,1] x2 (f32) -> flow [B,X,Y,Z,3] f32."""

@@ -8,9 +8,17 @@ import torch
 
 from . import _lib
 
-F32, BF16 = 0, 1
+F32, BF16, F32X3 = 0, 1, 2
 LINEAR, NEAREST = 0, 1
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def conv_mode(dtype, x3=False):
+    """MFMA conv arithmetic: bf16 tensors -> BF16; fp32 tensors -> exact fp32 MFMA, or (x3) the bf16
+    hi/lo split with three bf16 MFMAs per product (fp32-grade accuracy at ~5x the fp32-MFMA rate)."""
+    if dtype == torch.bfloat16:
+        return BF16
+    return F32X3 if x3 else F32
 
 
 def _stream():
@@ -138,23 +146,24 @@ def conv_kc(dtype):
     return 64 if dtype == torch.bfloat16 else 32
 
 
-def pack_conv_weights(w_keras, dtype, transpose_flip=False):
+def pack_conv_weights(w_keras, dtype, transpose_flip=False, x3=False):
     """w_keras [3,3,3,Cin,Cout] f32 (device) -> packed MFMA operand image (uint8 tensor)."""
     _chk(w_keras, torch.float32, "w_keras")
     cin, cout = int(w_keras.shape[3]), int(w_keras.shape[4])
     if transpose_flip:
         cin, cout = cout, cin
     lib = _lib.load()
-    nbytes = lib.mmr_conv3d_k3_packed_bytes(cin, cout, _DT[dtype])
+    mode = conv_mode(dtype, x3)
+    nbytes = lib.mmr_conv3d_k3_packed_bytes(cin, cout, mode)
     if nbytes < 0:
         raise _lib.MmrError(f"cannot pack conv weights Cin={cin} Cout={cout} for {dtype}")
     out = torch.empty(nbytes, dtype=torch.uint8, device=w_keras.device)
-    rc = lib.mmr_conv3d_k3_pack(w_keras.data_ptr(), out.data_ptr(), cin, cout, _DT[dtype], int(transpose_flip), _stream())
+    rc = lib.mmr_conv3d_k3_pack(w_keras.data_ptr(), out.data_ptr(), cin, cout, mode, int(transpose_flip), _stream())
     _lib.check(rc, "mmr_conv3d_k3_pack")
     return out
 
 
-def conv3d_k3(in0, w_packed, bias, cout, in1=None, up0=False, leaky=True, alpha=0.2, out_f32=False):
+def conv3d_k3(in0, w_packed, bias, cout, in1=None, up0=False, leaky=True, alpha=0.2, out_f32=False, x3=False):
     """Conv3D(cout,3,'same')(concat([up2(in0) if up0 else in0, in1])) + bias (+LeakyReLU)."""
     dtype = in0.dtype
     _chk(in0, dtype, "in0")
@@ -169,12 +178,13 @@ def conv3d_k3(in0, w_packed, bias, cout, in1=None, up0=False, leaky=True, alpha=
         C1 = in1.shape[4]
     odt = torch.float32 if (out_f32 or dtype == torch.float32) else torch.bfloat16
     out = torch.empty((B, X, Y, Z, cout), dtype=odt, device=in0.device)
-    fam = f"conv3d_k3_mfma_{'bf16' if dtype == torch.bfloat16 else 'f32'}_bn{256 if cout % 256 == 0 else 128 if cout % 128 == 0 else 64 if cout % 64 == 0 else 32}"
+    mode = conv_mode(dtype, x3)
+    fam = f"conv3d_k3_mfma_{('f32', 'bf16', 'f32x3')[mode]}_bn{256 if cout % 256 == 0 else 128 if cout % 128 == 0 else 64 if cout % 64 == 0 else 32}"
     with _Timed(fam, (C0 + C1, int(cout), X, Y, Z), 2.0 * 27 * (C0 + C1) * cout * B * X * Y * Z):
         rc = _lib.load().mmr_conv3d_k3_fwd(
             in0.data_ptr(), C0, int(up0), in1.data_ptr() if in1 is not None else None, C1,
             w_packed.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), None,
-            B, X, Y, Z, int(cout), int(leaky), float(alpha), _DT[dtype], int(out_f32), _stream())
+            B, X, Y, Z, int(cout), int(leaky), float(alpha), mode, int(out_f32), _stream())
     _lib.check(rc, "mmr_conv3d_k3_fwd")
     return out
 

@@ -73,7 +73,7 @@ class SynthMorphTrainer:
         def conv(x, in1=None, up0=False, leaky=True, cout=None):
             nonlocal li
             y = ops.conv3d_k3(x, m._packed[li], w[2 * li + 1], m.plan[li][2] if cout is None else cout, in1=in1,
-                              up0=up0, leaky=leaky, out_f32=True)
+                              up0=up0, leaky=leaky, out_f32=True, x3=m.x3)
             tape.append(("conv", li, x, up0, in1, y, leaky))
             li += 1
             return y
@@ -137,8 +137,8 @@ class SynthMorphTrainer:
                 if m.plan[li][0] == "flow":
                     dcat = ops.conv3d_k3_cout3_dgrad(dz, m._w[2 * li])
                 else:
-                    wt = ops.pack_conv_weights(m._w[2 * li], torch.float32, transpose_flip=True)
-                    dcat = ops.conv3d_k3(dz, wt, None, C0 + C1, leaky=False, out_f32=True)
+                    wt = ops.pack_conv_weights(m._w[2 * li], torch.float32, transpose_flip=True, x3=m.x3)
+                    dcat = ops.conv3d_k3(dz, wt, None, C0 + C1, leaky=False, out_f32=True, x3=m.x3)
                 del dz, dy
                 if in1 is None and not up0:
                     if id(x) in grads:

@@ -15,7 +15,7 @@ def _pair(rng, shape):
     return n(a)[None, ..., None], n(b)[None, ..., None]
 
 
-@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("fp32x3", 1e-4), ("bf16", 3e-2)])
 def test_vxmdense_forward_matches_oracle(dev, dtype, tol):
     import mmr
     from oracle import net_np
