@@ -172,6 +172,9 @@ int mmr_maxpool3d2_bwd_f32(const float* x, const float* dpool, float* dx, int B,
 int64_t mmr_conv3d_k3_wgrad_ws_bytes(int B, int X, int Y, int Z, int Cin, int Cout);
 int mmr_conv3d_k3_wgrad_f32(const float* in0, int C0, int up0, const float* in1, int C1, const float* dz, float* dw,
                             void* ws, int B, int X, int Y, int Z, int Cout, int accumulate, void* stream);
+/* same contract, bf16 hi/lo split products on the bf16 MFMA (pairs with MMR_DT_F32X3) */
+int mmr_conv3d_k3_wgrad_f32x3(const float* in0, int C0, int up0, const float* in1, int C1, const float* dz, float* dw,
+                              void* ws, int B, int X, int Y, int Z, int Cout, int accumulate, void* stream);
 int64_t mmr_conv3d_k3_cin2_wgrad_ws_bytes(int Cout);
 int mmr_conv3d_k3_cin2_wgrad_f32(const float* src, const float* trg, const float* dz, float* dw, void* ws,
                                  int B, int X, int Y, int Z, int Cout, int accumulate, void* stream);

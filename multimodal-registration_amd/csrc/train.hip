@@ -639,6 +639,220 @@ wgrad_kernel(const WgradParams p)
     }
 }
 
+// ---- fp32-grade wgrad on the bf16 matrix cores (fp32x3) --------------------------------------------- //
+// Same decomposition as wgrad_kernel, but X and dZ are split into bf16 (hi, lo) while being staged and
+// every product is three v_mfma_f32_32x32x16_bf16 (lo*hi + hi*lo + hi*hi).  Both MFMA operands need the
+// voxel (k) index contiguous per lane while LDS holds [voxel][channel] rows, so fragments are fetched with
+// the gfx950 transposing read ds_read_b64_tr_b16 (4 voxels x 16 channels per 16-lane group; semantics
+// probed on hardware with tools/tr_probe.hip).  LDS images (conflict-free for the transposed reads):
+//   sX row (128 B) = two 64-B planes (hi, lo), physical plane = plane ^ ((hz >> 1) & 1)
+//   sZ row (256 B) = four 64-B segments (plane*2 + co/32), physical segment = segment ^ (vz & 3)
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+__device__ __forceinline__ s16x4 tr_read(const char* p)
+{
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+
+__device__ __forceinline__ bf16x8_t frag8(s16x4 a, s16x4 b)
+{
+    s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__device__ __forceinline__ void split_bf16(float f, unsigned short& hi, unsigned short& lo)
+{
+    hi = f32_to_bf16(f);
+    lo = f32_to_bf16(f - bf16_to_f32(hi));
+}
+
+constexpr int WX_A_BYTES = W_HROWS * 128;  // 76800
+constexpr int WX_B_BYTES = 256 * 256;      // 65536
+
+template <int COT>
+__global__ void __launch_bounds__(W_THREADS, 2)
+wgrad_x3_kernel(const WgradParams p)
+{
+    constexpr int NU = (COT == 2) ? 7 : 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sX = smem;
+    char* sZ = smem + WX_A_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slice = blockIdx.y, cob = blockIdx.z;
+    const int ch0 = slice * 32;
+    const bool first = ch0 < p.C0;
+    const float* src = first ? p.in0 : p.in1;
+    const int Cs = first ? p.C0 : p.C1;
+    const int chs = first ? ch0 : ch0 - p.C0;
+    const bool up = first && p.up0;
+    const int X2 = p.X >> 1, Y2 = p.Y >> 1, Z2 = p.Z >> 1;
+    constexpr int A_IT = (W_HROWS * 4 + W_THREADS - 1) / W_THREADS;  // 5 items of 8 channels (32 B fp32)
+    constexpr int B_IT = 256 * 16 / W_THREADS;                       // 8 items of 4 couts (16 B fp32)
+
+    // lane roles for the transposing reads
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, h = g >> 1, cg = g & 1;
+    const int cot = (COT == 2) ? (wave & 1) : 0;
+    f32x16 acc[NU];
+    int offA_hi[NU], offA_lo[NU];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        int tap = (COT == 2) ? (wave >> 1) + 4 * j : wave + 8 * j;
+        if (tap > 26) tap = 26;
+        const int dz = tap % 3;
+        const int sw = ((q + dz) >> 1) & 1;  // plane swizzle of the rows this lane addresses (hz = 4r + q + dz)
+        const int tapoff = ((tap / 9) * (W_HY * W_HZ) + ((tap / 3) % 3) * W_HZ + dz) * 128;
+        offA_hi[j] = tapoff + ((0 ^ sw) << 6);
+        offA_lo[j] = tapoff + ((1 ^ sw) << 6);
+    }
+    int laneA[2], laneBh[2], laneBl[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        laneA[r] = (h * W_HZ + 4 * r + q) * 128 + (cg * 16 + 4 * pp) * 2;
+        const int rowb = (8 * h + 4 * r + q) * 256 + (cg * 16 + 4 * pp) * 2;
+        laneBh[r] = rowb + (((0 * 2 + cot) ^ q) << 6);
+        laneBl[r] = rowb + (((1 * 2 + cot) ^ q) << 6);
+    }
+
+    auto tile_origin = [&](int tile, int& b, int& x0, int& y0, int& z0) {
+        int t = tile;
+        const int tzi = t % p.ntz; t /= p.ntz;
+        const int tyi = t % p.nty; t /= p.nty;
+        const int txi = t % p.ntx;
+        b = t / p.ntx;
+        x0 = txi * W_TX; y0 = tyi * W_TY; z0 = tzi * W_TZ;
+    };
+    struct XItem { float4 a, b; };
+    auto load_x = [&](int b, int x0, int y0, int z0, int it) -> XItem {
+        const int i = tid + it * W_THREADS;
+        XItem val;
+        val.a = make_float4(0.f, 0.f, 0.f, 0.f);
+        val.b = val.a;
+        if (i < W_HROWS * 4) {
+            const int row = i >> 2, c = i & 3;
+            const int hx = row / (W_HY * W_HZ), hy = (row / W_HZ) % W_HY, hz = row % W_HZ;
+            const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
+            if (gx >= 0 && gx < p.X && gy >= 0 && gy < p.Y && gz >= 0 && gz < p.Z) {
+                size_t vox;
+                if (up) vox = (((size_t)b * X2 + (gx >> 1)) * Y2 + (gy >> 1)) * Z2 + (gz >> 1);
+                else vox = (((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz;
+                const float* qsrc = src + vox * Cs + chs + c * 8;
+                val.a = *reinterpret_cast<const float4*>(qsrc);
+                val.b = *reinterpret_cast<const float4*>(qsrc + 4);
+            }
+        }
+        return val;
+    };
+    auto store_x = [&](int it, const XItem& v) {
+        const int i = tid + it * W_THREADS;
+        if (i < W_HROWS * 4) {
+            const int row = i >> 2, c = i & 3;
+            const int hz = row % W_HZ;
+            const int sw = (hz >> 1) & 1;
+            const float f[8] = {v.a.x, v.a.y, v.a.z, v.a.w, v.b.x, v.b.y, v.b.z, v.b.w};
+            unsigned hi[4], lo[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned short h0, l0, h1, l1;
+                split_bf16(f[2 * e], h0, l0);
+                split_bf16(f[2 * e + 1], h1, l1);
+                hi[e] = (unsigned)h0 | ((unsigned)h1 << 16);
+                lo[e] = (unsigned)l0 | ((unsigned)l1 << 16);
+            }
+            *reinterpret_cast<uint4*>(sX + row * 128 + ((0 ^ sw) << 6) + c * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            *reinterpret_cast<uint4*>(sX + row * 128 + ((1 ^ sw) << 6) + c * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
+    };
+    auto load_z = [&](int b, int x0, int y0, int z0, int it) -> float4 {
+        const int i = tid + it * W_THREADS;
+        const int v = i >> 4, c4 = i & 15;
+        const int gx = x0 + (v >> 6), gy = y0 + ((v >> 3) & 7), gz = z0 + (v & 7);
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gx < p.X && gy < p.Y && gz < p.Z) {
+            const float* qq = p.dz + ((((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz) * p.Cout;
+            const int co = cob * 64 + c4 * 4;
+            if (co + 3 < p.Cout) val = *reinterpret_cast<const float4*>(qq + co);
+            else {
+                if (co < p.Cout) val.x = qq[co];
+                if (co + 1 < p.Cout) val.y = qq[co + 1];
+                if (co + 2 < p.Cout) val.z = qq[co + 2];
+            }
+        }
+        return val;
+    };
+    auto store_z = [&](int it, float4 val) {
+        const int i = tid + it * W_THREADS;
+        const int v = i >> 4, c4 = i & 15;
+        const int vz = v & 7;
+        unsigned short h0, l0, h1, l1, h2, l2, h3, l3;
+        split_bf16(val.x, h0, l0); split_bf16(val.y, h1, l1); split_bf16(val.z, h2, l2); split_bf16(val.w, h3, l3);
+        const int seg_hi = (0 * 2 + (c4 >> 3)) ^ (vz & 3), seg_lo = (1 * 2 + (c4 >> 3)) ^ (vz & 3);
+        *reinterpret_cast<uint2*>(sZ + v * 256 + (seg_hi << 6) + (c4 & 7) * 8) =
+            make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
+        *reinterpret_cast<uint2*>(sZ + v * 256 + (seg_lo << 6) + (c4 & 7) * 8) =
+            make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
+    };
+
+    XItem px[A_IT];
+    float4 pz[B_IT];
+    int tile = blockIdx.x;
+    if (tile < p.ntiles) {
+        int b, x0, y0, z0;
+        tile_origin(tile, b, x0, y0, z0);
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) px[it] = load_x(b, x0, y0, z0, it);
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) pz[it] = load_z(b, x0, y0, z0, it);
+    }
+    for (; tile < p.ntiles; tile += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) store_x(it, px[it]);
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) store_z(it, pz[it]);
+        __syncthreads();
+        const int nxt = tile + gridDim.x;
+        if (nxt < p.ntiles) {
+            int b, x0, y0, z0;
+            tile_origin(nxt, b, x0, y0, z0);
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) px[it] = load_x(b, x0, y0, z0, it);
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it) pz[it] = load_z(b, x0, y0, z0, it);
+        }
+        for (int kb = 0; kb < 16; ++kb) {  // 16 voxels per k-block: (vx = kb>>2, vy = (kb&3)*2 + {0,1}, vz = 0..7)
+            const char* xa = sX + ((kb >> 2) * (W_HY * W_HZ) + (kb & 3) * 2 * W_HZ) * 128;
+            const char* zb = sZ + kb * 16 * 256;
+            const bf16x8_t b_hi = frag8(tr_read(zb + laneBh[0]), tr_read(zb + laneBh[1]));
+            const bf16x8_t b_lo = frag8(tr_read(zb + laneBl[0]), tr_read(zb + laneBl[1]));
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                const bf16x8_t a_hi = frag8(tr_read(xa + laneA[0] + offA_hi[j]), tr_read(xa + laneA[1] + offA_hi[j]));
+                const bf16x8_t a_lo = frag8(tr_read(xa + laneA[0] + offA_lo[j]), tr_read(xa + laneA[1] + offA_lo[j]));
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    float* out = p.slab + (((size_t)blockIdx.x * gridDim.y + slice) * gridDim.z + cob) * (27 * 32 * 64);
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        const int tap = (COT == 2) ? (wave >> 1) + 4 * j : wave + 8 * j;
+        if (tap < 27) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                out[(tap * 32 + ci) * 64 + cot * 32 + (lane & 31)] = acc[j][r];
+            }
+        }
+    }
+}
+
 // dW[tap][ci][co] (+)= sum over slabs (fixed order)
 __global__ void __launch_bounds__(TB)
 wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nblk, int nslices, int ncob, int Cin,
@@ -1085,9 +1299,8 @@ extern "C" int64_t mmr_conv3d_k3_wgrad_ws_bytes(int B, int X, int Y, int Z, int 
 }
 
 // dW (Keras layout [27][C0+C1][Cout]) (+)= wgrad of conv(concat([up2(in0)|in0, in1])) given dZ [B,X,Y,Z,Cout]
-extern "C" int mmr_conv3d_k3_wgrad_f32(const float* in0, int C0, int up0, const float* in1, int C1, const float* dz,
-                                       float* dw, void* ws, int B, int X, int Y, int Z, int Cout, int accumulate,
-                                       void* stream)
+static int wgrad_impl(const float* in0, int C0, int up0, const float* in1, int C1, const float* dz, float* dw, void* ws,
+                      int B, int X, int Y, int Z, int Cout, int accumulate, int x3, void* stream)
 {
     if (!in0 || !dz || !dw || !ws || B < 1 || X < 1 || Y < 1 || Z < 1 || Cout < 1 || C0 < 32 || C0 % 32 || C1 < 0 ||
         C1 % 32 || (C1 > 0 && !in1))
@@ -1122,7 +1335,23 @@ extern "C" int mmr_conv3d_k3_wgrad_f32(const float* in0, int C0, int up0, const 
         if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
         attr_set = true;
     }
-    if (Cout <= 32)
+    if (x3) {
+        constexpr int LDSX = WX_A_BYTES + WX_B_BYTES;
+        static bool attr_x3 = false;
+        if (!attr_x3) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<2>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDSX);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<1>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDSX);
+            if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
+            attr_x3 = true;
+        }
+        if (Cout <= 32)
+            hipLaunchKernelGGL(wgrad_x3_kernel<1>, dim3(gx, nslices, ncob), dim3(W_THREADS), LDSX, as_stream(stream), p);
+        else
+            hipLaunchKernelGGL(wgrad_x3_kernel<2>, dim3(gx, nslices, ncob), dim3(W_THREADS), LDSX, as_stream(stream), p);
+    } else if (Cout <= 32)
         hipLaunchKernelGGL(wgrad_kernel<1>, dim3(gx, nslices, ncob), dim3(W_THREADS), LDS, as_stream(stream), p);
     else
         hipLaunchKernelGGL(wgrad_kernel<2>, dim3(gx, nslices, ncob), dim3(W_THREADS), LDS, as_stream(stream), p);
@@ -1131,6 +1360,21 @@ extern "C" int mmr_conv3d_k3_wgrad_f32(const float* in0, int C0, int up0, const 
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(stream_grid((int64_t)27 * (C0 + C1) * Cout, TB)), dim3(TB), 0,
                        as_stream(stream), (const float*)ws, dw, gx, nslices, ncob, C0 + C1, Cout, accumulate);
     return check_launch();
+}
+
+extern "C" int mmr_conv3d_k3_wgrad_f32(const float* in0, int C0, int up0, const float* in1, int C1, const float* dz,
+                                       float* dw, void* ws, int B, int X, int Y, int Z, int Cout, int accumulate,
+                                       void* stream)
+{
+    return wgrad_impl(in0, C0, up0, in1, C1, dz, dw, ws, B, X, Y, Z, Cout, accumulate, 0, stream);
+}
+
+// same contract; products are bf16 hi/lo splits (three bf16 MFMAs each), fp32-grade accuracy
+extern "C" int mmr_conv3d_k3_wgrad_f32x3(const float* in0, int C0, int up0, const float* in1, int C1, const float* dz,
+                                         float* dw, void* ws, int B, int X, int Y, int Z, int Cout, int accumulate,
+                                         void* stream)
+{
+    return wgrad_impl(in0, C0, up0, in1, C1, dz, dw, ws, B, X, Y, Z, Cout, accumulate, 1, stream);
 }
 
 extern "C" int64_t mmr_conv3d_k3_cin2_wgrad_ws_bytes(int Cout) { return Cout < 1 ? MMR_EINVAL : (int64_t)512 * 54 * Cout * sizeof(float); }

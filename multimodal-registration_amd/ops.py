@@ -522,7 +522,7 @@ def maxpool3d2_bwd(x, dpool, dx=None):
     return dx
 
 
-def conv3d_k3_wgrad(in0, dz, dw, in1=None, up0=False, accumulate=False):
+def conv3d_k3_wgrad(in0, dz, dw, in1=None, up0=False, accumulate=False, x3=False):
     """dw [3,3,3,C0+C1,Cout] (+)= weight gradient of conv3d_k3(in0, .., in1=in1, up0=up0) given dz."""
     _chk(in0, torch.float32, "in0")
     _chk(dz, torch.float32, "dz")
@@ -532,8 +532,10 @@ def conv3d_k3_wgrad(in0, dz, dw, in1=None, up0=False, accumulate=False):
     C1 = in1.shape[-1] if in1 is not None else 0
     lib = _lib.load()
     ws = _ws(lib.mmr_conv3d_k3_wgrad_ws_bytes(B, X, Y, Z, C0 + C1, Cout), dz.device)
-    with _Timed("conv3d_k3_wgrad_mfma_f32", (C0 + C1, Cout, X, Y, Z), 2.0 * 27 * (C0 + C1) * Cout * B * X * Y * Z):
-        rc = lib.mmr_conv3d_k3_wgrad_f32(in0.data_ptr(), C0, int(up0), in1.data_ptr() if in1 is not None else None, C1,
+    fn = lib.mmr_conv3d_k3_wgrad_f32x3 if x3 else lib.mmr_conv3d_k3_wgrad_f32
+    with _Timed("conv3d_k3_wgrad_mfma_f32x3" if x3 else "conv3d_k3_wgrad_mfma_f32", (C0 + C1, Cout, X, Y, Z),
+                2.0 * 27 * (C0 + C1) * Cout * B * X * Y * Z):
+        rc = fn(in0.data_ptr(), C0, int(up0), in1.data_ptr() if in1 is not None else None, C1,
                                          dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, X, Y, Z, Cout, int(accumulate), _stream())
     _lib.check(rc, "mmr_conv3d_k3_wgrad_f32")
     return dw

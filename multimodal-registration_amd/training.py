@@ -131,7 +131,7 @@ class SynthMorphTrainer:
                 _, li, x, up0, in1, y, leaky = rec
                 dy = grads.pop(id(y))
                 dz = ops.leaky_bwd_bias_(y if leaky else None, dy, self.g[2 * li + 1], leaky=leaky)
-                ops.conv3d_k3_wgrad(x, dz, self.g[2 * li], in1=in1, up0=up0)
+                ops.conv3d_k3_wgrad(x, dz, self.g[2 * li], in1=in1, up0=up0, x3=m.x3)
                 C0 = x.shape[-1]
                 C1 = in1.shape[-1] if in1 is not None else 0
                 if m.plan[li][0] == "flow":
