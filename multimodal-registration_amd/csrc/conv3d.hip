@@ -524,6 +524,189 @@ conv3d_cin2_kernel(const float* __restrict__ src, const float* __restrict__ trg,
     }
 }
 
+// ---- first layer on the matrix cores --------------------------------------------------------------- //
+// concat(moving, fixed) has 2 channels -> K = 27 taps x 2 = 54 (padded to 64).  Per 4x8x8 voxel tile the
+// im2col matrix X[256 voxels][64 k] is built in LDS from a haloed image patch, the weights are an LDS image
+// W[Cout][64 k], and D[cout][voxel] = W . X^T runs on v_mfma_f32_32x32x16_bf16 (bf16 mode: 4 MFMAs per
+// 32x32 tile; fp32x3 mode: hi/lo splits, 12 MFMAs, ~5e-6 relative error).  With couts on the accumulator
+// rows every lane owns runs of 4 consecutive couts of one voxel, so the epilogue stores 16 B per lane
+// (bf16: after a v_permlane32_swap pairing of the two half-waves) -- the layer is bound by its
+// N*Cout output write, not by the 136 GFLOP of arithmetic.
+constexpr int M2_THREADS = 256;
+
+template <bool X3, bool OUT_BF16>
+__global__ void __launch_bounds__(M2_THREADS)
+conv3d_cin2_mfma_kernel(const float* __restrict__ src, const float* __restrict__ trg, const float* __restrict__ w,
+                        const float* __restrict__ bias, void* __restrict__ out, int B, int X, int Y, int Z, int Cout,
+                        int leaky, float alpha, int ntx, int nty, int ntz)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NPL = X3 ? 2 : 1;
+    float* s_img = reinterpret_cast<float*>(smem);                 // [600][2]
+    float* s_bias = s_img + HROWS * 2;                             // [Cout] (<= 512)
+    char* s_x = smem + HROWS * 8 + 2048;                           // [NPL][256][128 B]
+    char* s_w = s_x + NPL * 256 * 128;                             // [NPL][Cout][128 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    int bid = blockIdx.x;
+    const int tzi = bid % ntz; bid /= ntz;
+    const int tyi = bid % nty; bid /= nty;
+    const int txi = bid % ntx;
+    const int b = bid / ntx;
+    const int x0 = txi * TX, y0 = tyi * TY, z0 = tzi * TZ;
+    const size_t nvox = (size_t)X * Y * Z;
+
+    for (int i = tid; i < HROWS; i += M2_THREADS) {
+        const int hx = i / (HY * HZ), hy = (i / HZ) % HY, hz = i % HZ;
+        const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
+        float a = 0.f, c = 0.f;
+        if (gx >= 0 && gx < X && gy >= 0 && gy < Y && gz >= 0 && gz < Z) {
+            const size_t o = (size_t)b * nvox + ((size_t)gx * Y + gy) * Z + gz;
+            a = src[o];
+            c = trg[o];
+        }
+        s_img[i * 2] = a;
+        s_img[i * 2 + 1] = c;
+    }
+    for (int i = tid; i < Cout; i += M2_THREADS) s_bias[i] = bias ? bias[i] : 0.f;
+    // weight image: row = cout, 64 k (k = tap*2 + ci; k >= 54 zero), chunk swizzle (row >> 1) & 7
+    for (int i = tid; i < Cout * 32; i += M2_THREADS) {
+        const int co = i % Cout, kp = i / Cout;  // kp = pair index: k = 2 kp, 2 kp + 1 (= tap kp, ci 0/1)
+        float f0 = 0.f, f1 = 0.f;
+        if (kp < 27) {
+            f0 = w[(kp * 2) * Cout + co];
+            f1 = w[(kp * 2 + 1) * Cout + co];
+        }
+        const bf16_t h0 = f32_to_bf16(f0), h1 = f32_to_bf16(f1);
+        const int chunk = kp >> 2, within = (kp & 3) * 4;
+        const int off = co * 128 + ((chunk ^ ((co >> 1) & 7)) << 4) + within;
+        *reinterpret_cast<unsigned*>(s_w + off) = (unsigned)h0 | ((unsigned)h1 << 16);
+        if constexpr (X3) {
+            const bf16_t l0 = f32_to_bf16(f0 - bf16_to_f32(h0)), l1 = f32_to_bf16(f1 - bf16_to_f32(h1));
+            *reinterpret_cast<unsigned*>(s_w + Cout * 128 + off) = (unsigned)l0 | ((unsigned)l1 << 16);
+        }
+    }
+    __syncthreads();
+    // im2col: row = voxel (x*64 + y*8 + z), k pair kp = tap
+    for (int i = tid; i < 256 * 32; i += M2_THREADS) {
+        const int v = i & 255, kp = i >> 8;
+        float f0 = 0.f, f1 = 0.f;
+        if (kp < 27) {
+            const int vx = v >> 6, vy = (v >> 3) & 7, vz = v & 7;
+            const int r = ((vx + kp / 9) * HY + vy + (kp / 3) % 3) * HZ + vz + kp % 3;
+            f0 = s_img[r * 2];
+            f1 = s_img[r * 2 + 1];
+        }
+        const bf16_t h0 = f32_to_bf16(f0), h1 = f32_to_bf16(f1);
+        const int chunk = kp >> 2, within = (kp & 3) * 4;
+        const int off = v * 128 + ((chunk ^ ((v >> 1) & 7)) << 4) + within;
+        *reinterpret_cast<unsigned*>(s_x + off) = (unsigned)h0 | ((unsigned)h1 << 16);
+        if constexpr (X3) {
+            const bf16_t l0 = f32_to_bf16(f0 - bf16_to_f32(h0)), l1 = f32_to_bf16(f1 - bf16_to_f32(h1));
+            *reinterpret_cast<unsigned*>(s_x + 256 * 128 + off) = (unsigned)l0 | ((unsigned)l1 << 16);
+        }
+    }
+    __syncthreads();
+
+    // this wave's 64 voxels = 2 column tiles; X fragments stay in registers for all cout tiles
+    uint4 xf[NPL][2][4];
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt) {
+            const int v = wave * 64 + vt * 32 + (lane & 31);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                xf[pl][vt][ks] = *reinterpret_cast<const uint4*>(s_x + pl * 256 * 128 + v * 128 +
+                                                                 (((2 * ks + h) ^ ((v >> 1) & 7)) << 4));
+        }
+    int gxv[2], gyv[2], gzv[2];
+#pragma unroll
+    for (int vt = 0; vt < 2; ++vt) {
+        const int v = wave * 64 + vt * 32 + (lane & 31);
+        gxv[vt] = x0 + (v >> 6); gyv[vt] = y0 + ((v >> 3) & 7); gzv[vt] = z0 + (v & 7);
+    }
+    for (int n = 0; n < Cout / 32; ++n) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[vt][r] = 0.f;
+        const int co_row = n * 32 + (lane & 31);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int woff = co_row * 128 + (((2 * ks + h) ^ ((co_row >> 1) & 7)) << 4);
+            const uint4 wh = *reinterpret_cast<const uint4*>(s_w + woff);
+            if constexpr (X3) {
+                const uint4 wl = *reinterpret_cast<const uint4*>(s_w + Cout * 128 + woff);
+#pragma unroll
+                for (int vt = 0; vt < 2; ++vt) {
+                    acc[vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wl),
+                                                                    __builtin_bit_cast(bf16x8, xf[0][vt][ks]), acc[vt], 0, 0, 0);
+                    acc[vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh),
+                                                                    __builtin_bit_cast(bf16x8, xf[NPL - 1][vt][ks]), acc[vt], 0, 0, 0);
+                    acc[vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh),
+                                                                    __builtin_bit_cast(bf16x8, xf[0][vt][ks]), acc[vt], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int vt = 0; vt < 2; ++vt)
+                    acc[vt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh),
+                                                                    __builtin_bit_cast(bf16x8, xf[0][vt][ks]), acc[vt], 0, 0, 0);
+            }
+        }
+        // epilogue: accumulator row = cout n*32 + (r&3) + 8*(r>>2) + 4*h, column = voxel
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt) {
+            const bool ok = gxv[vt] < X && gyv[vt] < Y && gzv[vt] < Z;
+            const size_t obase = ((size_t)b * nvox + ((size_t)gxv[vt] * Y + gyv[vt]) * Z + gzv[vt]) * Cout + n * 32;
+            float vals[16];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 bq = *reinterpret_cast<const float4*>(s_bias + n * 32 + 8 * gq + 4 * h);
+                const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[vt][gq * 4 + e] + bb[e];
+                    if (leaky && v < 0.f) v *= alpha;
+                    vals[gq * 4 + e] = v;
+                }
+            }
+            if constexpr (OUT_BF16) {
+                unsigned pk[4][2];
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    pk[gq][0] = (unsigned)f32_to_bf16(vals[gq * 4]) | ((unsigned)f32_to_bf16(vals[gq * 4 + 1]) << 16);
+                    pk[gq][1] = (unsigned)f32_to_bf16(vals[gq * 4 + 2]) | ((unsigned)f32_to_bf16(vals[gq * 4 + 3]) << 16);
+                }
+                // pair cout groups (0,1) and (2,3) across the two half-waves -> 16 contiguous bytes per lane
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        auto rsw = __builtin_amdgcn_permlane32_swap(pk[2 * pr][d], pk[2 * pr + 1][d], false, false);
+                        pk[2 * pr][d] = rsw[0];
+                        pk[2 * pr + 1][d] = rsw[1];
+                    }
+                    if (ok) {
+                        bf16_t* o = reinterpret_cast<bf16_t*>(out) + obase + 16 * pr + 8 * h;
+                        *reinterpret_cast<uint4*>(o) = make_uint4(pk[2 * pr][0], pk[2 * pr][1], pk[2 * pr + 1][0], pk[2 * pr + 1][1]);
+                    }
+                }
+            } else {
+                if (ok) {
+                    float* o = reinterpret_cast<float*>(out) + obase;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq)
+                        *reinterpret_cast<float4*>(o + 8 * gq + 4 * h) =
+                            make_float4(vals[gq * 4], vals[gq * 4 + 1], vals[gq * 4 + 2], vals[gq * 4 + 3]);
+                }
+            }
+        }
+    }
+}
+
 // ---- MaxPooling3D(2), 16 B per lane -------------------------------------- //
 template <int DT>
 __global__ void __launch_bounds__(256)
@@ -634,21 +817,51 @@ extern "C" int mmr_conv3d_k3_fwd(const void* in0, int C0, int up0, const void* i
     return dispatch_conv<MMR_DT_F32>(p, as_stream(stream));
 }
 
+template <bool X3, bool OUT_BF16>
+static int launch_cin2_mfma(const float* src, const float* trg, const float* w, const float* bias, void* out, int B, int X,
+                            int Y, int Z, int Cout, int leaky, float alpha, hipStream_t st)
+{
+    const int npl = X3 ? 2 : 1;
+    const int lds = HROWS * 8 + 2048 + npl * 256 * 128 + npl * Cout * 128;
+    if (lds > 160 * 1024) return MMR_EUNSUPPORTED;
+    static bool attr_set = false;
+    auto kern = conv3d_cin2_mfma_kernel<X3, OUT_BF16>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024);
+        if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
+        attr_set = true;
+    }
+    const int ntx = (X + TX - 1) / TX, nty = (Y + TY - 1) / TY, ntz = (Z + TZ - 1) / TZ;
+    const int64_t nblk = (int64_t)B * ntx * nty * ntz;
+    if (nblk > 0x7fffffff) return MMR_EINVAL;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(M2_THREADS), lds, st, src, trg, w, bias, out, B, X, Y, Z, Cout,
+                       leaky, alpha, ntx, nty, ntz);
+    return check_launch();
+}
+
 extern "C" int mmr_conv3d_k3_cin2_fwd(const float* src, const float* trg, const float* w_keras, const float* bias,
                                       void* out, void* pool_out, int B, int X, int Y, int Z, int Cout, int leaky,
                                       float alpha, int out_dtype, void* stream)
 {
     if (!src || !trg || !w_keras || !out || B < 1 || X < 1 || Y < 1 || Z < 1 || Cout < 1) return MMR_EINVAL;
     if (pool_out) return MMR_EUNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    // out_dtype: BF16 -> bf16 MFMA, bf16 out; F32X3 -> bf16 hi/lo split MFMA, fp32 out; F32 -> exact fp32 VALU kernel
+    if (Cout % 32 == 0 && Cout <= 512 && out_dtype == MMR_DT_BF16)
+        return launch_cin2_mfma<false, true>(src, trg, w_keras, bias, out, B, X, Y, Z, Cout, leaky, alpha, st);
+    if (Cout % 32 == 0 && Cout <= 320 && out_dtype == MMR_DT_F32X3)
+        return launch_cin2_mfma<true, false>(src, trg, w_keras, bias, out, B, X, Y, Z, Cout, leaky, alpha, st);
+    if (out_dtype == MMR_DT_F32X3) out_dtype = MMR_DT_F32;
     if (!((Cout <= 256 && 256 % Cout == 0) || Cout % 256 == 0)) return MMR_EINVAL;
     const int ntx = (X + F_TX - 1) / F_TX, nty = (Y + F_TY - 1) / F_TY, ntz = (Z + F_TZ - 1) / F_TZ;
     const int64_t nblk = (int64_t)B * ntx * nty * ntz;
     if (nblk > 0x7fffffff) return MMR_EINVAL;
     if (out_dtype == MMR_DT_BF16)
-        hipLaunchKernelGGL(conv3d_cin2_kernel<MMR_DT_BF16>, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), src,
+        hipLaunchKernelGGL(conv3d_cin2_kernel<MMR_DT_BF16>, dim3((unsigned)nblk), dim3(256), 0, st, src,
                            trg, w_keras, bias, out, B, X, Y, Z, Cout, leaky, alpha, ntx, nty, ntz);
     else if (out_dtype == MMR_DT_F32)
-        hipLaunchKernelGGL(conv3d_cin2_kernel<MMR_DT_F32>, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), src,
+        hipLaunchKernelGGL(conv3d_cin2_kernel<MMR_DT_F32>, dim3((unsigned)nblk), dim3(256), 0, st, src,
                            trg, w_keras, bias, out, B, X, Y, Z, Cout, leaky, alpha, ntx, nty, ntz);
     else
         return MMR_EINVAL;

@@ -196,7 +196,7 @@ class VxmDense:
         """[B,X,Y,Z,1] x2 (f32) -> flow [B,X,Y,Z,3] f32."""
         self._pack()
         w, nlev = self._w, len(self.enc)
-        last = ops.conv3d_k3_cin2(src, trg, w[0], w[1], self.dtype)
+        last = ops.conv3d_k3_cin2(src, trg, w[0], w[1], self.dtype, x3=self.x3)
         skips = [last]
         li = 1
         for _ in range(1, nlev):

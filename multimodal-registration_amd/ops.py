@@ -189,7 +189,7 @@ def conv3d_k3(in0, w_packed, bias, cout, in1=None, up0=False, leaky=True, alpha=
     return out
 
 
-def conv3d_k3_cin2(src, trg, w_keras, bias, out_dtype, leaky=True, alpha=0.2):
+def conv3d_k3_cin2(src, trg, w_keras, bias, out_dtype, leaky=True, alpha=0.2, x3=False):
     """First U-Net layer on concat([src, trg]) ([B,X,Y,Z,1] each, f32)."""
     _chk(src, torch.float32, "src")
     _chk(trg, torch.float32, "trg")
@@ -199,7 +199,7 @@ def conv3d_k3_cin2(src, trg, w_keras, bias, out_dtype, leaky=True, alpha=0.2):
     out = torch.empty((B, X, Y, Z, cout), dtype=out_dtype, device=src.device)
     rc = _lib.load().mmr_conv3d_k3_cin2_fwd(src.data_ptr(), trg.data_ptr(), w_keras.data_ptr(),
                                             bias.data_ptr() if bias is not None else None, out.data_ptr(), None,
-                                            B, X, Y, Z, cout, int(leaky), float(alpha), _DT[out_dtype], _stream())
+                                            B, X, Y, Z, cout, int(leaky), float(alpha), conv_mode(out_dtype, x3), _stream())
     _lib.check(rc, "mmr_conv3d_k3_cin2_fwd")
     return out
 

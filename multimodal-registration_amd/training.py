@@ -65,7 +65,7 @@ class SynthMorphTrainer:
         m = self.model
         m._pack()
         w, nlev = m._w, len(m.enc)
-        last = ops.conv3d_k3_cin2(src, trg, w[0], w[1], torch.float32)
+        last = ops.conv3d_k3_cin2(src, trg, w[0], w[1], torch.float32, x3=m.x3)
         tape.append(("conv0", 0, src, trg, last))
         skips = [last]
         li = 1

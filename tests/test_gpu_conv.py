@@ -67,7 +67,9 @@ def test_conv_matches_oracle(dev, dtype, shape, C0, C1, up0, Cout):
     assert _scale_err(got, ref) < tol
 
 
-@pytest.mark.parametrize("shape,Cout,odt", [((8, 8, 16), 64, "fp32"), ((5, 6, 19), 256, "fp32"), ((8, 8, 16), 256, "bf16")])
+@pytest.mark.parametrize("shape,Cout,odt", [((8, 8, 16), 64, "fp32"), ((5, 6, 19), 256, "fp32"), ((8, 8, 16), 256, "bf16"),
+                                            ((5, 9, 7), 64, "bf16"), ((8, 8, 16), 64, "fp32x3"), ((5, 6, 19), 256, "fp32x3"),
+                                            ((4, 8, 8), 32, "fp32x3")])
 def test_first_layer(dev, shape, Cout, odt):
     import mmr
     from oracle.cbind import conv3d_same
@@ -77,10 +79,12 @@ def test_first_layer(dev, shape, Cout, odt):
     w = (rng.standard_normal((3, 3, 3, 2, Cout)) * 0.2).astype(np.float32)
     bias = rng.standard_normal(Cout).astype(np.float32) * 0.1
     ref = conv3d_same(np.concatenate([src, trg], -1), w, bias, leaky=True)
-    tdt = torch.float32 if odt == "fp32" else torch.bfloat16
+    tdt = torch.bfloat16 if odt == "bf16" else torch.float32
     got = mmr.ops.conv3d_k3_cin2(torch.from_numpy(src).to(dev), torch.from_numpy(trg).to(dev),
-                                 torch.from_numpy(w).to(dev), torch.from_numpy(bias).to(dev), tdt)
-    assert _scale_err(got.float().cpu().numpy(), ref) < (1e-5 if odt == "fp32" else 4e-3)
+                                 torch.from_numpy(w).to(dev), torch.from_numpy(bias).to(dev), tdt, x3=(odt == "fp32x3"))
+    assert got.dtype == tdt
+    # bf16: inputs, weights and output rounded to bf16 (8-bit mantissa); fp32x3: hi/lo split; fp32: exact VALU kernel
+    assert _scale_err(got.float().cpu().numpy(), ref) < {"fp32": 1e-5, "fp32x3": 1e-4, "bf16": 1.2e-2}[odt]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
