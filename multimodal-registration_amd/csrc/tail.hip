@@ -102,33 +102,44 @@ warp3d_kernel(const T* __restrict__ vol, const float* __restrict__ flow, T* __re
     }
 }
 
+// One thread per OUTPUT VOXEL (axis setup and the 8 corner offsets are computed once, then the channels
+// are looped) with 32-bit indexing inside a batch item; NC > 0 unrolls the channel loop.
+template <int NC>
 __global__ void __launch_bounds__(256)
 resize_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int X, int Y, int Z, int C,
               int Xo, int Yo, int Zo, float stx, float sty, float stz, float mul, int pre_scale)
 {
-    const int64_t nvo = (int64_t)Xo * Yo * Zo, nvi = (int64_t)X * Y * Z;
-    const int64_t total = (int64_t)B * nvo * C;
-    const int64_t sz = C, sy = (int64_t)Z * C, sx = (int64_t)Y * Z * C;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const int64_t v = i / C;
-        const int64_t b = v / nvo;
-        const int64_t r = v - b * nvo;
-        const int z = (int)(r % Zo);
-        const int y = (int)((r / Zo) % Yo);
-        const int x = (int)(r / ((int64_t)Zo * Yo));
+    const int nvo = Xo * Yo * Zo;
+    const int64_t total = (int64_t)B * nvo;
+    const int sz = C, sy = Z * C, sx = Y * Z * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / nvo);
+        const int r = (int)(i - (int64_t)b * nvo);
+        const int z = r % Zo;
+        const int y = (r / Zo) % Yo;
+        const int x = r / (Zo * Yo);
         const Axis ax = axis_setup((float)x * stx, X - 1);
         const Axis ay = axis_setup((float)y * sty, Y - 1);
         const Axis az = axis_setup((float)z * stz, Z - 1);
-        const float* base = in + b * nvi * C + c;
-        float o;
-        if (pre_scale) {
-            o = trilinear(ax, ay, az, sx, sy, sz, [&](int64_t off) { return base[off] * mul; });
-        } else {
-            o = trilinear(ax, ay, az, sx, sy, sz, [&](int64_t off) { return base[off]; }) * mul;
+        const float* base = in + (int64_t)b * X * sx;
+        float* o = out + i * C;
+        const int x0 = ax.i0 * sx, x1 = ax.i1 * sx, y0 = ay.i0 * sy, y1 = ay.i1 * sy, z0 = az.i0 * sz, z1 = az.i1 * sz;
+        const int offs[8] = {x0 + y0 + z0, x0 + y0 + z1, x0 + y1 + z0, x0 + y1 + z1,
+                             x1 + y0 + z0, x1 + y0 + z1, x1 + y1 + z0, x1 + y1 + z1};
+        const float w00 = ax.w0 * ay.w0, w01 = ax.w0 * ay.w1, w10 = ax.w1 * ay.w0, w11 = ax.w1 * ay.w1;
+        const float wt[8] = {w00 * az.w0, w00 * az.w1, w01 * az.w0, w01 * az.w1,
+                             w10 * az.w0, w10 * az.w1, w11 * az.w0, w11 * az.w1};
+        const int nc = NC > 0 ? NC : C;
+#pragma unroll
+        for (int c = 0; c < nc; ++c) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float v = base[offs[k] + c];
+                acc = acc + wt[k] * (pre_scale ? v * mul : v);
+            }
+            o[c] = pre_scale ? acc : acc * mul;
         }
-        out[i] = o;
     }
 }
 
@@ -198,9 +209,18 @@ extern "C" int mmr_resize_trilinear_f32(const float* in, float* out, int B, int 
     const float stx = (float)(X - 1) / (float)(Xo > 1 ? Xo - 1 : 1);
     const float sty = (float)(Y - 1) / (float)(Yo > 1 ? Yo - 1 : 1);
     const float stz = (float)(Z - 1) / (float)(Zo > 1 ? Zo - 1 : 1);
-    const int64_t total = (int64_t)B * Xo * Yo * Zo * C;
-    hipLaunchKernelGGL(resize_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), in, out, B, X,
-                       Y, Z, C, Xo, Yo, Zo, stx, sty, stz, mul, pre_scale);
+    if ((int64_t)X * Y * Z * C > 0x7fffffff || (int64_t)Xo * Yo * Zo > 0x7fffffff) return MMR_EINVAL;
+    const int64_t total = (int64_t)B * Xo * Yo * Zo;
+    const dim3 grid(stream_grid(total, 256, 256 * 32)), blk(256);
+    if (C == 1)
+        hipLaunchKernelGGL(resize_kernel<1>, grid, blk, 0, as_stream(stream), in, out, B, X, Y, Z, C, Xo, Yo, Zo, stx,
+                           sty, stz, mul, pre_scale);
+    else if (C == 3)
+        hipLaunchKernelGGL(resize_kernel<3>, grid, blk, 0, as_stream(stream), in, out, B, X, Y, Z, C, Xo, Yo, Zo, stx,
+                           sty, stz, mul, pre_scale);
+    else
+        hipLaunchKernelGGL(resize_kernel<0>, grid, blk, 0, as_stream(stream), in, out, B, X, Y, Z, C, Xo, Yo, Zo, stx,
+                           sty, stz, mul, pre_scale);
     return check_launch();
 }
 

@@ -1078,6 +1078,203 @@ dgrad_cout3_generic_kernel(const float* __restrict__ dy, const float* __restrict
 }
 
 // ------------------------------------------------------------------------- //
+// Thin layers on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32)   //
+// ------------------------------------------------------------------------- //
+// The first layer (Cin = 2) and the flow head (Cout = 3) have one tiny channel axis.  Folding the 27 taps
+// into it gives a GEMM dimension of 54 / 81 "virtual channels" G[v][tap*Cs + c] = S[v +- off(tap)][c] that
+// is gathered on the fly from a haloed LDS tile of the small tensor S, so no 10x zero padding of the
+// channel axis is multiplied.
+constexpr int SM_THREADS = 256;
+
+// T[d][g] = sum_v Dn[v][d] * G[v][g];  d < 64 (one 64-channel block of the dense tensor per blockIdx.y),
+// g < 27*Cs (<= 96).  sign = +1: G[v][tap,c] = S[v + off(tap)][c] (first-layer wgrad: S = image pair),
+// sign = -1: S[v - off(tap)][c] (flow-head wgrad: S = dflow).  part: [gridDim.x*4][gridDim.y][64][96].
+__global__ void __launch_bounds__(SM_THREADS, 2)
+smallch_wgrad_kernel(const float* __restrict__ dense, int Cd, const float* __restrict__ s0, const float* __restrict__ s1,
+                     int Cs, int sign, float* __restrict__ part, int B, int X, int Y, int Z, int ntx, int nty, int ntz,
+                     int ntiles)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sS = reinterpret_cast<float*>(smem);            // [600][Cs]
+    float* sD = sS + W_HROWS * 3;                          // [256][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int cb = blockIdx.y;
+    const int KG = 27 * Cs;
+    int goff[3];
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        const int gcol = n * 32 + (lane & 31);
+        int o = 0;
+        if (gcol < KG) {
+            const int tap = gcol / Cs, c = gcol % Cs;
+            const int d = ((tap / 9 - 1) * (W_HY * W_HZ) + ((tap / 3) % 3 - 1) * W_HZ + (tap % 3 - 1));
+            o = sign * d * Cs + c;
+        }
+        goff[n] = o;
+    }
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    const size_t nvox = (size_t)X * Y * Z;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tzi = t % ntz; t /= ntz;
+        const int tyi = t % nty; t /= nty;
+        const int txi = t % ntx;
+        const int b = t / ntx;
+        const int x0 = txi * W_TX, y0 = tyi * W_TY, z0 = tzi * W_TZ;
+        __syncthreads();
+        for (int i = tid; i < W_HROWS; i += SM_THREADS) {
+            const int hx = i / (W_HY * W_HZ), hy = (i / W_HZ) % W_HY, hz = i % W_HZ;
+            const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
+            const bool ok = gx >= 0 && gx < X && gy >= 0 && gy < Y && gz >= 0 && gz < Z;
+            const size_t o = (size_t)b * nvox + ((size_t)gx * Y + gy) * Z + gz;
+            if (s1) {  // two single-channel volumes (moving, fixed)
+                sS[i * Cs] = ok ? s0[o] : 0.f;
+                sS[i * Cs + 1] = ok ? s1[o] : 0.f;
+            } else {
+                for (int c = 0; c < Cs; ++c) sS[i * Cs + c] = ok ? s0[o * Cs + c] : 0.f;
+            }
+        }
+        for (int i = tid; i < 256 * 16; i += SM_THREADS) {
+            const int v = i >> 4, c4 = i & 15;
+            const int gx = x0 + (v >> 6), gy = y0 + ((v >> 3) & 7), gz = z0 + (v & 7);
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gx < X && gy < Y && gz < Z)
+                val = *reinterpret_cast<const float4*>(dense + ((size_t)b * nvox + ((size_t)gx * Y + gy) * Z + gz) * Cd +
+                                                       cb * 64 + c4 * 4);
+            *reinterpret_cast<float4*>(sD + v * 64 + c4 * 4) = val;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int st = 0; st < 32; ++st) {
+            const int v = wave * 64 + st * 2 + h;
+            const int hrow = (((v >> 6) + 1) * W_HY + ((v >> 3) & 7) + 1) * W_HZ + (v & 7) + 1;
+            const float a0 = sD[v * 64 + (lane & 31)], a1 = sD[v * 64 + 32 + (lane & 31)];
+            float bv[3];
+#pragma unroll
+            for (int n = 0; n < 3; ++n) bv[n] = sS[hrow * Cs + goff[n]];
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[n], acc[0][n], 0, 0, 0);
+                acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[n], acc[1][n], 0, 0, 0);
+            }
+        }
+    }
+    float* o = part + (((size_t)(blockIdx.x * 4 + wave)) * gridDim.y + cb) * (64 * 96);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                o[d * 96 + n * 32 + (lane & 31)] = acc[m][n][r];
+            }
+}
+
+// sum the partial T's and scatter into the Keras weight-gradient layout
+//   mode 0 (flow head):   dW[tap][d][c]  = T[d][tap*Cs + c]   (d = input channel, Cd of them; Cs = 3)
+//   mode 1 (first layer): dW[tap][c][d]  = T[d][tap*Cs + c]   (d = output channel; Cs = 2)
+__global__ void __launch_bounds__(64)
+smallch_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nparts, int ncb, int Cd, int Cs,
+                            int mode, int accumulate)
+{
+    const int KG = 27 * Cs;
+    const int i = blockIdx.x;  // one wave per output element: ordered strided sum + wave reduction
+    const int g = i % KG, d = i / KG;
+    const int cb = d >> 6, dl = d & 63;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < nparts; k += 64) s += part[(((size_t)k) * ncb + cb) * (64 * 96) + dl * 96 + g];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) {
+        const int tap = g / Cs, c = g % Cs;
+        const size_t o = mode == 0 ? ((size_t)tap * Cd + d) * Cs + c : ((size_t)tap * Cs + c) * Cd + d;
+        if (accumulate) dw[o] += s; else dw[o] = s;
+    }
+}
+
+// flow-head dgrad: dX[v][ci] = sum_g G[v][g] * Wr[g][ci], g = tap*3 + co, G[v][g] = dY[v - off(tap)][co]
+// (M = 256 voxels per block, N = 64 input channels per blockIdx.y, K = 81 padded to 82)
+__global__ void __launch_bounds__(SM_THREADS, 2)
+flow_dgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int B, int X,
+                       int Y, int Z, int Cin, int ntx, int nty, int ntz)
+{
+    __shared__ float sS[W_HROWS * 3];
+    __shared__ float sW[82 * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int cb = blockIdx.y;
+    int bid = blockIdx.x;
+    const int tzi = bid % ntz; bid /= ntz;
+    const int tyi = bid % nty; bid /= nty;
+    const int txi = bid % ntx;
+    const int b = bid / ntx;
+    const int x0 = txi * W_TX, y0 = tyi * W_TY, z0 = tzi * W_TZ;
+    const size_t nvox = (size_t)X * Y * Z;
+    for (int i = tid; i < W_HROWS; i += SM_THREADS) {
+        const int hx = i / (W_HY * W_HZ), hy = (i / W_HZ) % W_HY, hz = i % W_HZ;
+        const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
+        const bool ok = gx >= 0 && gx < X && gy >= 0 && gy < Y && gz >= 0 && gz < Z;
+        const size_t o = ((size_t)b * nvox + ((size_t)gx * Y + gy) * Z + gz) * 3;
+        sS[i * 3] = ok ? dy[o] : 0.f;
+        sS[i * 3 + 1] = ok ? dy[o + 1] : 0.f;
+        sS[i * 3 + 2] = ok ? dy[o + 2] : 0.f;
+    }
+    for (int i = tid; i < 82 * 64; i += SM_THREADS) {
+        const int g = i >> 6, ci = i & 63;
+        sW[i] = (g < 81) ? w[((size_t)(g / 3) * Cin + cb * 64 + ci) * 3 + (g % 3)] : 0.f;
+    }
+    __syncthreads();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    int hrow[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int v = wave * 64 + m * 32 + (lane & 31);
+        hrow[m] = ((((v >> 6) + 1) * W_HY + ((v >> 3) & 7) + 1) * W_HZ + (v & 7) + 1) * 3;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 41; ++kk) {
+        const int g0 = 2 * kk, g1 = 2 * kk + 1;  // compile-time; lane half h picks one
+        const int t0 = g0 / 3, t1 = (g1 < 81) ? g1 / 3 : 0;
+        const int o0 = -(((t0 / 9 - 1) * (W_HY * W_HZ) + ((t0 / 3) % 3 - 1) * W_HZ + (t0 % 3 - 1)) * 3) + g0 % 3;
+        const int o1 = (g1 < 81) ? -(((t1 / 9 - 1) * (W_HY * W_HZ) + ((t1 / 3) % 3 - 1) * W_HZ + (t1 % 3 - 1)) * 3) + g1 % 3 : 0;
+        const int off = h ? o1 : o0;
+        const float a0 = sS[hrow[0] + off], a1 = sS[hrow[1] + off];
+        const float b0 = sW[(g0 + h) * 64 + (lane & 31)], b1 = sW[(g0 + h) * 64 + 32 + (lane & 31)];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int v = wave * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int gx = x0 + (v >> 6), gy = y0 + ((v >> 3) & 7), gz = z0 + (v & 7);
+            if (gx < X && gy < Y && gz < Z) {
+                float* o = dx + ((size_t)b * nvox + ((size_t)gx * Y + gy) * Z + gz) * Cin + cb * 64 + (lane & 31);
+                o[0] = acc[m][0][r];
+                o[32] = acc[m][1][r];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------- //
 // Adam (Keras: w -= lr_t * m / (sqrt(v) + eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t))
 // ------------------------------------------------------------------------- //
 __global__ void __launch_bounds__(TB)
@@ -1293,8 +1490,8 @@ extern "C" int64_t mmr_conv3d_k3_wgrad_ws_bytes(int B, int X, int Y, int Z, int 
     int ntx, nty, ntz, ntiles, nslices, ncob, gx;
     wgrad_geom(B, X, Y, Z, Cin, Cout, ntx, nty, ntz, ntiles, nslices, ncob, gx);
     int64_t bytes = (int64_t)gx * nslices * ncob * 27 * 32 * 64 * sizeof(float);
-    const int64_t valu = (int64_t)1024 * 27 * Cin * 3 * sizeof(float);  // wgrad_cout3_kernel partials
-    if (Cout == 3 && valu > bytes) bytes = valu;
+    const int64_t thin = (int64_t)512 * 4 * 64 * 96 * sizeof(float);  // smallch_wgrad_kernel partials
+    if (Cout == 3 && thin > bytes) bytes = thin;
     return bytes;
 }
 
@@ -1306,17 +1503,27 @@ static int wgrad_impl(const float* in0, int C0, int up0, const float* in1, int C
         C1 % 32 || (C1 > 0 && !in1))
         return MMR_EINVAL;
     if (up0 && ((X | Y | Z) & 1)) return MMR_EINVAL;
-    if (Cout == 3 && C1 == 0 && !up0 && C0 % 64 == 0) {  // flow head: VALU kernel, scalar dY, no padding waste
-        const int nzr = (Z + WG3_RUN - 1) / WG3_RUN;
-        const int64_t njobs = (int64_t)B * X * Y * nzr;
-        int nblk = (int)((njobs + 3) / 4 < 1024 ? (njobs + 3) / 4 : 1024);
-        if ((int64_t)nblk * 27 * C0 * 3 * (int64_t)sizeof(float) > mmr_conv3d_k3_wgrad_ws_bytes(B, X, Y, Z, C0, Cout)) nblk = 1;
-        hipLaunchKernelGGL(wgrad_cout3_kernel, dim3(nblk, C0 / 64), dim3(TB), 0, as_stream(stream), in0, dz, (float*)ws,
-                           B, X, Y, Z, C0, nzr, njobs);
+    if (Cout == 3 && C1 == 0 && !up0 && C0 % 64 == 0) {  // flow head: taps folded into the GEMM N axis (81 of 96 used)
+        const int ntx = (X + W_TX - 1) / W_TX, nty = (Y + W_TY - 1) / W_TY, ntz = (Z + W_TZ - 1) / W_TZ;
+        const int ntiles = B * ntx * nty * ntz;
+        const int ncb = C0 / 64;
+        int gx = 512 / ncb;
+        if (gx > ntiles) gx = ntiles;
+        if (gx < 1) gx = 1;
+        const size_t lds = (size_t)(W_HROWS * 3 + 256 * 64) * sizeof(float);
+        static bool attr0 = false;
+        if (!attr0) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(smallch_wgrad_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
+            attr0 = true;
+        }
+        hipLaunchKernelGGL(smallch_wgrad_kernel, dim3(gx, ncb), dim3(SM_THREADS), lds, as_stream(stream), in0, C0, dz,
+                           (const float*)nullptr, 3, -1, (float*)ws, B, X, Y, Z, ntx, nty, ntz, ntiles);
         int rc0 = check_launch();
         if (rc0) return rc0;
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(stream_grid((int64_t)27 * C0 * 3, TB)), dim3(TB), 0,
-                           as_stream(stream), (const float*)ws, dw, (int64_t)27 * C0 * 3, nblk, accumulate);
+        hipLaunchKernelGGL(smallch_wgrad_reduce_kernel, dim3(C0 * 81), dim3(64), 0,
+                           as_stream(stream), (const float*)ws, dw, gx * 4, ncb, C0, 3, 0, accumulate);
         return check_launch();
     }
     WgradParams p;
@@ -1377,12 +1584,41 @@ extern "C" int mmr_conv3d_k3_wgrad_f32x3(const float* in0, int C0, int up0, cons
     return wgrad_impl(in0, C0, up0, in1, C1, dz, dw, ws, B, X, Y, Z, Cout, accumulate, 1, stream);
 }
 
-extern "C" int64_t mmr_conv3d_k3_cin2_wgrad_ws_bytes(int Cout) { return Cout < 1 ? MMR_EINVAL : (int64_t)512 * 54 * Cout * sizeof(float); }
+extern "C" int64_t mmr_conv3d_k3_cin2_wgrad_ws_bytes(int Cout)
+{
+    if (Cout < 1) return MMR_EINVAL;
+    const int64_t a = (int64_t)512 * 54 * Cout * sizeof(float);
+    const int64_t b = (int64_t)512 * 4 * 64 * 96 * sizeof(float);
+    return a > b ? a : b;
+}
 
 extern "C" int mmr_conv3d_k3_cin2_wgrad_f32(const float* src, const float* trg, const float* dz, float* dw, void* ws,
                                             int B, int X, int Y, int Z, int Cout, int accumulate, void* stream)
 {
     if (!src || !trg || !dz || !dw || !ws || B < 1 || X < 1 || Y < 1 || Z < 1) return MMR_EINVAL;
+    if (Cout % 64 == 0) {  // fp32 matrix cores: T[co][tap*2 + ci] = sum_v dZ[v][co] * img_ci[v + off(tap)]
+        const int ntx = (X + W_TX - 1) / W_TX, nty = (Y + W_TY - 1) / W_TY, ntz = (Z + W_TZ - 1) / W_TZ;
+        const int ntiles = B * ntx * nty * ntz;
+        const int ncb = Cout / 64;
+        int gx = 512 / ncb;
+        if (gx > ntiles) gx = ntiles;
+        if (gx < 1) gx = 1;
+        const size_t lds = (size_t)(W_HROWS * 3 + 256 * 64) * sizeof(float);
+        static bool attr0 = false;
+        if (!attr0) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(smallch_wgrad_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
+            attr0 = true;
+        }
+        hipLaunchKernelGGL(smallch_wgrad_kernel, dim3(gx, ncb), dim3(SM_THREADS), lds, as_stream(stream), dz, Cout, src, trg,
+                           2, +1, (float*)ws, B, X, Y, Z, ntx, nty, ntz, ntiles);
+        int rc0 = check_launch();
+        if (rc0) return rc0;
+        hipLaunchKernelGGL(smallch_wgrad_reduce_kernel, dim3(Cout * 54), dim3(64), 0,
+                           as_stream(stream), (const float*)ws, dw, gx * 4, ncb, Cout, 2, 1, accumulate);
+        return check_launch();
+    }
     if (!(Cout == 32 || Cout == 64 || Cout == 128 || Cout == 256)) return MMR_EUNSUPPORTED;
     const int ntx = (X + G_TX - 1) / G_TX, nty = (Y + G_TY - 1) / G_TY, ntz = (Z + G_TZ - 1) / G_TZ;
     const int ntiles = B * ntx * nty * ntz;
@@ -1400,6 +1636,14 @@ extern "C" int mmr_conv3d_k3_cout3_dgrad_f32(const float* dy, const float* w_ker
                                              int Z, int Cin, void* stream)
 {
     if (!dy || !w_keras || !dx || B < 1 || X < 1 || Y < 1 || Z < 1 || Cin < 1 || Cin > 512) return MMR_EINVAL;
+    if (Cin % 64 == 0) {  // fp32 matrix cores, K = 27 taps x 3 folded
+        const int ntx = (X + W_TX - 1) / W_TX, nty = (Y + W_TY - 1) / W_TY, ntz = (Z + W_TZ - 1) / W_TZ;
+        const int64_t nblk = (int64_t)B * ntx * nty * ntz;
+        if (nblk > 0x7fffffff) return MMR_EINVAL;
+        hipLaunchKernelGGL(flow_dgrad_mfma_kernel, dim3((unsigned)nblk, Cin / 64), dim3(SM_THREADS), 0, as_stream(stream),
+                           dy, w_keras, dx, B, X, Y, Z, Cin, ntx, nty, ntz);
+        return check_launch();
+    }
     if (Cin % 4 == 0) {
         const int64_t nblk = ((int64_t)B * X * Y * Z + TB - 1) / TB;
         if (nblk > 0x7fffffff) return MMR_EINVAL;
