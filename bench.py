@@ -7,8 +7,10 @@ infer (default) = BASELINE.json configs[1]: 3d_reg.py-style inference, one VxmDe
   (enc/dec = 256, int_steps 5, half-res SVF) on a 160x160x192 pair, bf16 MFMA / fp32 accumulate,
   inputs resident in HBM.  A step = one pair.  N > 1 = independent replicas (single-pair inference
   does not shard), weak scaling, no data-path collective.
-train = configs[2]: SynthMorph training step at 160^3, enc/dec = 64 (config/config.json), fp32, 1 pair per
-  GPU, Dice + Grad-l2, generators on device, RCCL SUM all-reduce of the flat gradient buffer + Adam.
+train = configs[2]: SynthMorph training step at 160^3, enc/dec = 64 (config/config.json), 1 pair per GPU,
+  Dice + Grad-l2, generators on device, RCCL SUM all-reduce of the flat gradient buffer + Adam.  Tensors are
+  fp32; --dtype fp32x3 (default) runs the conv products as bf16 hi/lo splits (3 bf16 MFMAs, ~5e-6 relative
+  error, inside north_star's 1e-4 fp32 bar), --dtype fp32 uses the exact fp32 MFMA.
 ncc   = configs[4]: local NCC (win 9) + bending energy forward on 256^3 fp32 volumes.
 Rank 0 prints ONE JSON line.
 """
@@ -164,7 +166,7 @@ def main():
         from mmr import synth, training
         shape = tuple(args.shape or (160, 160, 160))
         feats = args.features or 64
-        dtype = args.dtype or "fp32"
+        dtype = args.dtype or "fp32x3"
         if dtype == "bf16":
             raise SystemExit("training runs fp32 or fp32x3 (fp32 tensors; bf16 hi/lo split inside the convs)")
         L = 26

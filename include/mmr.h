@@ -142,6 +142,12 @@ int mmr_dice_labels_fwd(const uint8_t* lab1, const uint8_t* lab2, const float* f
 /* dflow (+)= scale * d loss / d flow */
 int mmr_dice_labels_bwd(const uint8_t* lab1, const uint8_t* lab2, const float* flow, const float* top_bot,
                         float* dflow, int B, int X, int Y, int Z, int L, float scale, int accumulate, void* stream);
+/* losses.dice_loss_zeropad (losses.py:11-69, as its docstring intends; the reference function itself always
+ * raises): voxels whose label-0 channel is >= 1 in either map are masked, labels 1..L-1 of batch item 0. */
+int mmr_dice_labels_zeropad_fwd(const uint8_t* lab1, const uint8_t* lab2, const float* flow, float* loss, float* top_bot,
+                                void* ws, int B, int X, int Y, int Z, int L, void* stream);
+int mmr_dice_labels_zeropad_bwd(const uint8_t* lab1, const uint8_t* lab2, const float* flow, const float* top_bot,
+                                float* dflow, int B, int X, int Y, int Z, int L, float scale, int accumulate, void* stream);
 /* dflow (+)= scale * d/dflow sum_b Grad('l2', loss_mult)(flow)[b] */
 int mmr_grad_l2_bwd_f32(const float* flow, float* dflow, int B, int X, int Y, int Z, int C, float loss_mult,
                         float scale, int accumulate, void* stream);

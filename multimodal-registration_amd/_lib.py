@@ -51,6 +51,8 @@ SIGNATURES = {
     "mmr_dice_labels_ws_bytes": (c_int64, [I, c_int64, I]),
     "mmr_dice_labels_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
     "mmr_dice_labels_bwd": (I, [P, P, P, P, P, I, I, I, I, I, F, I, P]),
+    "mmr_dice_labels_zeropad_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
+    "mmr_dice_labels_zeropad_bwd": (I, [P, P, P, P, P, I, I, I, I, I, F, I, P]),
     "mmr_grad_l2_bwd_f32": (I, [P, P, I, I, I, I, I, F, F, I, P]),
     "mmr_resize_trilinear_bwd_f32": (I, [P, P, I, I, I, I, I, I, I, I, F, P]),
     "mmr_compose_bwd_f32": (I, [P, P, P, P, P, I, I, I, I, P]),

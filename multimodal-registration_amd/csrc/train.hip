@@ -61,7 +61,7 @@ __device__ __forceinline__ AxisG axis_setup_g(float loc, int maxi)
 __global__ void __launch_bounds__(TB)
 dice_labels_partial_kernel(const uint8_t* __restrict__ lab1, const uint8_t* __restrict__ lab2,
                            const float* __restrict__ flow, double* __restrict__ part, int X, int Y, int Z, int L,
-                           int nblk)
+                           int nblk, int zeropad)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_tp = reinterpret_cast<float*>(smem);  // [L][TB]
@@ -81,11 +81,22 @@ dice_labels_partial_kernel(const uint8_t* __restrict__ lab1, const uint8_t* __re
         const AxisG az = axis_setup_g((float)z + f[v * 3 + 2], Z - 1);
         const int t = a2[v];
         float pt = 0.f;  // pred at the target's label
+        float wl[8];
+        int ll[8];
+        float p0 = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int cx = c >> 2, cy = (c >> 1) & 1, cz = c & 1;
-            const float w = ((cx ? ax.w1 : ax.w0) * (cy ? ay.w1 : ay.w0)) * (cz ? az.w1 : az.w0);
-            const int l = a1[(cx ? ax.i1 : ax.i0) * sx + (cy ? ay.i1 : ay.i0) * sy + (cz ? az.i1 : az.i0)];
+            wl[c] = ((cx ? ax.w1 : ax.w0) * (cy ? ay.w1 : ay.w0)) * (cz ? az.w1 : az.w0);
+            ll[c] = a1[(cx ? ax.i1 : ax.i0) * sx + (cy ? ay.i1 : ay.i0) * sy + (cz ? az.i1 : az.i0)];
+            if (ll[c] == 0) p0 += wl[c];
+        }
+        // losses.py:34-54 intent: drop voxels whose label-0 channel is >= 1 in either map
+        if (zeropad && (t == 0 || p0 >= 1.f)) continue;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float w = wl[c];
+            const int l = ll[c];
             if (l < L) s_bt[l * TB + tid] += w;
             if (l == t) pt += w;
         }
@@ -108,7 +119,7 @@ dice_labels_partial_kernel(const uint8_t* __restrict__ lab1, const uint8_t* __re
 // top_bot[b][l] = (2*sum tp, sum t+p); loss[0] = -mean divide_no_nan(top, bot)
 __global__ void __launch_bounds__(TB)
 dice_labels_final_kernel(const double* __restrict__ part, float* __restrict__ loss, float* __restrict__ top_bot,
-                         int B, int L, int nblk)
+                         int B, int L, int nblk, int zeropad)
 {
     __shared__ double sh[4];
     double acc = 0.0;
@@ -123,24 +134,25 @@ dice_labels_final_kernel(const double* __restrict__ part, float* __restrict__ lo
         const float ft = (float)(2.0 * st), fb = (float)sb;
         top_bot[i * 2] = ft;
         top_bot[i * 2 + 1] = fb;
-        acc += (fb != 0.f) ? (double)(ft / fb) : 0.0;
+        const bool counted = !zeropad || (b == 0 && l >= 1);  // zeropad: labels 1..L-1 of batch item 0 only
+        if (counted) acc += (fb != 0.f) ? (double)(ft / fb) : 0.0;
     }
     const double s = block_sum_d(acc, sh);
-    if (threadIdx.x == 0) loss[0] = (float)(-s / (double)(B * L));
+    if (threadIdx.x == 0) loss[0] = (float)(-s / (double)(zeropad ? (L - 1) : B * L));
 }
 
 // d_flow[b,v,:] (+)= scale * d(dice)/d(flow); dice = -1/(B L) sum_{b,l} top/bot
 __global__ void __launch_bounds__(TB)
 dice_labels_bwd_kernel(const uint8_t* __restrict__ lab1, const uint8_t* __restrict__ lab2,
                        const float* __restrict__ flow, const float* __restrict__ top_bot, float* __restrict__ dflow,
-                       int B, int X, int Y, int Z, int L, float scale, int accumulate)
+                       int B, int X, int Y, int Z, int L, float scale, int accumulate, int zeropad)
 {
     __shared__ float sA[256], sB[256];  // G[l] = sA[l] + [l == target] * sB[l]
     const int b = blockIdx.y;
-    const float c = -scale / (float)(B * L);
+    const float c = zeropad ? ((b == 0) ? -scale / (float)(L - 1) : 0.f) : -scale / (float)(B * L);
     for (int l = threadIdx.x; l < 256; l += TB) {
         float a = 0.f, bb = 0.f;
-        if (l < L) {
+        if (l < L && !(zeropad && l == 0)) {
             const float top = top_bot[(b * L + l) * 2], bot = top_bot[(b * L + l) * 2 + 1];
             if (bot != 0.f) {
                 a = -c * top / (bot * bot);   // d(top/bot)/dp via bot: -top/bot^2
@@ -164,11 +176,17 @@ dice_labels_bwd_kernel(const uint8_t* __restrict__ lab1, const uint8_t* __restri
         const AxisG az = axis_setup_g((float)z + f[v * 3 + 2], Z - 1);
         const int t = a2[v];
         float G[8];
+        float p0 = 0.f;
 #pragma unroll
         for (int cc = 0; cc < 8; ++cc) {
             const int cx = cc >> 2, cy = (cc >> 1) & 1, cz = cc & 1;
             const int l = a1[(cx ? ax.i1 : ax.i0) * sx + (cy ? ay.i1 : ay.i0) * sy + (cz ? az.i1 : az.i0)];
             G[cc] = sA[l] + (l == t ? sB[l] : 0.f);
+            if (l == 0) p0 += ((cx ? ax.w1 : ax.w0) * (cy ? ay.w1 : ay.w0)) * (cz ? az.w1 : az.w0);
+        }
+        if (zeropad && (t == 0 || p0 >= 1.f)) {  // masked voxel: no gradient (the mask itself is piecewise constant)
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) G[cc] = 0.f;
         }
         // d out / d loc_x = inr_x * sum_{cy,cz} wy wz (G[1,cy,cz] - G[0,cy,cz]) etc.
         const float gx = ax.inr * (ay.w0 * az.w0 * (G[4] - G[0]) + ay.w0 * az.w1 * (G[5] - G[1]) +
@@ -1310,18 +1328,42 @@ extern "C" int64_t mmr_dice_labels_ws_bytes(int B, int64_t nvox, int L)
     return (int64_t)B * rblocks(nvox, TB * 16) * L * 2 * sizeof(double);
 }
 
-extern "C" int mmr_dice_labels_fwd(const uint8_t* lab1, const uint8_t* lab2, const float* flow, float* loss,
-                                   float* top_bot, void* ws, int B, int X, int Y, int Z, int L, void* stream)
+static int dice_labels_fwd_impl(const uint8_t* lab1, const uint8_t* lab2, const float* flow, float* loss,
+                                float* top_bot, void* ws, int B, int X, int Y, int Z, int L, int zeropad, void* stream)
 {
     if (!lab1 || !lab2 || !flow || !loss || !top_bot || !ws || B < 1 || X < 1 || Y < 1 || Z < 1 || L < 1 || L > 64)
         return MMR_EINVAL;
     const int nblk = rblocks((int64_t)X * Y * Z, TB * 16);
     hipLaunchKernelGGL(dice_labels_partial_kernel, dim3(nblk, B), dim3(TB), 2 * L * TB * sizeof(float),
-                       as_stream(stream), lab1, lab2, flow, (double*)ws, X, Y, Z, L, nblk);
+                       as_stream(stream), lab1, lab2, flow, (double*)ws, X, Y, Z, L, nblk, zeropad);
     int rc = check_launch();
     if (rc) return rc;
     hipLaunchKernelGGL(dice_labels_final_kernel, dim3(1), dim3(TB), 0, as_stream(stream), (const double*)ws, loss,
-                       top_bot, B, L, nblk);
+                       top_bot, B, L, nblk, zeropad);
+    return check_launch();
+}
+
+extern "C" int mmr_dice_labels_fwd(const uint8_t* lab1, const uint8_t* lab2, const float* flow, float* loss,
+                                   float* top_bot, void* ws, int B, int X, int Y, int Z, int L, void* stream)
+{
+    return dice_labels_fwd_impl(lab1, lab2, flow, loss, top_bot, ws, B, X, Y, Z, L, 0, stream);
+}
+
+extern "C" int mmr_dice_labels_zeropad_fwd(const uint8_t* lab1, const uint8_t* lab2, const float* flow, float* loss,
+                                           float* top_bot, void* ws, int B, int X, int Y, int Z, int L, void* stream)
+{
+    if (L < 2) return MMR_EINVAL;
+    return dice_labels_fwd_impl(lab1, lab2, flow, loss, top_bot, ws, B, X, Y, Z, L, 1, stream);
+}
+
+static int dice_labels_bwd_impl(const uint8_t* lab1, const uint8_t* lab2, const float* flow, const float* top_bot,
+                                float* dflow, int B, int X, int Y, int Z, int L, float scale, int accumulate, int zeropad,
+                                void* stream)
+{
+    if (!lab1 || !lab2 || !flow || !top_bot || !dflow || B < 1 || X < 1 || Y < 1 || Z < 1 || L < 1 || L > 64)
+        return MMR_EINVAL;
+    hipLaunchKernelGGL(dice_labels_bwd_kernel, dim3(rblocks((int64_t)X * Y * Z, TB * 4, 2048), B), dim3(TB), 0,
+                       as_stream(stream), lab1, lab2, flow, top_bot, dflow, B, X, Y, Z, L, scale, accumulate, zeropad);
     return check_launch();
 }
 
@@ -1329,11 +1371,14 @@ extern "C" int mmr_dice_labels_bwd(const uint8_t* lab1, const uint8_t* lab2, con
                                    float* dflow, int B, int X, int Y, int Z, int L, float scale, int accumulate,
                                    void* stream)
 {
-    if (!lab1 || !lab2 || !flow || !top_bot || !dflow || B < 1 || X < 1 || Y < 1 || Z < 1 || L < 1 || L > 64)
-        return MMR_EINVAL;
-    hipLaunchKernelGGL(dice_labels_bwd_kernel, dim3(rblocks((int64_t)X * Y * Z, TB * 4, 2048), B), dim3(TB), 0,
-                       as_stream(stream), lab1, lab2, flow, top_bot, dflow, B, X, Y, Z, L, scale, accumulate);
-    return check_launch();
+    return dice_labels_bwd_impl(lab1, lab2, flow, top_bot, dflow, B, X, Y, Z, L, scale, accumulate, 0, stream);
+}
+
+extern "C" int mmr_dice_labels_zeropad_bwd(const uint8_t* lab1, const uint8_t* lab2, const float* flow,
+                                           const float* top_bot, float* dflow, int B, int X, int Y, int Z, int L,
+                                           float scale, int accumulate, void* stream)
+{
+    return dice_labels_bwd_impl(lab1, lab2, flow, top_bot, dflow, B, X, Y, Z, L, scale, accumulate, 1, stream);
 }
 
 extern "C" int mmr_grad_l2_bwd_f32(const float* flow, float* dflow, int B, int X, int Y, int Z, int C, float loss_mult,

@@ -381,7 +381,7 @@ def axpy_(y, x, a=1.0):
 
 
 # ------------------------------- training ------------------------------- #
-def dice_labels_fwd(lab1, lab2, flow, L):
+def dice_labels_fwd(lab1, lab2, flow, L, zeropad=False):
     """Dice(one_hot(lab2), warp_linear(one_hot(lab1), flow)) from uint8 label maps [B,X,Y,Z(,1)]."""
     _chk(lab1, torch.uint8, "lab1")
     _chk(lab2, torch.uint8, "lab2")
@@ -393,19 +393,21 @@ def dice_labels_fwd(lab1, lab2, flow, L):
     ws = _ws(lib.mmr_dice_labels_ws_bytes(B, X * Y * Z, L), flow.device)
     loss = torch.empty(1, dtype=torch.float32, device=flow.device)
     tb = torch.empty((B, L, 2), dtype=torch.float32, device=flow.device)
-    rc = lib.mmr_dice_labels_fwd(lab1.data_ptr(), lab2.data_ptr(), flow.data_ptr(), loss.data_ptr(), tb.data_ptr(),
-                                 ws.data_ptr(), B, X, Y, Z, int(L), _stream())
+    fn = lib.mmr_dice_labels_zeropad_fwd if zeropad else lib.mmr_dice_labels_fwd
+    rc = fn(lab1.data_ptr(), lab2.data_ptr(), flow.data_ptr(), loss.data_ptr(), tb.data_ptr(),
+            ws.data_ptr(), B, X, Y, Z, int(L), _stream())
     _lib.check(rc, "mmr_dice_labels_fwd")
     return loss[0], tb
 
 
-def dice_labels_bwd(lab1, lab2, flow, top_bot, L, scale=1.0, out=None):
+def dice_labels_bwd(lab1, lab2, flow, top_bot, L, scale=1.0, out=None, zeropad=False):
     B, X, Y, Z = flow.shape[:4]
     acc = out is not None
     if out is None:
         out = torch.empty_like(flow)
-    rc = _lib.load().mmr_dice_labels_bwd(lab1.data_ptr(), lab2.data_ptr(), flow.data_ptr(), top_bot.data_ptr(),
-                                         out.data_ptr(), B, X, Y, Z, int(L), float(scale), int(acc), _stream())
+    fn = _lib.load().mmr_dice_labels_zeropad_bwd if zeropad else _lib.load().mmr_dice_labels_bwd
+    rc = fn(lab1.data_ptr(), lab2.data_ptr(), flow.data_ptr(), top_bot.data_ptr(),
+            out.data_ptr(), B, X, Y, Z, int(L), float(scale), int(acc), _stream())
     _lib.check(rc, "mmr_dice_labels_bwd")
     return out
 

@@ -175,13 +175,13 @@ class SynthMorphTrainer:
         tape = []
         flow = self._forward(ima_1, ima_2, tape)
         svf, steps, pos_lo, pos = self._tail_forward(flow)
-        dice, top_bot = ops.dice_labels_fwd(lab1, lab2, pos, self.L)
+        dice, top_bot = ops.dice_labels_fwd(lab1, lab2, pos, self.L, zeropad=self.zero_pad_dice)
         gl = ops.grad_l2_loss(pos, self.reg_param)
         out = {"dice": dice, "grad": gl, "loss": (dice + 1.0) + gl.mean(), "pos_flow": pos, "preint_flow": svf}
         if not train:
             return out
         # d/dflow of sum_b [(dice + 1) + grad_b]   (Keras sums the per-replica loss vector)
-        dpos = ops.dice_labels_bwd(lab1, lab2, pos, top_bot, self.L, scale=float(b))
+        dpos = ops.dice_labels_bwd(lab1, lab2, pos, top_bot, self.L, scale=float(b), zeropad=self.zero_pad_dice)
         ops.grad_l2_bwd(pos, self.reg_param, scale=1.0, out=dpos)
         dflow = self._tail_backward(dpos, svf, steps)
         self._backward(tape, dflow)

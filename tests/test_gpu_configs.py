@@ -1,0 +1,73 @@
+"""BASELINE.json configs as end-to-end cases (parity-test cases, not bench lines):
+ C1: config/config.json-style SynthMorph training, 2 synthetic label maps, vol 64^3, 1 step;
+ C4: bids_two_steps_registration.py cascade (two VxmDense passes + compose) on a synthetic pair."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# the 44 keys of the reference's config/config.json (values adapted to C1: 64^3, 2 maps, 1 epoch of 1 step)
+CONFIG_C1 = {
+    "model_dir": "models", "log_dir": "logs", "bool_sub_dir": False, "sub_dir": "train_ex", "gen_label_only": False,
+    "gen_label": True, "save_label": False, "label_dir": "labels", "zero_borders_maps": False,
+    "zero_borders_maps_val": False, "zero_bord_scale": 8, "zero_bord_frac": 0.5, "in_shape": [64, 64, 64],
+    "num_labels": 26, "num_maps": 2, "im_scales": [16, 32, 64], "def_scales": [8, 16, 32], "im_max_std": 1,
+    "def_max_std": 3, "add_str": "26lab_", "same_subj": True, "blur_std": 1, "gamma": 0.25, "vel_std": 3, "vel_res": 16,
+    "bias_std": 0.3, "bias_res": 40, "gpu": "0", "epochs": 1, "batch_size": 1, "train_frac": 0.5, "batch_size_val": 1,
+    "save_freq": 1, "bool_init_weights": False, "init_weights": "model.h5", "reg_param": 1, "lr": 1e-4, "init_epoch": 0,
+    "verbose": 0, "int_steps": 5, "int_res": 2, "svf_res": 2, "enc": [64, 64, 64, 64], "dec": [64, 64, 64, 64, 64, 64],
+}
+
+
+def test_c1_training_from_reference_config(dev, tmp_path):
+    from mmr import networks, training
+    assert len(CONFIG_C1) == 44
+    cfg = dict(CONFIG_C1, model_dir=str(tmp_path / "models"))
+    trainer, hist = training.run_training(cfg, device=dev, seed=0)
+    assert len(hist) == 1 and np.isfinite(hist[0]["loss"]) and 0 < hist[0]["loss"] < 2.5
+    assert "val_loss" in hist[0] and np.isfinite(hist[0]["val_loss"])
+    # ModelCheckpoint-style files: initial save (epoch 0) and the epoch-1 save; reloadable with shape change
+    for ep in (0, 1):
+        assert (tmp_path / "models" / f"{ep:04d}.safetensors").exists()
+    m = networks.VxmDense.load(str(tmp_path / "models" / "0001.safetensors"), compute_dtype="fp32")
+    assert m.inshape == (64, 64, 64) and len(m.get_weights()) == 22
+    m2 = networks.VxmDense((32, 48, 32), nb_unet_features=(cfg["enc"], cfg["dec"]), int_steps=5, int_resolution=2,
+                           svf_resolution=2, compute_dtype="fp32")
+    m2.set_weights(m.get_weights())  # 3d_reg.py:305-306
+    rng = np.random.default_rng(0)
+    moved, warp = m2.predict([rng.random((1, 32, 48, 32, 1)), rng.random((1, 32, 48, 32, 1))])
+    assert moved.shape == (1, 32, 48, 32, 1) and warp.shape == (1, 16, 24, 16, 3) and np.isfinite(moved).all()
+
+
+def test_c4_two_step_cascade_matches_oracle(dev):
+    """bids_two_steps_registration.py:318-325 (linear / whole volume)."""
+    import mmr
+    from oracle import net_np
+    from oracle import ops_np as O
+    shape, enc, dec = (32, 32, 32), [64] * 4, [64] * 6
+    rng = np.random.default_rng(1)
+    mov = rng.random((1,) + shape + (1,)).astype(np.float32)
+    fix = rng.random((1,) + shape + (1,)).astype(np.float32)
+    w1 = net_np.init_weights(enc, dec, seed=1, flow_std=2e-2)
+    w2 = net_np.init_weights(enc, dec, seed=2, flow_std=2e-2)
+    kw = dict(nb_unet_features=(enc, dec), int_steps=5, int_resolution=2, svf_resolution=2, compute_dtype="fp32")
+    m1, m2 = mmr.networks.VxmDense(shape, **kw), mmr.networks.VxmDense(shape, **kw)
+    m1.set_weights(w1)
+    m2.set_weights(w2)
+    moved1, warp1 = m1.predict([mov, fix])
+    moved, warp2 = m2.predict([moved1, fix])
+    warp = mmr.utils.compose([warp1[0], warp2[0]])
+    r1 = net_np.vxm_dense_forward(mov, fix, w1, enc, dec, 5, 2, 2)
+    r2 = net_np.vxm_dense_forward(r1["moved"], fix, w2, enc, dec, 5, 2, 2)
+    ref_warp = O.compose(r1["preint_flow"][0], r2["preint_flow"][0])
+    scale = 1 if warp1[0].shape[0] == shape[0] else 2
+    assert scale == 2 and warp.shape == (16, 16, 16, 3)
+    assert np.abs(moved - r2["moved"]).max() / np.abs(r2["moved"]).max() < 1e-4
+    assert np.abs(warp - ref_warp).max() / np.abs(ref_warp).max() < 1e-4
+    # the field the reference would save: rescaled x2 to full resolution (bids_two_steps_registration.py:515)
+    full = mmr.utils.rescale_dense_transform(warp[None], scale)
+    np.testing.assert_allclose(full[0], O.rescale_dense_transform(ref_warp, 2), atol=2e-4 * np.abs(ref_warp).max() + 1e-6)
+    # nearest-neighbour variant applies the composed field with Transform (…:354-355)
+    tr = mmr.networks.Transform(shape, interp_method="nearest", rescale=scale, nb_feats=1).predict([mov, warp[None]])
+    assert tr.shape == (1,) + shape + (1,)

@@ -46,6 +46,42 @@ def test_dice_from_labels_matches_onehot_formulation(dev):
     assert _rel(acc - 1, 2 * f.grad) < 1e-4
 
 
+def test_dice_zeropad_from_labels(dev):
+    """Zero-pad-aware Dice (losses.py docstring intent) from label maps vs the one-hot oracle + autograd."""
+    import mmr
+    from oracle import grad_torch as G
+    from oracle import ops_np as O
+    rng = np.random.default_rng(11)
+    B, S, L = 2, (10, 12, 9), 6
+    lab1 = rng.integers(0, L, (B,) + S).astype(np.uint8)
+    lab2 = rng.integers(0, L, (B,) + S).astype(np.uint8)
+    lab1[:, :3] = 0  # zero-padded borders in both maps
+    lab2[:, :, :2] = 0
+    flow = (rng.standard_normal((B,) + S + (3,)) * 1.5).astype(np.float32)
+    loss, tb = mmr.ops.dice_labels_fwd(_t(lab1, dev), _t(lab2, dev), _t(flow, dev), L, zeropad=True)
+    e = np.eye(L, dtype=np.float32)
+    pred = O.spatial_transformer(e[lab1], flow, "linear")
+    ref = O.dice_loss_zeropad(e[lab2], pred)
+    assert abs(float(loss) - ref) < 1e-5
+    # the product's composed one-hot version agrees too
+    comp = mmr.losses.dice_loss_zeropad(e[lab2], pred)
+    assert abs(float(comp) - ref) < 1e-5
+    # gradient: autograd through the same masked formula (mask treated as constant)
+    f = torch.from_numpy(flow).double().requires_grad_(True)
+    et = torch.eye(L, dtype=torch.float64)
+    p = torch.stack([G.transform(et[torch.from_numpy(lab1[b]).long()], f[b]) for b in range(B)])
+    t0, p0 = et[torch.from_numpy(lab2[0]).long()], p[0]
+    # the mask is decided on the fp32 prediction, exactly as the forward does
+    keep = ~((t0[..., 0] >= 1) | torch.from_numpy(pred[0][..., 0] >= 1))
+    tm, pm = t0 * keep[..., None], p0 * keep[..., None]
+    top = 2 * (tm * pm).sum((0, 1, 2))[1:]
+    bot = (tm + pm).sum((0, 1, 2))[1:]
+    (-(top / bot).mean()).backward()
+    got = mmr.ops.dice_labels_bwd(_t(lab1, dev), _t(lab2, dev), _t(flow, dev), tb, L, scale=1.0, zeropad=True)
+    assert _rel(got, f.grad) < 1e-4
+    assert float(got[1].abs().max()) == 0.0  # only batch item 0 contributes (losses.py:38-39)
+
+
 def test_grad_l2_bwd(dev):
     import mmr
     from oracle import grad_torch as G
