@@ -133,102 +133,133 @@ __global__ void grad_l2_final_kernel(const double* __restrict__ part, float* __r
 }
 
 // ------------------------------ local NCC ------------------------------- //
-// Block = one (TY x TZ) column marched along an X segment.  Per plane: load
-// the haloed tile of I and J, form I,J,I^2,J^2,IJ in LDS, box-sum along z
-// then y (zero 'SAME' padding), keep a 9-deep register ring of plane sums per
-// thread and sum the ring for the x box.  HBM traffic = inputs x halo factor.
-template <int TY, int TZ, int WIN>
-__global__ void __launch_bounds__(TY * TZ)
-ncc_partial_kernel(const float* __restrict__ I, const float* __restrict__ J, double* __restrict__ part,
-                   int X, int Y, int Z, int xseg, int nseg, float eps)
+// Two wave-centric passes, no LDS, no block barriers:
+//  pass 1 (zy box): a wave owns a strip of rows x 56 z-outputs (64 lanes incl. 4+4 halo) of one x-plane
+//    and walks the rows; the 9-wide z window is a log-step wavefront-shuffle reduction
+//    (s2 = v + shfl(v,1); s4 = s2 + shfl(s2,2); s8 = s4 + shfl(s4,4); s9 = s8 + shfl(v,8)), the 9-row y
+//    window a register ring.  Writes the 5 zy-box sums of (I, J, I^2, J^2, IJ).
+//  pass 2 (x box + cc): a thread owns a (y,z) column and slides a 9-plane register ring along x.
+// 'SAME' zero padding falls out of loading zeros outside the volume.
+constexpr int NCC_ZOUT = 56;   // outputs per wave along z (lanes 4..59)
+constexpr int NCC_ROWS = 32;   // output rows per wave strip
+
+__device__ __forceinline__ float box9_lanes(float v)
 {
-    constexpr int R = WIN / 2;           // 4
-    constexpr int HY = TY + 2 * R, HZ = TZ + 2 * R;
-    __shared__ float s_q[5][HY][HZ + 1];
-    __shared__ float s_z[5][HY][TZ + 1];
-    __shared__ double sh[(TY * TZ + 63) / 64 > 4 ? (TY * TZ + 63) / 64 : 4];
-    const int tz = threadIdx.x % TZ, ty = threadIdx.x / TZ;
+    const float s2 = v + __shfl_down(v, 1, 64);
+    const float s4 = s2 + __shfl_down(s2, 2, 64);
+    const float s8 = s4 + __shfl_down(s4, 4, 64);
+    return s8 + __shfl_down(v, 8, 64);  // lane l holds sum of lanes l..l+8
+}
+
+__global__ void __launch_bounds__(256)
+ncc_zybox_kernel(const float* __restrict__ I, const float* __restrict__ J, float* __restrict__ zy, int B, int X, int Y,
+                 int Z, int nzs, int nys)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)B * X * nys * nzs;
+    if (wid >= nw) return;
+    int64_t t = wid;
+    const int zs = (int)(t % nzs); t /= nzs;
+    const int ys = (int)(t % nys); t /= nys;
+    const int x = (int)(t % X);
+    const int b = (int)(t / X);
+    const int z = zs * NCC_ZOUT + lane - 4;          // input z of this lane; box result at lane l covers z..z+8
+    const int y0 = ys * NCC_ROWS;
+    const int y1 = (y0 + NCC_ROWS < Y) ? y0 + NCC_ROWS : Y;
+    const bool zin = z >= 0 && z < Z;
+    const size_t nvox = (size_t)X * Y * Z;
+    const float* Ip = I + (size_t)b * nvox + (size_t)x * Y * Z;
+    const float* Jp = J + (size_t)b * nvox + (size_t)x * Y * Z;
+    float ring[9][5];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) ring[k][q] = 0.f;
+    // output for centre z_c = z + 4 lives in lane l (window lanes l..l+8): valid for lanes 0..55
+    const int zc = z + 4;
+    const bool zout = lane < NCC_ZOUT && zc < Z;
+    for (int yb = y0 - 4; yb < y1 + 4; yb += 9) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int yy = yb + k;
+            if (yy < y1 + 4) {
+                float a = 0.f, c = 0.f;
+                if (zin && yy >= 0 && yy < Y) {
+                    a = Ip[(size_t)yy * Z + z];
+                    c = Jp[(size_t)yy * Z + z];
+                }
+                ring[k][0] = box9_lanes(a);
+                ring[k][1] = box9_lanes(c);
+                ring[k][2] = box9_lanes(a * a);
+                ring[k][3] = box9_lanes(c * c);
+                ring[k][4] = box9_lanes(a * c);
+                const int yo = yy - 4;
+                if (yo >= y0 && yo < y1 && zout) {
+                    float* o = zy + ((((size_t)b * 5) * X + x) * Y + yo) * Z + zc;
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 9; ++j) s += ring[j][q];
+                        o[(size_t)q * nvox] = s;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// zy: [B][5][X][Y][Z]; thread = (y,z) column of one x segment
+__global__ void __launch_bounds__(256)
+ncc_xbox_kernel(const float* __restrict__ zy, double* __restrict__ part, int X, int Y, int Z, int xseg, int nseg, float eps)
+{
+    __shared__ double sh[4];
     const int b = blockIdx.z / nseg, seg = blockIdx.z % nseg;
-    const int z0 = blockIdx.x * TZ, y0 = blockIdx.y * TY;
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int ncol = Y * Z;
     const int x0 = seg * xseg;
     const int x1 = (x0 + xseg < X) ? x0 + xseg : X;
-    const int64_t nvox = (int64_t)X * Y * Z;
-    const float* Ib = I + (int64_t)b * nvox;
-    const float* Jb = J + (int64_t)b * nvox;
-    const float ws = (float)(WIN * WIN * WIN);
-    float ring[WIN][5];
+    const size_t nvox = (size_t)X * Y * Z;
+    const float* base = zy + (size_t)b * 5 * nvox + col;
+    const float ws = 729.f;
+    float ring[9][5];
 #pragma unroll
-    for (int k = 0; k < WIN; ++k)
+    for (int k = 0; k < 9; ++k)
 #pragma unroll
         for (int q = 0; q < 5; ++q) ring[k][q] = 0.f;
     float acc = 0.f;
-    const bool own = (y0 + ty < Y) && (z0 + tz < Z);
-    // planes xs = x0-R .. x1-1+R ; after pushing plane xs, voxel xo = xs-R is complete
-    for (int xb = x0 - R; xb < x1 + R; xb += WIN) {
+    if (col < ncol) {
+        for (int xb = x0 - 4; xb < x1 + 4; xb += 9) {
 #pragma unroll
-        for (int k = 0; k < WIN; ++k) {
-            const int xs = xb + k;
-            if (xs < x1 + R) {  // uniform across the block
-                const bool xin = (xs >= 0) && (xs < X);
-                __syncthreads();
-                for (int i = threadIdx.x; i < HY * HZ; i += TY * TZ) {
-                    const int hz = i % HZ, hy = i / HZ;
-                    const int yy = y0 + hy - R, zz = z0 + hz - R;
-                    float a = 0.f, c = 0.f;
-                    if (xin && yy >= 0 && yy < Y && zz >= 0 && zz < Z) {
-                        const int64_t o = ((int64_t)xs * Y + yy) * Z + zz;
-                        a = Ib[o];
-                        c = Jb[o];
+            for (int k = 0; k < 9; ++k) {
+                const int xs = xb + k;
+                if (xs < x1 + 4) {
+                    const bool xin = xs >= 0 && xs < X;
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) ring[k][q] = xin ? base[(size_t)q * nvox + (size_t)xs * ncol] : 0.f;
+                    const int xo = xs - 4;
+                    if (xo >= x0 && xo < x1) {
+                        float S[5];
+#pragma unroll
+                        for (int q = 0; q < 5; ++q) {
+                            float s = 0.f;
+#pragma unroll
+                            for (int j = 0; j < 9; ++j) s += ring[j][q];
+                            S[q] = s;
+                        }
+                        const float uI = S[0] / ws, uJ = S[1] / ws;
+                        const float cross = S[4] - uJ * S[0] - uI * S[1] + uI * uJ * ws;
+                        const float Iv = S[2] - 2.f * uI * S[0] + uI * uI * ws;
+                        const float Jv = S[3] - 2.f * uJ * S[1] + uJ * uJ * ws;
+                        acc += cross * cross / (Iv * Jv + eps);
                     }
-                    s_q[0][hy][hz] = a;
-                    s_q[1][hy][hz] = c;
-                    s_q[2][hy][hz] = a * a;
-                    s_q[3][hy][hz] = c * c;
-                    s_q[4][hy][hz] = a * c;
-                }
-                __syncthreads();
-                for (int i = threadIdx.x; i < HY * TZ; i += TY * TZ) {
-                    const int z = i % TZ, hy = i / TZ;
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) {
-                        float s = 0.f;
-#pragma unroll
-                        for (int j = 0; j < WIN; ++j) s += s_q[q][hy][z + j];
-                        s_z[q][hy][z] = s;
-                    }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int q = 0; q < 5; ++q) {
-                    float s = 0.f;
-#pragma unroll
-                    for (int j = 0; j < WIN; ++j) s += s_z[q][ty + j][tz];
-                    ring[k][q] = s;
-                }
-                const int xo = xs - R;
-                if (own && xo >= x0 && xo < x1) {
-                    float S[5];
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) {
-                        float s = 0.f;
-#pragma unroll
-                        for (int j = 0; j < WIN; ++j) s += ring[j][q];
-                        S[q] = s;
-                    }
-                    const float uI = S[0] / ws, uJ = S[1] / ws;
-                    const float cross = S[4] - uJ * S[0] - uI * S[1] + uI * uJ * ws;
-                    const float Iv = S[2] - 2.f * uI * S[0] + uI * uI * ws;
-                    const float Jv = S[3] - 2.f * uJ * S[1] + uJ * uJ * ws;
-                    acc += cross * cross / (Iv * Jv + eps);
                 }
             }
         }
     }
     const double r = block_sum((double)acc, sh);
-    if (threadIdx.x == 0) {
-        const int64_t nb = (int64_t)gridDim.x * gridDim.y * nseg;
-        part[(int64_t)b * nb + ((int64_t)seg * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = r;
-    }
+    if (threadIdx.x == 0) part[((size_t)b * nseg + seg) * gridDim.x + blockIdx.x] = r;
 }
 
 __global__ void mean_final_kernel(const double* __restrict__ part, float* __restrict__ out, int B, int64_t nb,
@@ -243,34 +274,59 @@ __global__ void mean_final_kernel(const double* __restrict__ part, float* __rest
 }
 
 // ------------------------------ bending --------------------------------- //
+// A thread owns an interior (y,z) column and marches along an x segment keeping the three x-planes of its
+// stencil in registers: per voxel it loads only the 5 points of the incoming plane (centre, y+-1, z+-1) x 3
+// channels instead of 19 x 3; z runs across lanes so every load is a contiguous 12 B/lane stream.
+struct P5 { float c[3], ym[3], yp[3], zm[3], zp[3]; };
+
+__device__ __forceinline__ P5 load_p5(const float* q, int sy)
+{
+    P5 r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        r.c[k] = q[k]; r.ym[k] = q[k - sy]; r.yp[k] = q[k + sy]; r.zm[k] = q[k - 3]; r.zp[k] = q[k + 3];
+    }
+    return r;
+}
+
 __global__ void __launch_bounds__(RED_BLOCK)
-bending_partial_kernel(const float* __restrict__ u, double* __restrict__ part, int X, int Y, int Z, int nblk)
+bending_partial_kernel(const float* __restrict__ u, double* __restrict__ part, int X, int Y, int Z, int xseg, int nseg)
 {
     __shared__ double sh[4];
-    const int b = blockIdx.y;
-    const int64_t sz = 3, sy = (int64_t)Z * 3, sx = (int64_t)Y * Z * 3;
-    const float* p = u + (int64_t)b * X * sx;
-    const int Xi = X - 2, Yi = Y - 2, Zi = Z - 2;
-    const int64_t n_el = (int64_t)Xi * Yi * Zi * 3;
+    const int b = blockIdx.z / nseg, seg = blockIdx.z % nseg;
+    const int Yi = Y - 2, Zi = Z - 2;
+    const int col = blockIdx.x * RED_BLOCK + threadIdx.x;
+    const int sy = Z * 3;
+    const size_t sx = (size_t)Y * Z * 3;
     float acc = 0.f;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_el; e += (int64_t)nblk * blockDim.x) {
-        const int c = (int)(e % 3);
-        const int64_t v = e / 3;
-        const int z = (int)(v % Zi) + 1;
-        const int y = (int)((v / Zi) % Yi) + 1;
-        const int x = (int)(v / ((int64_t)Zi * Yi)) + 1;
-        const float* q = p + x * sx + y * sy + z * sz + c;
-        const float c0 = q[0];
-        const float dxx = q[sx] - 2.f * c0 + q[-sx];
-        const float dyy = q[sy] - 2.f * c0 + q[-sy];
-        const float dzz = q[sz] - 2.f * c0 + q[-sz];
-        const float dxy = (q[sx + sy] - q[sx - sy] - q[-sx + sy] + q[-sx - sy]) * 0.25f;
-        const float dxz = (q[sx + sz] - q[sx - sz] - q[-sx + sz] + q[-sx - sz]) * 0.25f;
-        const float dyz = (q[sy + sz] - q[sy - sz] - q[-sy + sz] + q[-sy - sz]) * 0.25f;
-        acc += dxx * dxx + dyy * dyy + dzz * dzz + 2.f * (dxy * dxy + dxz * dxz + dyz * dyz);
+    if (col < Yi * Zi) {
+        const int y = col / Zi + 1, z = col % Zi + 1;
+        const int x0 = 1 + seg * xseg;
+        const int x1 = (x0 + xseg < X - 1) ? x0 + xseg : X - 1;
+        const float* q = u + (size_t)b * X * sx + (size_t)y * sy + (size_t)z * 3;
+        // need centre, y+-1, z+-1 at x-1 and x+1; plus the four yz diagonals at x
+        P5 pm = load_p5(q + (size_t)(x0 - 1) * sx, sy);
+        P5 pc = load_p5(q + (size_t)x0 * sx, sy);
+        for (int x = x0; x < x1; ++x) {
+            const float* qc = q + (size_t)x * sx;
+            const P5 pp = load_p5(qc + sx, sy);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float c0 = pc.c[k];
+                const float dxx = pp.c[k] - 2.f * c0 + pm.c[k];
+                const float dyy = pc.yp[k] - 2.f * c0 + pc.ym[k];
+                const float dzz = pc.zp[k] - 2.f * c0 + pc.zm[k];
+                const float dxy = (pp.yp[k] - pp.ym[k] - pm.yp[k] + pm.ym[k]) * 0.25f;
+                const float dxz = (pp.zp[k] - pp.zm[k] - pm.zp[k] + pm.zm[k]) * 0.25f;
+                const float dyz = (qc[k + sy + 3] - qc[k + sy - 3] - qc[k - sy + 3] + qc[k - sy - 3]) * 0.25f;
+                acc += dxx * dxx + dyy * dyy + dzz * dzz + 2.f * (dxy * dxy + dxz * dxz + dyz * dyz);
+            }
+            pm = pc;
+            pc = pp;
+        }
     }
     const double r = block_sum((double)acc, sh);
-    if (threadIdx.x == 0) part[(int64_t)b * nblk + blockIdx.x] = r;
+    if (threadIdx.x == 0) part[((size_t)b * nseg + seg) * gridDim.x + blockIdx.x] = r;
 }
 
 inline int red_blocks(int64_t n_el)
@@ -326,21 +382,21 @@ extern "C" int mmr_grad_l2_fwd_f32(const float* flow, float* out, void* ws, int 
 }
 
 namespace {
-constexpr int NCC_TY = 8, NCC_TZ = 32, NCC_XSEG = 64;
-inline void ncc_grid(int X, int Y, int Z, int& gz, int& gy, int& nseg)
+constexpr int NCC_XSEG = 64;
+inline void ncc_geom(int X, int Y, int Z, int& nseg, int& ncolblk)
 {
-    gz = (Z + NCC_TZ - 1) / NCC_TZ;
-    gy = (Y + NCC_TY - 1) / NCC_TY;
     nseg = (X + NCC_XSEG - 1) / NCC_XSEG;
+    ncolblk = (int)(((int64_t)Y * Z + 255) / 256);
 }
 }  // namespace
 
+// workspace = the five zy-box volumes (fp32) followed by the per-block partial sums
 extern "C" int64_t mmr_ncc_ws_bytes(int B, int X, int Y, int Z)
 {
     if (B < 1 || X < 1 || Y < 1 || Z < 1) return MMR_EINVAL;
-    int gz, gy, nseg;
-    ncc_grid(X, Y, Z, gz, gy, nseg);
-    return (int64_t)B * gz * gy * nseg * sizeof(double);
+    int nseg, ncolblk;
+    ncc_geom(X, Y, Z, nseg, ncolblk);
+    return (int64_t)B * 5 * X * Y * Z * sizeof(float) + (int64_t)B * nseg * ncolblk * sizeof(double);
 }
 
 extern "C" int mmr_ncc_fwd_f32(const float* I, const float* J, float* out, void* ws, int B, int X, int Y, int Z,
@@ -348,34 +404,57 @@ extern "C" int mmr_ncc_fwd_f32(const float* I, const float* J, float* out, void*
 {
     if (!I || !J || !out || !ws || B < 1 || X < 1 || Y < 1 || Z < 1) return MMR_EINVAL;
     if (win != 9) return MMR_EUNSUPPORTED;
-    int gz, gy, nseg;
-    ncc_grid(X, Y, Z, gz, gy, nseg);
+    int nseg, ncolblk;
+    ncc_geom(X, Y, Z, nseg, ncolblk);
     if ((int64_t)B * nseg > 65535) return MMR_EINVAL;
-    hipLaunchKernelGGL((ncc_partial_kernel<NCC_TY, NCC_TZ, 9>), dim3(gz, gy, B * nseg), dim3(NCC_TY * NCC_TZ), 0,
-                       as_stream(stream), I, J, (double*)ws, X, Y, Z, NCC_XSEG, nseg, eps);
+    float* zy = (float*)ws;
+    double* part = (double*)((char*)ws + (size_t)B * 5 * X * Y * Z * sizeof(float));
+    const int nzs = (Z + NCC_ZOUT - 1) / NCC_ZOUT, nys = (Y + NCC_ROWS - 1) / NCC_ROWS;
+    const int64_t nw = (int64_t)B * X * nys * nzs;
+    const int64_t nb1 = (nw + 3) / 4;
+    if (nb1 > 0x7fffffff) return MMR_EINVAL;
+    hipLaunchKernelGGL(ncc_zybox_kernel, dim3((unsigned)nb1), dim3(256), 0, as_stream(stream), I, J, zy, B, X, Y, Z, nzs, nys);
     int rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(mean_final_kernel, dim3(B), dim3(RED_BLOCK), 0, as_stream(stream), (const double*)ws, out, B,
-                       (int64_t)gz * gy * nseg, (double)X * Y * Z, -1.0f);
+    hipLaunchKernelGGL(ncc_xbox_kernel, dim3(ncolblk, 1, B * nseg), dim3(256), 0, as_stream(stream), (const float*)zy, part,
+                       X, Y, Z, NCC_XSEG, nseg, eps);
+    rc = check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(mean_final_kernel, dim3(B), dim3(RED_BLOCK), 0, as_stream(stream), (const double*)part, out, B,
+                       (int64_t)nseg * ncolblk, (double)X * Y * Z, -1.0f);
     return check_launch();
 }
+
+namespace {
+constexpr int BEND_XSEG = 32;
+inline void bend_geom(int X, int Y, int Z, int& nseg, int& ncolblk)
+{
+    nseg = (X - 2 + BEND_XSEG - 1) / BEND_XSEG;
+    ncolblk = (int)(((int64_t)(Y - 2) * (Z - 2) + RED_BLOCK - 1) / RED_BLOCK);
+}
+}  // namespace
 
 extern "C" int64_t mmr_bending_ws_bytes(int B, int X, int Y, int Z)
 {
     if (B < 1 || X < 3 || Y < 3 || Z < 3) return MMR_EINVAL;
-    return (int64_t)B * red_blocks((int64_t)(X - 2) * (Y - 2) * (Z - 2) * 3) * sizeof(double);
+    int nseg, ncolblk;
+    bend_geom(X, Y, Z, nseg, ncolblk);
+    return (int64_t)B * nseg * ncolblk * sizeof(double);
 }
 
 extern "C" int mmr_bending_fwd_f32(const float* flow, float* out, void* ws, int B, int X, int Y, int Z, void* stream)
 {
     if (!flow || !out || !ws || B < 1 || X < 3 || Y < 3 || Z < 3) return MMR_EINVAL;
-    const int64_t n = (int64_t)(X - 2) * (Y - 2) * (Z - 2) * 3;
-    const int nblk = red_blocks(n);
-    hipLaunchKernelGGL(bending_partial_kernel, dim3(nblk, B), dim3(RED_BLOCK), 0, as_stream(stream), flow,
-                       (double*)ws, X, Y, Z, nblk);
+    if ((int64_t)Y * Z * 3 > 0x7fffffff) return MMR_EINVAL;
+    int nseg, ncolblk;
+    bend_geom(X, Y, Z, nseg, ncolblk);
+    if ((int64_t)B * nseg > 65535) return MMR_EINVAL;
+    hipLaunchKernelGGL(bending_partial_kernel, dim3(ncolblk, 1, B * nseg), dim3(RED_BLOCK), 0, as_stream(stream), flow,
+                       (double*)ws, X, Y, Z, BEND_XSEG, nseg);
     int rc = check_launch();
     if (rc) return rc;
+    const int64_t n = (int64_t)(X - 2) * (Y - 2) * (Z - 2) * 3;
     hipLaunchKernelGGL(mean_final_kernel, dim3(B), dim3(RED_BLOCK), 0, as_stream(stream), (const double*)ws, out, B,
-                       (int64_t)nblk, (double)n, 1.0f);
+                       (int64_t)nseg * ncolblk, (double)n, 1.0f);
     return check_launch();
 }
