@@ -90,6 +90,10 @@ int mmr_conv3d_k3_fwd(const void* in0, int C0, int up0, const void* in1, int C1,
 int mmr_conv3d_k3_cin2_fwd(const float* src, const float* trg, const float* w_keras, const float* bias,
                            void* out, void* pool_out, int B, int X, int Y, int Z, int Cout,
                            int leaky, float alpha, int out_dtype, void* stream);
+/* Flow head Conv3D(3, 3, 'same') without activation: taps folded into the GEMM N axis (81 of 96 columns).
+ * in: bf16 (MMR_DT_BF16) or fp32 (MMR_DT_F32X3); out fp32 [B,X,Y,Z,3]. */
+int mmr_conv3d_k3_cout3_fwd(const void* in, const float* w_keras, const float* bias, float* out,
+                            int B, int X, int Y, int Z, int Cin, int dtype, void* stream);
 int mmr_maxpool3d2_fwd(const void* in, void* out, int B, int X, int Y, int Z, int C, int dtype, void* stream);
 
 /* ---- losses ------------------------------------------------------------ *

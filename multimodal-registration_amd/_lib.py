@@ -29,6 +29,7 @@ SIGNATURES = {
     "mmr_conv3d_k3_pack": (I, [P, P, I, I, I, I, P]),
     "mmr_conv3d_k3_fwd": (I, [P, I, I, P, I, P, P, P, P, I, I, I, I, I, I, F, I, I, P]),
     "mmr_conv3d_k3_cin2_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, F, I, P]),
+    "mmr_conv3d_k3_cout3_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "mmr_maxpool3d2_fwd": (I, [P, P, I, I, I, I, I, I, P]),
     "mmr_dice_ws_bytes": (c_int64, [I, c_int64, I]),
     "mmr_dice_fwd_f32": (I, [P, P, P, P, P, I, c_int64, I, P]),

@@ -774,6 +774,175 @@ conv3d_cin2_mfma_kernel(const float* __restrict__ src, const float* __restrict__
     }
 }
 
+// ---- flow head (Cout = 3) ---------------------------------------------------------------------------- //
+// Padding 3 output channels to an MFMA tile wastes >= 5x.  Instead the 27 taps are folded into the GEMM N
+// axis: P[v'][tap*3+co] = sum_ci X[v'][ci] * W[tap][ci][co] is a 1x1x1 contraction with N = 81 (of 96) for
+// every voxel v' of a haloed 4x6x10 patch (240 rows = 15 MFMA row tiles exactly), and the 3x3x3 conv is the
+// gather-sum out[v][co] = b[co] + sum_tap P[v + off(tap)][tap*3+co] over the patch, done through LDS.
+// A fragments come straight from global memory (every lane: one halo voxel, 16 B of channels), weights are
+// an LDS image shared by the block's tiles; v_mfma_f32_16x16x32_bf16, fp32 accumulate, fp32 output.
+// X3: fp32 input split into bf16 hi/lo on the fly, three MFMAs per product (fp32-grade).
+constexpr int FH_TX = 2, FH_TY = 4, FH_TZ = 8;
+constexpr int FH_HX = 4, FH_HY = 6, FH_HZ = 10;
+constexpr int FH_ROWS = FH_HX * FH_HY * FH_HZ;  // 240
+constexpr int FH_THREADS = 256;
+
+template <bool X3>
+__global__ void __launch_bounds__(FH_THREADS, 1)
+flow_head_kernel(const char* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+                 float* __restrict__ out, int B, int X, int Y, int Z, int Cin, int ntx, int nty, int ntz, int ntiles)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nkc = Cin / 8;                       // 16-B k-chunks
+    char* sW = smem;                               // [X3 ? 2 : 1][nkc][96][16 B]
+    float* sP = reinterpret_cast<float*>(smem + (X3 ? 2 : 1) * nkc * 96 * 16);  // [240][81]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q16 = lane >> 4;
+    constexpr int ES = X3 ? 4 : 2;
+
+    // weight image: W'[k = ci][n = tap*3+co]
+    for (int i = tid; i < nkc * 96; i += FH_THREADS) {
+        const int n = i % 96, kc = i / 96;
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float f0 = 0.f, f1 = 0.f;
+            if (n < 81) {
+                f0 = w[((size_t)(n / 3) * Cin + kc * 8 + 2 * e) * 3 + n % 3];
+                f1 = w[((size_t)(n / 3) * Cin + kc * 8 + 2 * e + 1) * 3 + n % 3];
+            }
+            const bf16_t h0 = f32_to_bf16(f0), h1 = f32_to_bf16(f1);
+            hi[e] = (unsigned)h0 | ((unsigned)h1 << 16);
+            if constexpr (X3) {
+                const bf16_t l0 = f32_to_bf16(f0 - bf16_to_f32(h0)), l1 = f32_to_bf16(f1 - bf16_to_f32(h1));
+                lo[e] = (unsigned)l0 | ((unsigned)l1 << 16);
+            }
+        }
+        *reinterpret_cast<uint4*>(sW + (size_t)i * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        if constexpr (X3) *reinterpret_cast<uint4*>(sW + (size_t)(nkc * 96 + i) * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+    const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f, b2 = bias ? bias[2] : 0.f;
+    __syncthreads();  // weight image complete
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tzi = t % ntz; t /= ntz;
+        const int tyi = t % nty; t /= nty;
+        const int txi = t % ntx;
+        const int b = t / ntx;
+        const int x0 = txi * FH_TX, y0 = tyi * FH_TY, z0 = tzi * FH_TZ;
+        // this wave's row tiles: mi = wave + 4 j; per lane the global row pointer of its halo voxel
+        const char* rowp[4];
+        bool rowok[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int mi = wave + 4 * j;
+            const int hv = mi * 16 + r16;
+            const int hx = hv / (FH_HY * FH_HZ), hy = (hv / FH_HZ) % FH_HY, hz = hv % FH_HZ;
+            const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
+            rowok[j] = (mi < 15) && gx >= 0 && gx < X && gy >= 0 && gy < Y && gz >= 0 && gz < Z;
+            const size_t vox = rowok[j] ? ((((size_t)b * X + gx) * Y + gy) * Z + gz) : 0;
+            rowp[j] = in + vox * Cin * ES + q16 * (X3 ? 32 : 16);
+        }
+        f32x4 acc[4][6];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int n = 0; n < 6; ++n) acc[j][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nsteps = Cin / 32;
+        // software pipeline: the raw A loads of k-step s+1 are in flight while step s runs on the matrix cores
+        uint4 raw0[4], raw1[4];
+        auto load_raw = [&](int s, uint4* r0, uint4* r1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                r0[j] = make_uint4(0, 0, 0, 0);
+                r1[j] = make_uint4(0, 0, 0, 0);
+                if (rowok[j]) {
+                    r0[j] = *reinterpret_cast<const uint4*>(rowp[j] + (size_t)s * (X3 ? 128 : 64));
+                    if constexpr (X3) r1[j] = *reinterpret_cast<const uint4*>(rowp[j] + (size_t)s * 128 + 16);
+                }
+            }
+        };
+        load_raw(0, raw0, raw1);
+        for (int s = 0; s < nsteps; ++s) {
+            uint4 ah[4], al[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (X3) {
+                    const unsigned u[8] = {raw0[j].x, raw0[j].y, raw0[j].z, raw0[j].w, raw1[j].x, raw1[j].y, raw1[j].z, raw1[j].w};
+                    unsigned hh[4], ll[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float f0 = __uint_as_float(u[2 * e]), f1 = __uint_as_float(u[2 * e + 1]);
+                        const bf16_t h0 = f32_to_bf16(f0), h1 = f32_to_bf16(f1);
+                        const bf16_t l0 = f32_to_bf16(f0 - bf16_to_f32(h0)), l1 = f32_to_bf16(f1 - bf16_to_f32(h1));
+                        hh[e] = (unsigned)h0 | ((unsigned)h1 << 16);
+                        ll[e] = (unsigned)l0 | ((unsigned)l1 << 16);
+                    }
+                    ah[j] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+                    al[j] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+                } else {
+                    ah[j] = raw0[j];
+                }
+            }
+            if (s + 1 < nsteps) load_raw(s + 1, raw0, raw1);
+#pragma unroll
+            for (int n = 0; n < 6; ++n) {
+                const int boff = ((4 * s + q16) * 96 + n * 16 + r16) * 16;
+                const uint4 bh = *reinterpret_cast<const uint4*>(sW + boff);
+                if constexpr (X3) {
+                    const uint4 bl = *reinterpret_cast<const uint4*>(sW + (size_t)nkc * 96 * 16 + boff);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[j]),
+                                                                          __builtin_bit_cast(bf16x8, bh), acc[j][n], 0, 0, 0);
+                        acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[j]),
+                                                                          __builtin_bit_cast(bf16x8, bl), acc[j][n], 0, 0, 0);
+                        acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[j]),
+                                                                          __builtin_bit_cast(bf16x8, bh), acc[j][n], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[j]),
+                                                                          __builtin_bit_cast(bf16x8, bh), acc[j][n], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();  // previous tile's gather finished reading sP (and the weight image is in place)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int mi = wave + 4 * j;
+            if (mi < 15) {
+#pragma unroll
+                for (int n = 0; n < 6; ++n) {
+                    const int col = n * 16 + r16;
+                    if (col < 81) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sP[(mi * 16 + q16 * 4 + r) * 81 + col] = acc[j][n][r];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < FH_TX * FH_TY * FH_TZ * 3) {
+            const int co = tid % 3, v = tid / 3;
+            const int vz = v % FH_TZ, vy = (v / FH_TZ) % FH_TY, vx = v / (FH_TZ * FH_TY);
+            const int gx = x0 + vx, gy = y0 + vy, gz = z0 + vz;
+            if (gx < X && gy < Y && gz < Z) {
+                float a = co == 0 ? b0 : (co == 1 ? b1 : b2);
+#pragma unroll
+                for (int tap = 0; tap < 27; ++tap) {
+                    const int hv = ((vx + tap / 9) * FH_HY + vy + (tap / 3) % 3) * FH_HZ + vz + tap % 3;
+                    a += sP[hv * 81 + tap * 3 + co];
+                }
+                out[((((size_t)b * X + gx) * Y + gy) * Z + gz) * 3 + co] = a;
+            }
+        }
+    }
+}
+
 // ---- MaxPooling3D(2), 16 B per lane -------------------------------------- //
 template <int DT>
 __global__ void __launch_bounds__(256)
@@ -932,6 +1101,38 @@ extern "C" int mmr_conv3d_k3_cin2_fwd(const float* src, const float* trg, const 
                            trg, w_keras, bias, out, B, X, Y, Z, Cout, leaky, alpha, ntx, nty, ntz);
     else
         return MMR_EINVAL;
+    return check_launch();
+}
+
+// Flow head: Conv3D(3, 3, 'same', no activation), in [B,X,Y,Z,Cin] (bf16, or fp32 with MMR_DT_F32X3) -> out fp32.
+extern "C" int mmr_conv3d_k3_cout3_fwd(const void* in, const float* w_keras, const float* bias, float* out, int B,
+                                       int X, int Y, int Z, int Cin, int dtype, void* stream)
+{
+    if (!in || !w_keras || !out || B < 1 || X < 1 || Y < 1 || Z < 1 || Cin < 32 || Cin % 32) return MMR_EINVAL;
+    if (dtype != MMR_DT_BF16 && dtype != MMR_DT_F32X3) return MMR_EUNSUPPORTED;
+    const int npl = dtype == MMR_DT_F32X3 ? 2 : 1;
+    const int lds = npl * (Cin / 8) * 96 * 16 + FH_ROWS * 81 * 4;
+    if (lds > 160 * 1024) return MMR_EUNSUPPORTED;
+    const int ntx = (X + FH_TX - 1) / FH_TX, nty = (Y + FH_TY - 1) / FH_TY, ntz = (Z + FH_TZ - 1) / FH_TZ;
+    const int64_t nt = (int64_t)B * ntx * nty * ntz;
+    if (nt > 0x7fffffff) return MMR_EINVAL;
+    const int grid = nt < 1024 ? (int)nt : 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flow_head_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(flow_head_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
+        attr_set = true;
+    }
+    if (dtype == MMR_DT_F32X3)
+        hipLaunchKernelGGL(flow_head_kernel<true>, dim3(grid), dim3(FH_THREADS), lds, as_stream(stream), (const char*)in,
+                           w_keras, bias, out, B, X, Y, Z, Cin, ntx, nty, ntz, (int)nt);
+    else
+        hipLaunchKernelGGL(flow_head_kernel<false>, dim3(grid), dim3(FH_THREADS), lds, as_stream(stream), (const char*)in,
+                           w_keras, bias, out, B, X, Y, Z, Cin, ntx, nty, ntz, (int)nt);
     return check_launch();
 }
 

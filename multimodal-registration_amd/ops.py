@@ -204,6 +204,21 @@ def conv3d_k3_cin2(src, trg, w_keras, bias, out_dtype, leaky=True, alpha=0.2, x3
     return out
 
 
+def conv3d_k3_cout3(x, w_keras, bias, x3=False):
+    """Flow head: Conv3D(3,3,'same') without activation, taps folded into the GEMM N axis -> fp32 [B,X,Y,Z,3]."""
+    _chk(x, x.dtype, "x")
+    _chk(w_keras, torch.float32, "w_keras")
+    B, X, Y, Z, Cin = x.shape
+    mode = conv_mode(x.dtype, x3)
+    out = torch.empty((B, X, Y, Z, 3), dtype=torch.float32, device=x.device)
+    with _Timed(f"flow_head_{('f32', 'bf16', 'f32x3')[mode]}", (Cin, 3, X, Y, Z), 2.0 * 27 * Cin * 3 * B * X * Y * Z):
+        rc = _lib.load().mmr_conv3d_k3_cout3_fwd(x.data_ptr(), w_keras.data_ptr(),
+                                                 bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                                                 B, X, Y, Z, Cin, mode, _stream())
+    _lib.check(rc, "mmr_conv3d_k3_cout3_fwd")
+    return out
+
+
 def maxpool3d2(x):
     _chk(x, x.dtype, "x")
     B, X, Y, Z, C = x.shape

@@ -72,6 +72,11 @@ class SynthMorphTrainer:
 
         def conv(x, in1=None, up0=False, leaky=True, cout=None):
             nonlocal li
+            if cout == 3 and in1 is None and not up0 and m.x3 and x.shape[-1] % 32 == 0:
+                y = ops.conv3d_k3_cout3(x, w[2 * li], w[2 * li + 1], x3=True)
+                tape.append(("conv", li, x, up0, in1, y, leaky))
+                li += 1
+                return y
             y = ops.conv3d_k3(x, m._packed[li], w[2 * li + 1], m.plan[li][2] if cout is None else cout, in1=in1,
                               up0=up0, leaky=leaky, out_f32=True, x3=m.x3)
             tape.append(("conv", li, x, up0, in1, y, leaky))

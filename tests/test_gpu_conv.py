@@ -95,3 +95,27 @@ def test_maxpool(dev, dtype):
     x = torch.from_numpy(rng.standard_normal((2, 6, 8, 10, 64)).astype(np.float32)).to(dev).to(dtype)
     got = mmr.ops.maxpool3d2(x).float().cpu().numpy()
     assert np.array_equal(got, O.maxpool2(x.float().cpu().numpy()))
+
+
+@pytest.mark.parametrize("shape,Cin,mode", [((5, 9, 7), 64, "bf16"), ((8, 8, 16), 256, "bf16"), ((2, 4, 8), 32, "fp32x3"),
+                                            ((6, 7, 19), 64, "fp32x3"), ((4, 4, 8), 128, "fp32x3")])
+def test_flow_head_folded_taps(dev, shape, Cin, mode):
+    """Flow head with the taps folded into the GEMM N axis vs the C oracle."""
+    import mmr
+    from oracle.cbind import conv3d_same
+    from oracle.net_np import bf16_round
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((2,) + shape + (Cin,)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, Cin, 3)) * 0.05).astype(np.float32)
+    bias = rng.standard_normal(3).astype(np.float32)
+    if mode == "bf16":
+        x, wq = bf16_round(x), bf16_round(w)
+    else:
+        wq = w
+    ref = conv3d_same(x, wq, bias, leaky=False)
+    xt = torch.from_numpy(x).to(dev)
+    if mode == "bf16":
+        xt = xt.to(torch.bfloat16)
+    got = mmr.ops.conv3d_k3_cout3(xt, torch.from_numpy(w).to(dev), torch.from_numpy(bias).to(dev), x3=(mode == "fp32x3"))
+    assert got.dtype == torch.float32 and tuple(got.shape) == (2,) + shape + (3,)
+    assert _scale_err(got.cpu().numpy(), ref) < (1e-5 if mode == "bf16" else 1e-4)
