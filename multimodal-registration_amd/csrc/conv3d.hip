@@ -104,22 +104,28 @@ template <int DT, int WM, int WN, int MT, int NT, int VAR>
 __global__ void __launch_bounds__(CONV_THREADS, 2)
 conv3d_k3_kernel(const ConvParams p)
 {
+    // output tile = TXT x 8 x 8 voxels (TXT = 4: 256 rows, TXT = 8: 512 rows for the narrow-N configurations,
+    // which doubles the MFMA work between two barriers and halves the fragment reads per MFMA)
+    constexpr int TXT = WM * MT * 32 / (TY * TZ);
+    constexpr int HXT = TXT + 2;
+    constexpr int HROWS_T = HXT * HY * HZ;
+    constexpr int A_BYTES_T = HROWS_T * ROWB;
     constexpr bool FRAG_DB = VAR & 1, PREF_A = (VAR >> 1) & 1;
     // VAR bit 5: v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (bf16 only): same bytes per flop, the chip holds
     // a higher clock on this shape (MI355X_MICROARCH.md, DVFS give-back item 7)
     constexpr bool M16 = ((VAR >> 5) & 1) && (DT == MMR_DT_BF16);
     static_assert(WM * WN == 8, "8 waves");
-    static_assert(WM * MT * 32 == TX * TY * TZ, "M tile");
+    static_assert(TXT == 4 || TXT == 8, "M tile");
     constexpr int BN = WN * NT * 32;
     constexpr int ES = Elt<DT>::size;
     constexpr int KC = Elt<DT>::kc;
     constexpr int B_BYTES = BN * 128;
     constexpr int B_ITERS = B_BYTES / (CONV_THREADS * 16);
-    constexpr int A_ITERS = ((DT == MMR_DT_F32X3 ? HROWS * 4 : HROWS * 8) + CONV_THREADS - 1) / CONV_THREADS;  // 10 (5 for fp32x3)
+    constexpr int A_ITERS = ((DT == MMR_DT_F32X3 ? HROWS_T * 4 : HROWS_T * 8) + CONV_THREADS - 1) / CONV_THREADS;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
-    char* sB = smem + A_BYTES;
+    char* sB = smem + A_BYTES_T;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -132,7 +138,7 @@ conv3d_k3_kernel(const ConvParams p)
     const int tyi = bid % p.nty; bid /= p.nty;
     const int txi = bid % p.ntx;
     const int b = bid / p.ntx;
-    const int x0 = txi * TX, y0 = tyi * TY, z0 = tzi * TZ;
+    const int x0 = txi * TXT, y0 = tyi * TY, z0 = tzi * TZ;
     const int ntile = blockIdx.y;
 
     const int pv = row_perm(lane & 31);
@@ -180,7 +186,7 @@ conv3d_k3_kernel(const ConvParams p)
     // global load of item `it` of this thread's share of the haloed tile of channel slice s.
     // bf16 / fp32: item = (row, 16-B chunk); fp32x3: item = (row, 8-channel group) = 32 B of fp32.
     constexpr bool X3 = (DT == MMR_DT_F32X3);
-    constexpr int A_ITEMS = X3 ? HROWS * 4 : HROWS * 8;
+    constexpr int A_ITEMS = X3 ? HROWS_T * 4 : HROWS_T * 8;
     struct AItem { uint4 a, b; };
     auto load_a = [&](int s, int it) -> AItem {
         const int i = tid + it * CONV_THREADS;
@@ -483,7 +489,9 @@ template <int DT, int WM, int WN, int MT, int NT, int VAR>
 int launch_conv(const ConvParams& p, int ntiles_n, hipStream_t st)
 {
     constexpr int BN = WN * NT * 32;
-    constexpr int LDS = A_BYTES + 2 * BN * 128;
+    constexpr int TXT = WM * MT * 32 / (TY * TZ);
+    constexpr int LDS = (TXT + 2) * HY * HZ * ROWB + 2 * BN * 128;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     auto kern = conv3d_k3_kernel<DT, WM, WN, MT, NT, VAR>;
     if (!attr_set) {
@@ -492,9 +500,11 @@ int launch_conv(const ConvParams& p, int ntiles_n, hipStream_t st)
         if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
         attr_set = true;
     }
-    const int64_t nblk = (int64_t)p.B * p.ntx * p.nty * p.ntz;
+    ConvParams q = p;
+    q.ntx = (p.X + TXT - 1) / TXT;
+    const int64_t nblk = (int64_t)q.B * q.ntx * q.nty * q.ntz;
     if (nblk > 0x7fffffff) return MMR_EINVAL;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, ntiles_n), dim3(CONV_THREADS), LDS, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, ntiles_n), dim3(CONV_THREADS), LDS, st, q);
     return check_launch();
 }
 
@@ -510,6 +520,11 @@ int dispatch_conv(const ConvParams& p, hipStream_t st)
         const char* e = getenv("MMR_CONV_VARIANT");
         var = e ? atoi(e) : 32;
     }
+    static int tile8 = -1;
+    if (tile8 < 0) {
+        const char* e = getenv("MMR_CONV_TILE");
+        tile8 = (e && atoi(e) == 4) ? 0 : 1;
+    }
     switch (BN) {
         case 256:
             if (var == 0) return launch_conv<DT, 2, 4, 4, 2, 0>(p, nt, st);
@@ -520,9 +535,16 @@ int dispatch_conv(const ConvParams& p, hipStream_t st)
             if (var == 8) return launch_conv<DT, 2, 4, 4, 2, 8>(p, nt, st);
             if (var == 12) return launch_conv<DT, 2, 4, 4, 2, 12>(p, nt, st);
             return launch_conv<DT, 2, 4, 4, 2, 32>(p, nt, st);
-        case 128: return launch_conv<DT, 4, 2, 2, 2, 3>(p, nt, st);
-        case 64: return launch_conv<DT, 8, 1, 1, 2, 3>(p, nt, st);
-        default: return launch_conv<DT, 8, 1, 1, 1, 3>(p, nt, st);
+        // narrow N: 8x8x8-voxel tiles (MT doubled); MMR_CONV_TILE=4 restores the 4x8x8 tiles for A/B runs
+        case 128:
+            if (tile8) return launch_conv<DT, 4, 2, 4, 2, 0>(p, nt, st);
+            return launch_conv<DT, 4, 2, 2, 2, 3>(p, nt, st);
+        case 64:
+            if (tile8) return launch_conv<DT, 8, 1, 2, 2, 0>(p, nt, st);
+            return launch_conv<DT, 8, 1, 1, 2, 3>(p, nt, st);
+        default:
+            if (tile8) return launch_conv<DT, 8, 1, 2, 1, 0>(p, nt, st);
+            return launch_conv<DT, 8, 1, 1, 1, 3>(p, nt, st);
     }
 }
 
