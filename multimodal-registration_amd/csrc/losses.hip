@@ -65,25 +65,32 @@ dice_partial_kernel(const float* __restrict__ yt, const float* __restrict__ yp, 
     }
 }
 
+__global__ void __launch_bounds__(64)
+dice_sum_kernel(const double* __restrict__ part, float* __restrict__ top_bot, int L, int nblk)
+{
+    const int i = blockIdx.x;  // b * L + l: one wave, ordered strided sums + wave reduction
+    const int b = i / L, l = i % L;
+    double st = 0.0, sb = 0.0;
+    for (int k = threadIdx.x; k < nblk; k += 64) {
+        const double* o = part + (((int64_t)b * nblk + k) * L + l) * 2;
+        st += o[0];
+        sb += o[1];
+    }
+    st = wave_sum(st);
+    sb = wave_sum(sb);
+    if (threadIdx.x == 0) {
+        top_bot[i * 2] = (float)(2.0 * st);
+        top_bot[i * 2 + 1] = (float)sb;
+    }
+}
+
 __global__ void __launch_bounds__(RED_BLOCK)
-dice_final_kernel(const double* __restrict__ part, float* __restrict__ loss, float* __restrict__ top_bot,
-                  int B, int L, int nblk)
+dice_final_kernel(const float* __restrict__ top_bot, float* __restrict__ loss, int B, int L)
 {
     __shared__ double sh[4];
     double acc = 0.0;
     for (int i = threadIdx.x; i < B * L; i += blockDim.x) {
-        const int b = i / L, l = i % L;
-        double st = 0.0, sb = 0.0;
-        for (int k = 0; k < nblk; ++k) {
-            const double* o = part + (((int64_t)b * nblk + k) * L + l) * 2;
-            st += o[0];
-            sb += o[1];
-        }
-        const float ft = (float)(2.0 * st), fb = (float)sb;
-        if (top_bot) {
-            top_bot[i * 2] = ft;
-            top_bot[i * 2 + 1] = fb;
-        }
+        const float ft = top_bot[i * 2], fb = top_bot[i * 2 + 1];
         acc += (fb != 0.f) ? (double)(ft / fb) : 0.0;  // divide_no_nan
     }
     const double s = block_sum(acc, sh);
@@ -119,17 +126,22 @@ grad_l2_partial_kernel(const float* __restrict__ f, double* __restrict__ part, i
     }
 }
 
-__global__ void grad_l2_final_kernel(const double* __restrict__ part, float* __restrict__ out, int B, int X, int Y,
-                                     int Z, int C, int nblk, float loss_mult)
+// one wave per batch item: ordered strided sums of the per-block partials + wave reduction
+__global__ void __launch_bounds__(64)
+grad_l2_final_kernel(const double* __restrict__ part, float* __restrict__ out, int B, int X, int Y,
+                     int Z, int C, int nblk, float loss_mult)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    double s[3] = {0, 0, 0};
-    for (int k = 0; k < nblk; ++k)
-        for (int d = 0; d < 3; ++d) s[d] += part[((int64_t)b * nblk + k) * 3 + d];
-    const double nx = (double)(X - 1) * Y * Z * C, ny = (double)X * (Y - 1) * Z * C, nz = (double)X * Y * (Z - 1) * C;
-    const double m = (s[0] / nx + s[1] / ny + s[2] / nz) / 3.0;
-    out[b] = (float)(m * (double)loss_mult);
+    const int b = blockIdx.x;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int k = threadIdx.x; k < nblk; k += 64) {
+        const double* o = part + ((int64_t)b * nblk + k) * 3;
+        s0 += o[0]; s1 += o[1]; s2 += o[2];
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (threadIdx.x == 0) {
+        const double nx = (double)(X - 1) * Y * Z * C, ny = (double)X * (Y - 1) * Z * C, nz = (double)X * Y * (Z - 1) * C;
+        out[b] = (float)((s0 / nx + s1 / ny + s2 / nz) / 3.0 * (double)loss_mult);
+    }
 }
 
 // ------------------------------ local NCC ------------------------------- //
@@ -344,7 +356,7 @@ using namespace mmr;
 extern "C" int64_t mmr_dice_ws_bytes(int B, int64_t nvox, int L)
 {
     if (B < 1 || nvox < 1 || L < 1) return MMR_EINVAL;
-    return (int64_t)B * red_blocks(nvox * L) * L * 2 * sizeof(double);
+    return (int64_t)B * red_blocks(nvox * L) * L * 2 * sizeof(double) + (int64_t)B * L * 2 * sizeof(float);
 }
 
 extern "C" int mmr_dice_fwd_f32(const float* y_true, const float* y_pred, float* loss_out, float* top_bot, void* ws,
@@ -356,8 +368,11 @@ extern "C" int mmr_dice_fwd_f32(const float* y_true, const float* y_pred, float*
                        as_stream(stream), y_true, y_pred, (double*)ws, nvox, L, nblk);
     int rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(dice_final_kernel, dim3(1), dim3(RED_BLOCK), 0, as_stream(stream), (const double*)ws, loss_out,
-                       top_bot, B, L, nblk);
+    float* tb = top_bot ? top_bot : (float*)((char*)ws + (size_t)B * nblk * L * 2 * sizeof(double));
+    hipLaunchKernelGGL(dice_sum_kernel, dim3(B * L), dim3(64), 0, as_stream(stream), (const double*)ws, tb, L, nblk);
+    rc = check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(dice_final_kernel, dim3(1), dim3(RED_BLOCK), 0, as_stream(stream), (const float*)tb, loss_out, B, L);
     return check_launch();
 }
 
@@ -376,7 +391,7 @@ extern "C" int mmr_grad_l2_fwd_f32(const float* flow, float* out, void* ws, int 
                        (double*)ws, X, Y, Z, C, nblk);
     int rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(grad_l2_final_kernel, dim3((B + 63) / 64), dim3(64), 0, as_stream(stream), (const double*)ws,
+    hipLaunchKernelGGL(grad_l2_final_kernel, dim3(B), dim3(64), 0, as_stream(stream), (const double*)ws,
                        out, B, X, Y, Z, C, nblk, loss_mult);
     return check_launch();
 }

@@ -116,24 +116,35 @@ dice_labels_partial_kernel(const uint8_t* __restrict__ lab1, const uint8_t* __re
     }
 }
 
-// top_bot[b][l] = (2*sum tp, sum t+p); loss[0] = -mean divide_no_nan(top, bot)
+// top_bot[b][l] = (2*sum tp, sum t+p); loss[0] = -mean divide_no_nan(top, bot).
+// One wave per (b,l): ordered strided partial sums + wave reduction (was a serial 1024-long loop per thread).
+__global__ void __launch_bounds__(64)
+dice_labels_sum_kernel(const double* __restrict__ part, float* __restrict__ top_bot, int L, int nblk)
+{
+    const int i = blockIdx.x;  // b * L + l
+    const int b = i / L, l = i % L;
+    double st = 0.0, sb = 0.0;
+    for (int k = threadIdx.x; k < nblk; k += 64) {
+        const double* o = part + (((int64_t)b * nblk + k) * L + l) * 2;
+        st += o[0];
+        sb += o[1];
+    }
+    st = wave_sum(st);
+    sb = wave_sum(sb);
+    if (threadIdx.x == 0) {
+        top_bot[i * 2] = (float)(2.0 * st);
+        top_bot[i * 2 + 1] = (float)sb;
+    }
+}
+
 __global__ void __launch_bounds__(TB)
-dice_labels_final_kernel(const double* __restrict__ part, float* __restrict__ loss, float* __restrict__ top_bot,
-                         int B, int L, int nblk, int zeropad)
+dice_labels_final_kernel(const float* __restrict__ top_bot, float* __restrict__ loss, int B, int L, int zeropad)
 {
     __shared__ double sh[4];
     double acc = 0.0;
     for (int i = threadIdx.x; i < B * L; i += blockDim.x) {
         const int b = i / L, l = i % L;
-        double st = 0.0, sb = 0.0;
-        for (int k = 0; k < nblk; ++k) {
-            const double* o = part + (((int64_t)b * nblk + k) * L + l) * 2;
-            st += o[0];
-            sb += o[1];
-        }
-        const float ft = (float)(2.0 * st), fb = (float)sb;
-        top_bot[i * 2] = ft;
-        top_bot[i * 2 + 1] = fb;
+        const float ft = top_bot[i * 2], fb = top_bot[i * 2 + 1];
         const bool counted = !zeropad || (b == 0 && l >= 1);  // zeropad: labels 1..L-1 of batch item 0 only
         if (counted) acc += (fb != 0.f) ? (double)(ft / fb) : 0.0;
     }
@@ -1338,8 +1349,12 @@ static int dice_labels_fwd_impl(const uint8_t* lab1, const uint8_t* lab2, const 
                        as_stream(stream), lab1, lab2, flow, (double*)ws, X, Y, Z, L, nblk, zeropad);
     int rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(dice_labels_final_kernel, dim3(1), dim3(TB), 0, as_stream(stream), (const double*)ws, loss,
-                       top_bot, B, L, nblk, zeropad);
+    hipLaunchKernelGGL(dice_labels_sum_kernel, dim3(B * L), dim3(64), 0, as_stream(stream), (const double*)ws, top_bot, L,
+                       nblk);
+    rc = check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(dice_labels_final_kernel, dim3(1), dim3(TB), 0, as_stream(stream), (const float*)top_bot, loss, B,
+                       L, zeropad);
     return check_launch();
 }
 

@@ -46,7 +46,7 @@ def draw_perlin(out_shape, scales, min_std=0, max_std=1, modulate=True, rng=None
     rng = np.random.default_rng(seed) if rng is None else rng
     rec = {"stds": [], "noise": []}
     C = int(np.prod(feat))
-    out = torch.zeros((1,) + spatial + (C,), dtype=torch.float32, device=device)
+    out = None
     for i, scale in enumerate(scales):
         coarse_sp = tuple(int(math.ceil(s / scale)) for s in spatial)
         coarse = coarse_sp + ((int(math.ceil(feat[0] / scale)), feat[1]) if four_d else feat)
@@ -70,7 +70,9 @@ def draw_perlin(out_shape, scales, min_std=0, max_std=1, modulate=True, rng=None
             gc = w0 * gc[:, :, :, l0] + (1 - w0) * gc[:, :, :, l1]
             g = to_device(gc.astype(np.float32), device=device)
         g = g.reshape((1,) + coarse_sp + (C,)).contiguous()
-        if scale == 1:
+        if out is None:  # first scale: the resize writes std * upsampled noise directly (no zero-fill, no axpy pass)
+            out = ops.resize_trilinear(g, spatial, mul=std) if (scale != 1 or coarse_sp != spatial) else g * std
+        elif scale == 1:
             ops.axpy_(out, g, std)
         else:
             ops.axpy_(out, ops.resize_trilinear(g, spatial), std)
