@@ -90,14 +90,15 @@ class VxmDense:
                             svf_resolution=svf_resolution, int_resolution=int_resolution, fill_value=fill_value)
         self.plan = _plan(enc, dec)
         self._kc = ops.conv_kc(self.dtype)
-        for name_, cin, cout in self.plan[1:]:
-            if any(c % self._kc for c in cin):
-                raise NotImplementedError(
-                    f"layer {name_}: channel counts {cin} must be multiples of {self._kc} for "
-                    f"{compute_dtype} (the reference configs use 64 and 256)")
-        c0 = self.plan[0][2]
-        if not ((c0 <= 256 and 256 % c0 == 0) or c0 % 256 == 0):
-            raise NotImplementedError("first layer width must divide 256 or be a multiple of 256")
+        # Physical widths: every feature width is rounded up to the MFMA channel-slice size (64 bf16 / 32 fp32)
+        # with zero weights and zero bias, so padded channels carry LeakyReLU(0) = 0 and results are unchanged
+        # (e.g. voxelmorph's default [16,32,32,32] / [32,...,16,16] features run as 32/64-wide layers).
+        ph = lambda c: -(-c // self._kc) * self._kc
+        self.pplan = [(n, tuple(c if n == self.plan[0][0] else ph(c) for c in cin), cout if n == "flow" else ph(cout))
+                      for n, cin, cout in self.plan]
+        c0 = self.pplan[0][2]
+        if self.dtype == torch.float32 and not self.x3 and not ((c0 <= 256 and 256 % c0 == 0) or c0 % 256 == 0):
+            raise NotImplementedError("exact-fp32 first layer: padded width must divide 256 or be a multiple of 256")
         self._init_weights(seed)
         self.references = types.SimpleNamespace(
             unet_model=None, source=None, target=None, svf=None, preint_flow=None, postint_flow=None,
@@ -105,12 +106,22 @@ class VxmDense:
         self._losses = []
 
     # ------------------------------------------------------------------ weights
+    def _logical_index(self, li):
+        """(input-channel index into the physical kernel, logical cout) of layer li."""
+        _, cin, cout = self.plan[li]
+        _, pcin, _ = self.pplan[li]
+        idx, off = [], 0
+        for c, pc in zip(cin, pcin):
+            idx += list(range(off, off + c))
+            off += pc
+        return torch.tensor(idx, device=self.device, dtype=torch.long), cout
+
     def _init_weights(self, seed):
-        """All 22 arrays live in ONE flat fp32 buffer (views in Keras order) so that Adam and the
-        data-parallel all-reduce are a single launch / a single collective."""
+        """All 22 arrays live in ONE flat fp32 buffer (views in Keras order, physical = padded widths) so that
+        Adam and the data-parallel all-reduce are a single launch / a single collective."""
         g = torch.Generator(device="cpu").manual_seed(int(seed))
         shapes = []
-        for name_, cin, cout in self.plan:
+        for name_, cin, cout in self.pplan:
             shapes += [(3, 3, 3, sum(cin), cout), (cout,)]
         sizes = [int(np.prod(s)) for s in shapes]
         self._flat = torch.zeros(sum(sizes), dtype=torch.float32, device=self.device)
@@ -118,6 +129,7 @@ class VxmDense:
         for shp, n in zip(shapes, sizes):
             self._w.append(self._flat[off:off + n].view(shp))
             off += n
+        init = []
         for i, (name_, cin, cout) in enumerate(self.plan):
             ci = sum(cin)
             if name_ == "flow":
@@ -126,23 +138,36 @@ class VxmDense:
                 std = math.sqrt(2.0 / (27 * ci)) / 0.87962566103423978
                 w = torch.empty((3, 3, 3, ci, cout))
                 torch.nn.init.trunc_normal_(w, 0.0, std, -2 * std, 2 * std, generator=g)
-            self._w[2 * i].copy_(w)
-        self._packed = None
+            init += [w, torch.zeros(cout)]
+        self.set_weights(init)
 
     def get_weights(self):
-        return [w.detach().cpu().numpy() for w in self._w]
+        """22 arrays at the LOGICAL widths, Keras order (what ``set_weights`` of a rebuilt model accepts)."""
+        out = []
+        for li in range(len(self.plan)):
+            idx, cout = self._logical_index(li)
+            out.append(self._w[2 * li].index_select(3, idx)[..., :cout].detach().cpu().numpy())
+            out.append(self._w[2 * li + 1][:cout].detach().cpu().numpy())
+        return out
 
     def set_weights(self, weights):
         if len(weights) != len(self._w):
             raise ValueError(f"expected {len(self._w)} arrays, got {len(weights)}")
         staged = []
-        for cur, w in zip(self._w, weights):
-            w = to_device(np.asarray(w) if not isinstance(w, torch.Tensor) else w, device=self.device)
-            if tuple(w.shape) != tuple(cur.shape):
-                raise ValueError(f"weight shape {tuple(w.shape)} does not match {tuple(cur.shape)}")
-            staged.append(w)
-        for cur, w in zip(self._w, staged):
-            cur.copy_(w)
+        for li, (name_, cin, cout) in enumerate(self.plan):
+            k = to_device(weights[2 * li] if isinstance(weights[2 * li], torch.Tensor) else np.asarray(weights[2 * li]),
+                          device=self.device)
+            b = to_device(weights[2 * li + 1] if isinstance(weights[2 * li + 1], torch.Tensor)
+                          else np.asarray(weights[2 * li + 1]), device=self.device)
+            if tuple(k.shape) != (3, 3, 3, sum(cin), cout) or tuple(b.shape) != (cout,):
+                raise ValueError(f"weight shapes {tuple(k.shape)}, {tuple(b.shape)} do not match layer {name_} "
+                                 f"{(3, 3, 3, sum(cin), cout)}, {(cout,)}")
+            staged.append((k, b))
+        self._flat.zero_()
+        for li, (k, b) in enumerate(staged):
+            idx, cout = self._logical_index(li)
+            self._w[2 * li][..., :cout].index_copy_(3, idx, k)
+            self._w[2 * li + 1][:cout].copy_(b)
         self._packed = None
 
     def invalidate_packed(self):
@@ -151,17 +176,17 @@ class VxmDense:
 
     def _pack(self):
         if self._packed is None:
-            self._packed = [None] + [ops.pack_conv_weights(self._w[2 * i], self.dtype, x3=self.x3)
+            self._packed = [None] + [ops.pack_conv_weights(self._w[2 * i].contiguous(), self.dtype, x3=self.x3)
                                      for i in range(1, len(self.plan))]
         return self._packed
 
     def count_params(self):
-        return sum(int(w.numel()) for w in self._w)
+        return sum(27 * sum(cin) * cout + cout for _, cin, cout in self.plan)
 
     def summary(self):
         print(f'Model: "{self.name}"  inshape={self.inshape}  compute_dtype={self.dtype}')
         for i, (n, cin, cout) in enumerate(self.plan):
-            print(f"  {n:28s} Conv3D 3x3x3 {sum(cin):4d} -> {cout:4d}   params {self._w[2*i].numel() + cout}")
+            print(f"  {n:28s} Conv3D 3x3x3 {sum(cin):4d} -> {cout:4d}   params {27 * sum(cin) * cout + cout}")
         print(f"Total params: {self.count_params():,}")
 
     # ------------------------------------------------------------------ save / load
@@ -170,7 +195,7 @@ class VxmDense:
 
     def save(self, path):
         from safetensors.torch import save_file
-        tensors = {f"w{i:02d}": w.detach().cpu().contiguous() for i, w in enumerate(self._w)}
+        tensors = {f"w{i:02d}": torch.from_numpy(np.ascontiguousarray(w)) for i, w in enumerate(self.get_weights())}
         save_file(tensors, path, metadata={"config": json.dumps(self._config), "format": "mmr-vxmdense-1"})
 
     def load_weights(self, path):
@@ -190,7 +215,7 @@ class VxmDense:
     # ------------------------------------------------------------------ forward
     def _conv(self, li, x, **kw):
         """Layer li of the plan on the MFMA kernel."""
-        return ops.conv3d_k3(x, self._packed[li], self._w[2 * li + 1], self.plan[li][2], x3=self.x3, **kw)
+        return ops.conv3d_k3(x, self._packed[li], self._w[2 * li + 1], self.pplan[li][2], x3=self.x3, **kw)
 
     def unet(self, src, trg):
         """[B,X,Y,Z,1] x2 (f32) -> flow [B,X,Y,Z,3] f32."""

@@ -77,7 +77,7 @@ class SynthMorphTrainer:
                 tape.append(("conv", li, x, up0, in1, y, leaky))
                 li += 1
                 return y
-            y = ops.conv3d_k3(x, m._packed[li], w[2 * li + 1], m.plan[li][2] if cout is None else cout, in1=in1,
+            y = ops.conv3d_k3(x, m._packed[li], w[2 * li + 1], m.pplan[li][2] if cout is None else cout, in1=in1,
                               up0=up0, leaky=leaky, out_f32=True, x3=m.x3)
             tape.append(("conv", li, x, up0, in1, y, leaky))
             li += 1

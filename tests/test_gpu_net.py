@@ -71,3 +71,30 @@ def test_transform_network(dev):
         full = O.rescale_dense_transform(trf[0], 2)
         ref = O.transform(vol[0].astype(np.float32), full, method)[None]
         np.testing.assert_allclose(got, ref, atol=2e-6)
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 3e-2)])
+def test_default_voxelmorph_features_via_channel_padding(dev, dtype, tol):
+    """voxelmorph's default widths (16/32) are not multiples of the MFMA slice: they run zero-padded and must
+    give the same result as the oracle at the logical widths; get/set_weights exchange the logical arrays."""
+    import mmr
+    from oracle import net_np
+    shape = (16, 16, 16)
+    enc, dec = [16, 32, 32, 32], [32, 32, 32, 32, 32, 16, 16]
+    rng = np.random.default_rng(3)
+    mov, fix = _pair(rng, shape)
+    weights = net_np.init_weights(enc, dec, seed=2, flow_std=3e-2)
+    for i in range(1, len(weights), 2):
+        weights[i] = (rng.standard_normal(weights[i].shape) * 0.05).astype(np.float32)
+    model = mmr.networks.VxmDense(shape, int_steps=7, int_resolution=2, svf_resolution=1, compute_dtype=dtype)  # defaults
+    assert [p[2] for p in model.plan] == enc + dec + [3]
+    model.set_weights(weights)
+    for a, b in zip(model.get_weights(), weights):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    moved, preint = model.predict([mov, fix])
+    quant = net_np.bf16_round if dtype == "bf16" else None
+    ref = net_np.vxm_dense_forward(mov, fix, weights, enc, dec, 7, 2, 1, quant=quant)
+    assert preint.shape == ref["preint_flow"].shape == (1, 8, 8, 8, 3)
+    for got, exp in ((preint, ref["preint_flow"]), (moved, ref["moved"])):
+        assert np.abs(got - exp).max() / np.abs(exp).max() < tol
+    assert model.count_params() == sum(w.size for w in weights)
