@@ -113,7 +113,7 @@ conv3d_k3_kernel(const ConvParams p)
     constexpr bool FRAG_DB = VAR & 1, PREF_A = (VAR >> 1) & 1;
     // VAR bit 5: v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (bf16 only): same bytes per flop, the chip holds
     // a higher clock on this shape (MI355X_MICROARCH.md, DVFS give-back item 7)
-    constexpr bool M16 = ((VAR >> 5) & 1) && (DT == MMR_DT_BF16);
+    constexpr bool M16 = ((VAR >> 5) & 1) && (DT == MMR_DT_BF16 || DT == MMR_DT_F32X3);
     static_assert(WM * WN == 8, "8 waves");
     static_assert(TXT == 4 || TXT == 8, "M tile");
     constexpr int BN = WN * NT * 32;
@@ -275,21 +275,47 @@ conv3d_k3_kernel(const ConvParams p)
         const char* bB = sB + cur * B_BYTES;
         if constexpr (M16) {
             const int sw16 = swz((r16 >> 3) + dy, (r16 & 7) + dz);
+            if constexpr (DT == MMR_DT_F32X3) {
+                // one 32-channel k-step per tap: chunks 0..3 = hi, 4..7 = lo
+                uint4 ah16[2 * MT], al16[2 * MT], bh16[2 * NT], bl16[2 * NT];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                uint4 fa16[2 * MT], fb16[2 * NT];
+                for (int mi = 0; mi < 2 * MT; ++mi) {
+                    ah16[mi] = *reinterpret_cast<const uint4*>(bA + a16_off[mi] + ((q16 ^ sw16) << 4));
+                    al16[mi] = *reinterpret_cast<const uint4*>(bA + a16_off[mi] + (((4 + q16) ^ sw16) << 4));
+                }
+#pragma unroll
+                for (int ni = 0; ni < 2 * NT; ++ni) {
+                    bh16[ni] = *reinterpret_cast<const uint4*>(bB + b16_off[ni]);
+                    bl16[ni] = *reinterpret_cast<const uint4*>(bB + b16_off[ni] + 4 * BN * 16);
+                }
 #pragma unroll
                 for (int mi = 0; mi < 2 * MT; ++mi)
-                    fa16[mi] = *reinterpret_cast<const uint4*>(bA + a16_off[mi] + (((4 * ks + q16) ^ sw16) << 4));
 #pragma unroll
-                for (int ni = 0; ni < 2 * NT; ++ni)
-                    fb16[ni] = *reinterpret_cast<const uint4*>(bB + b16_off[ni] + ks * 4 * BN * 16);
+                    for (int ni = 0; ni < 2 * NT; ++ni) {
+                        acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, al16[mi]), __builtin_bit_cast(bf16x8, bh16[ni]), acc16[mi][ni], 0, 0, 0);
+                        acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, ah16[mi]), __builtin_bit_cast(bf16x8, bl16[ni]), acc16[mi][ni], 0, 0, 0);
+                        acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, ah16[mi]), __builtin_bit_cast(bf16x8, bh16[ni]), acc16[mi][ni], 0, 0, 0);
+                    }
+            } else {
 #pragma unroll
-                for (int mi = 0; mi < 2 * MT; ++mi)
+                for (int ks = 0; ks < 2; ++ks) {
+                    uint4 fa16[2 * MT], fb16[2 * NT];
+#pragma unroll
+                    for (int mi = 0; mi < 2 * MT; ++mi)
+                        fa16[mi] = *reinterpret_cast<const uint4*>(bA + a16_off[mi] + (((4 * ks + q16) ^ sw16) << 4));
 #pragma unroll
                     for (int ni = 0; ni < 2 * NT; ++ni)
-                        acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, fa16[mi]), __builtin_bit_cast(bf16x8, fb16[ni]), acc16[mi][ni], 0, 0, 0);
+                        fb16[ni] = *reinterpret_cast<const uint4*>(bB + b16_off[ni] + ks * 4 * BN * 16);
+#pragma unroll
+                    for (int mi = 0; mi < 2 * MT; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2 * NT; ++ni)
+                            acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, fa16[mi]), __builtin_bit_cast(bf16x8, fb16[ni]), acc16[mi][ni], 0, 0, 0);
+                }
             }
         } else if constexpr (X3) {
             // chunks 0..3 = hi of channels 8c..8c+7, chunks 4..7 = lo; two 16-channel k-steps per tap
@@ -537,9 +563,11 @@ int dispatch_conv(const ConvParams& p, hipStream_t st)
             return launch_conv<DT, 2, 4, 4, 2, 32>(p, nt, st);
         // narrow N: 8x8x8-voxel tiles (MT doubled); MMR_CONV_TILE=4 restores the 4x8x8 tiles for A/B runs
         case 128:
+            if (tile8 && var == 32) return launch_conv<DT, 4, 2, 4, 2, 32>(p, nt, st);
             if (tile8) return launch_conv<DT, 4, 2, 4, 2, 0>(p, nt, st);
             return launch_conv<DT, 4, 2, 2, 2, 3>(p, nt, st);
         case 64:
+            if (tile8 && var == 32) return launch_conv<DT, 8, 1, 2, 2, 32>(p, nt, st);
             if (tile8) return launch_conv<DT, 8, 1, 2, 2, 0>(p, nt, st);
             return launch_conv<DT, 8, 1, 1, 2, 3>(p, nt, st);
         default:

@@ -239,7 +239,7 @@ class VxmDense:
             last = self._conv(li, last, in1=skip, up0=skip is not None)
             skip = None
             li += 1
-        if skip is None and (self.dtype == torch.bfloat16 or self.x3) and last.shape[-1] % 32 == 0:
+        if skip is None and ops.flow_head_supported(last.shape[-1], self.dtype, self.x3):
             return ops.conv3d_k3_cout3(last, w[2 * li], w[2 * li + 1], x3=self.x3)  # taps folded into N
         return self._conv(li, last, in1=skip, up0=skip is not None, leaky=False, out_f32=True)
 

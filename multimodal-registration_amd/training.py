@@ -72,7 +72,7 @@ class SynthMorphTrainer:
 
         def conv(x, in1=None, up0=False, leaky=True, cout=None):
             nonlocal li
-            if cout == 3 and in1 is None and not up0 and m.x3 and x.shape[-1] % 32 == 0:
+            if cout == 3 and in1 is None and not up0 and ops.flow_head_supported(x.shape[-1], torch.float32, m.x3):
                 y = ops.conv3d_k3_cout3(x, w[2 * li], w[2 * li + 1], x3=True)
                 tape.append(("conv", li, x, up0, in1, y, leaky))
                 li += 1
