@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--features", type=int, default=None)
     ap.add_argument("--shape", type=int, nargs=3, default=None)
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp32", "fp32x3"])
+    ap.add_argument("--bwd", default=None, choices=["bf16"], help="train: opt-in bf16-product backward (not the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -180,12 +181,13 @@ def main():
         model = mmr.networks.VxmDense(shape, nb_unet_features=(enc, dec), int_steps=5, int_resolution=2, svf_resolution=2,
                                       compute_dtype=dtype, device=dev, seed=0)
         tr = training.SynthMorphTrainer(model, g1, g2, reg_param=1.0, optimizer=training.Adam(1e-4),
-                                        world_size=world, rank=rank)
+                                        world_size=world, rank=rank, backward_precision=args.bwd)
         src = torch.from_numpy(maps[0][None, ..., None]).to(dev)
         trg = torch.from_numpy(maps[1][None, ..., None]).to(dev)
         step = lambda: tr.train_step(src, trg)["loss"]
         workload = (f"train_synthmorph.py step (BASELINE configs[2]): {shape[0]}^3, enc/dec={feats}, {L} labels, Dice + "
-                    f"Grad-l2(reg 1), generators + fwd + bwd + all-reduce + Adam, 1 pair per GPU, label maps resident in HBM")
+                    f"Grad-l2(reg 1), generators + fwd + bwd + all-reduce + Adam, 1 pair per GPU, label maps resident in HBM"
+                    + (" [OPT-IN bf16-product backward]" if args.bwd else ""))
         par = f"dp{world} (batch sharded by rank, one SUM all-reduce of {model._flat.numel() * 4 / 1e6:.1f} MB over RCCL)"
         cpu_fn = lambda: cpu_baseline_train(enc, dec, shape, L)
         metric, unit, pairs_per_step = "volume-pairs/sec", "pairs/s", 1

@@ -32,6 +32,7 @@ extern "C" {
 #define MMR_DT_F32 0
 #define MMR_DT_BF16 1
 #define MMR_DT_F32X3 2  /* fp32 tensors, bf16 hi/lo split inside the conv (3 bf16 MFMAs per product) */
+#define MMR_DT_F32X1 3  /* fp32 tensors, products of the bf16 hi halves only (opt-in, backward pass) */
 
 int mmr_version(void);
 const char* mmr_error_string(int code);
@@ -184,6 +185,9 @@ int mmr_conv3d_k3_wgrad_f32(const float* in0, int C0, int up0, const float* in1,
                             void* ws, int B, int X, int Y, int Z, int Cout, int accumulate, void* stream);
 /* same contract, bf16 hi/lo split products on the bf16 MFMA (pairs with MMR_DT_F32X3) */
 int mmr_conv3d_k3_wgrad_f32x3(const float* in0, int C0, int up0, const float* in1, int C1, const float* dz, float* dw,
+                              void* ws, int B, int X, int Y, int Z, int Cout, int accumulate, void* stream);
+/* same, hi halves only (one bf16 MFMA per product, fp32 accumulate; pairs with MMR_DT_F32X1) */
+int mmr_conv3d_k3_wgrad_f32x1(const float* in0, int C0, int up0, const float* in1, int C1, const float* dz, float* dw,
                               void* ws, int B, int X, int Y, int Z, int Cout, int accumulate, void* stream);
 int64_t mmr_conv3d_k3_cin2_wgrad_ws_bytes(int Cout);
 int mmr_conv3d_k3_cin2_wgrad_f32(const float* src, const float* trg, const float* dz, float* dw, void* ws,

@@ -60,6 +60,8 @@ template <> struct Elt<MMR_DT_F32> { static constexpr int size = 4; static const
 // fp32 tensors in HBM, split on the fly into bf16 (hi, lo) pairs: a*b ~ hi*hi + hi*lo + lo*hi on the bf16 MFMA
 // (3 MFMAs at 16x the fp32-MFMA rate, ~1e-5 relative error): LDS row = [32 ch hi | 32 ch lo] = 128 B.
 template <> struct Elt<MMR_DT_F32X3> { static constexpr int size = 4; static constexpr int kc = 32; };
+// fp32 tensors, products on the hi halves only (one bf16 MFMA, bf16-grade): opt-in for the backward pass
+template <> struct Elt<MMR_DT_F32X1> { static constexpr int size = 4; static constexpr int kc = 32; };
 
 // LDS-DMA (global_load_lds_dwordx4) issued through inline asm so that hipcc does NOT see an LDS write:
 // with the builtin it cannot prove that the DMA destination (B buffer cur^1) and the fragment reads (sA,
@@ -113,7 +115,8 @@ conv3d_k3_kernel(const ConvParams p)
     constexpr bool FRAG_DB = VAR & 1, PREF_A = (VAR >> 1) & 1;
     // VAR bit 5: v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (bf16 only): same bytes per flop, the chip holds
     // a higher clock on this shape (MI355X_MICROARCH.md, DVFS give-back item 7)
-    constexpr bool M16 = ((VAR >> 5) & 1) && (DT == MMR_DT_BF16 || DT == MMR_DT_F32X3);
+    constexpr bool M16 = ((VAR >> 5) & 1) && (DT == MMR_DT_BF16 || DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1);
+    constexpr bool LO = (DT == MMR_DT_F32X3);  // lo halves staged and multiplied
     static_assert(WM * WN == 8, "8 waves");
     static_assert(TXT == 4 || TXT == 8, "M tile");
     constexpr int BN = WN * NT * 32;
@@ -121,7 +124,7 @@ conv3d_k3_kernel(const ConvParams p)
     constexpr int KC = Elt<DT>::kc;
     constexpr int B_BYTES = BN * 128;
     constexpr int B_ITERS = B_BYTES / (CONV_THREADS * 16);
-    constexpr int A_ITERS = ((DT == MMR_DT_F32X3 ? HROWS_T * 4 : HROWS_T * 8) + CONV_THREADS - 1) / CONV_THREADS;
+    constexpr int A_ITERS = (((DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) ? HROWS_T * 4 : HROWS_T * 8) + CONV_THREADS - 1) / CONV_THREADS;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
@@ -185,7 +188,7 @@ conv3d_k3_kernel(const ConvParams p)
 
     // global load of item `it` of this thread's share of the haloed tile of channel slice s.
     // bf16 / fp32: item = (row, 16-B chunk); fp32x3: item = (row, 8-channel group) = 32 B of fp32.
-    constexpr bool X3 = (DT == MMR_DT_F32X3);
+    constexpr bool X3 = (DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1);  // fp32 in HBM, [hi | lo] LDS rows
     constexpr int A_ITEMS = X3 ? HROWS_T * 4 : HROWS_T * 8;
     struct AItem { uint4 a, b; };
     auto load_a = [&](int s, int it) -> AItem {
@@ -232,7 +235,8 @@ conv3d_k3_kernel(const ConvParams p)
                     lo[e] = (unsigned)l0 | ((unsigned)l1 << 16);
                 }
                 *reinterpret_cast<uint4*>(sA + row * ROWB + ((chunk ^ sz_) << 4)) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-                *reinterpret_cast<uint4*>(sA + row * ROWB + (((chunk + 4) ^ sz_) << 4)) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+                if constexpr (LO)
+                    *reinterpret_cast<uint4*>(sA + row * ROWB + (((chunk + 4) ^ sz_) << 4)) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
             } else {
                 *reinterpret_cast<uint4*>(sA + row * ROWB + ((chunk ^ sz_) << 4)) = val.a;
             }
@@ -275,27 +279,29 @@ conv3d_k3_kernel(const ConvParams p)
         const char* bB = sB + cur * B_BYTES;
         if constexpr (M16) {
             const int sw16 = swz((r16 >> 3) + dy, (r16 & 7) + dz);
-            if constexpr (DT == MMR_DT_F32X3) {
+            if constexpr (X3) {
                 // one 32-channel k-step per tap: chunks 0..3 = hi, 4..7 = lo
                 uint4 ah16[2 * MT], al16[2 * MT], bh16[2 * NT], bl16[2 * NT];
 #pragma unroll
                 for (int mi = 0; mi < 2 * MT; ++mi) {
                     ah16[mi] = *reinterpret_cast<const uint4*>(bA + a16_off[mi] + ((q16 ^ sw16) << 4));
-                    al16[mi] = *reinterpret_cast<const uint4*>(bA + a16_off[mi] + (((4 + q16) ^ sw16) << 4));
+                    if constexpr (LO) al16[mi] = *reinterpret_cast<const uint4*>(bA + a16_off[mi] + (((4 + q16) ^ sw16) << 4));
                 }
 #pragma unroll
                 for (int ni = 0; ni < 2 * NT; ++ni) {
                     bh16[ni] = *reinterpret_cast<const uint4*>(bB + b16_off[ni]);
-                    bl16[ni] = *reinterpret_cast<const uint4*>(bB + b16_off[ni] + 4 * BN * 16);
+                    if constexpr (LO) bl16[ni] = *reinterpret_cast<const uint4*>(bB + b16_off[ni] + 4 * BN * 16);
                 }
 #pragma unroll
                 for (int mi = 0; mi < 2 * MT; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 2 * NT; ++ni) {
-                        acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, al16[mi]), __builtin_bit_cast(bf16x8, bh16[ni]), acc16[mi][ni], 0, 0, 0);
-                        acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, ah16[mi]), __builtin_bit_cast(bf16x8, bl16[ni]), acc16[mi][ni], 0, 0, 0);
+                        if constexpr (LO) {
+                            acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, al16[mi]), __builtin_bit_cast(bf16x8, bh16[ni]), acc16[mi][ni], 0, 0, 0);
+                            acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, ah16[mi]), __builtin_bit_cast(bf16x8, bl16[ni]), acc16[mi][ni], 0, 0, 0);
+                        }
                         acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             __builtin_bit_cast(bf16x8, ah16[mi]), __builtin_bit_cast(bf16x8, bh16[ni]), acc16[mi][ni], 0, 0, 0);
                     }
@@ -325,21 +331,23 @@ conv3d_k3_kernel(const ConvParams p)
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     ah[m] = *reinterpret_cast<const uint4*>(bA + a_off[m] + ((ks << 5) ^ sw));
-                    al[m] = *reinterpret_cast<const uint4*>(bA + a_off[m] + ((64 + (ks << 5)) ^ sw));
+                    if constexpr (LO) al[m] = *reinterpret_cast<const uint4*>(bA + a_off[m] + ((64 + (ks << 5)) ^ sw));
                 }
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     bh[n] = *reinterpret_cast<const uint4*>(bB + b_off[n] + ks * 2 * BN * 16);
-                    bl[n] = *reinterpret_cast<const uint4*>(bB + b_off[n] + (4 + ks * 2) * BN * 16);
+                    if constexpr (LO) bl[n] = *reinterpret_cast<const uint4*>(bB + b_off[n] + (4 + ks * 2) * BN * 16);
                 }
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, al[m]), __builtin_bit_cast(bf16x8, bh[n]), acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, ah[m]), __builtin_bit_cast(bf16x8, bl[n]), acc[m][n], 0, 0, 0);
+                        if constexpr (LO) {
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8, al[m]), __builtin_bit_cast(bf16x8, bh[n]), acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8, ah[m]), __builtin_bit_cast(bf16x8, bl[n]), acc[m][n], 0, 0, 0);
+                        }
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                             __builtin_bit_cast(bf16x8, ah[m]), __builtin_bit_cast(bf16x8, bh[n]), acc[m][n], 0, 0, 0);
                     }
@@ -493,7 +501,7 @@ __global__ void pack_kernel(const float* __restrict__ w, char* __restrict__ wp, 
         char* dst = wp + i * 16;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            const int cc = (DT == MMR_DT_F32X3) ? (chunk & 3) : chunk;
+            const int cc = (DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) ? (chunk & 3) : chunk;
             const int ci = s * KC + cc * EPC + e;
             float v = 0.f;
             if (co < Cout) {
@@ -504,7 +512,7 @@ __global__ void pack_kernel(const float* __restrict__ w, char* __restrict__ wp, 
                 reinterpret_cast<float*>(dst)[e] = v;
             } else {
                 bf16_t hb = f32_to_bf16(v);
-                if (DT == MMR_DT_F32X3 && chunk >= 4) hb = f32_to_bf16(v - bf16_to_f32(hb));  // lo part
+                if ((DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) && chunk >= 4) hb = f32_to_bf16(v - bf16_to_f32(hb));  // lo part
                 reinterpret_cast<bf16_t*>(dst)[e] = hb;
             }
         }
@@ -1054,7 +1062,7 @@ extern "C" int64_t mmr_conv3d_k3_packed_bytes(int Cin, int Cout, int dtype)
 {
     if (Cin < 1 || Cout < 1) return MMR_EINVAL;
     const int kc = (dtype == MMR_DT_BF16) ? 64 : 32;
-    if (dtype != MMR_DT_BF16 && dtype != MMR_DT_F32 && dtype != MMR_DT_F32X3) return MMR_EINVAL;
+    if (dtype < 0 || dtype > MMR_DT_F32X1) return MMR_EINVAL;
     if (Cin % kc) return MMR_EINVAL;
     const int BN = conv_bn(Cout);
     const int nt = (Cout + BN - 1) / BN;
@@ -1072,7 +1080,7 @@ extern "C" int mmr_conv3d_k3_pack(const float* w_keras, void* w_packed, int Cin,
     if (dtype == MMR_DT_BF16)
         hipLaunchKernelGGL(pack_kernel<MMR_DT_BF16>, dim3(grid), dim3(256), 0, as_stream(stream), w_keras,
                            (char*)w_packed, Cin, Cout, BN, nt, transpose_flip);
-    else if (dtype == MMR_DT_F32X3)
+    else if (dtype == MMR_DT_F32X3 || dtype == MMR_DT_F32X1)
         hipLaunchKernelGGL(pack_kernel<MMR_DT_F32X3>, dim3(grid), dim3(256), 0, as_stream(stream), w_keras,
                            (char*)w_packed, Cin, Cout, BN, nt, transpose_flip);
     else
@@ -1086,7 +1094,7 @@ extern "C" int mmr_conv3d_k3_fwd(const void* in0, int C0, int up0, const void* i
                                  int leaky, float alpha, int dtype, int out_f32, void* stream)
 {
     if (!in0 || !w_packed || !out || B < 1 || X < 1 || Y < 1 || Z < 1 || Cout < 1 || C0 < 1 || C1 < 0) return MMR_EINVAL;
-    if (dtype != MMR_DT_BF16 && dtype != MMR_DT_F32 && dtype != MMR_DT_F32X3) return MMR_EINVAL;
+    if (dtype < 0 || dtype > MMR_DT_F32X1) return MMR_EINVAL;
     if (C1 > 0 && !in1) return MMR_EINVAL;
     if (pool_out) return MMR_EUNSUPPORTED;  // fused pooling: planned; use mmr_maxpool3d2_fwd
     const int kc = (dtype == MMR_DT_BF16) ? 64 : 32;
@@ -1100,6 +1108,7 @@ extern "C" int mmr_conv3d_k3_fwd(const void* in0, int C0, int up0, const void* i
     p.ntx = (X + TX - 1) / TX; p.nty = (Y + TY - 1) / TY; p.ntz = (Z + TZ - 1) / TZ;
     if (dtype == MMR_DT_BF16) return dispatch_conv<MMR_DT_BF16>(p, as_stream(stream));
     if (dtype == MMR_DT_F32X3) return dispatch_conv<MMR_DT_F32X3>(p, as_stream(stream));
+    if (dtype == MMR_DT_F32X1) return dispatch_conv<MMR_DT_F32X1>(p, as_stream(stream));
     return dispatch_conv<MMR_DT_F32>(p, as_stream(stream));
 }
 

@@ -700,7 +700,7 @@ __device__ __forceinline__ void split_bf16(float f, unsigned short& hi, unsigned
 constexpr int WX_A_BYTES = W_HROWS * 128;  // 76800
 constexpr int WX_B_BYTES = 256 * 256;      // 65536
 
-template <int COT>
+template <int COT, bool LO>
 __global__ void __launch_bounds__(W_THREADS, 2)
 wgrad_x3_kernel(const WgradParams p)
 {
@@ -793,7 +793,8 @@ wgrad_x3_kernel(const WgradParams p)
                 lo[e] = (unsigned)l0 | ((unsigned)l1 << 16);
             }
             *reinterpret_cast<uint4*>(sX + row * 128 + ((0 ^ sw) << 6) + c * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-            *reinterpret_cast<uint4*>(sX + row * 128 + ((1 ^ sw) << 6) + c * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            if constexpr (LO)
+                *reinterpret_cast<uint4*>(sX + row * 128 + ((1 ^ sw) << 6) + c * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
         }
     };
     auto load_z = [&](int b, int x0, int y0, int z0, int it) -> float4 {
@@ -822,8 +823,9 @@ wgrad_x3_kernel(const WgradParams p)
         const int seg_hi = (0 * 2 + (c4 >> 3)) ^ (vz & 3), seg_lo = (1 * 2 + (c4 >> 3)) ^ (vz & 3);
         *reinterpret_cast<uint2*>(sZ + v * 256 + (seg_hi << 6) + (c4 & 7) * 8) =
             make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
-        *reinterpret_cast<uint2*>(sZ + v * 256 + (seg_lo << 6) + (c4 & 7) * 8) =
-            make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
+        if constexpr (LO)
+            *reinterpret_cast<uint2*>(sZ + v * 256 + (seg_lo << 6) + (c4 & 7) * 8) =
+                make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
     };
 
     XItem px[A_IT];
@@ -857,13 +859,16 @@ wgrad_x3_kernel(const WgradParams p)
             const char* xa = sX + ((kb >> 2) * (W_HY * W_HZ) + (kb & 3) * 2 * W_HZ) * 128;
             const char* zb = sZ + kb * 16 * 256;
             const bf16x8_t b_hi = frag8(tr_read(zb + laneBh[0]), tr_read(zb + laneBh[1]));
-            const bf16x8_t b_lo = frag8(tr_read(zb + laneBl[0]), tr_read(zb + laneBl[1]));
+            bf16x8_t b_lo = b_hi;
+            if constexpr (LO) b_lo = frag8(tr_read(zb + laneBl[0]), tr_read(zb + laneBl[1]));
 #pragma unroll
             for (int j = 0; j < NU; ++j) {
                 const bf16x8_t a_hi = frag8(tr_read(xa + laneA[0] + offA_hi[j]), tr_read(xa + laneA[1] + offA_hi[j]));
-                const bf16x8_t a_lo = frag8(tr_read(xa + laneA[0] + offA_lo[j]), tr_read(xa + laneA[1] + offA_lo[j]));
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[j], 0, 0, 0);
+                if constexpr (LO) {
+                    const bf16x8_t a_lo = frag8(tr_read(xa + laneA[0] + offA_lo[j]), tr_read(xa + laneA[1] + offA_lo[j]));
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[j], 0, 0, 0);
+                }
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[j], 0, 0, 0);
             }
         }
@@ -1490,6 +1495,10 @@ extern "C" int mmr_warp3d_bwd_vol_f32(const float* flow, const float* dout, floa
     return check_launch();
 }
 
+extern "C" int mmr_conv3d_k3_wgrad_f32x1(const float* in0, int C0, int up0, const float* in1, int C1, const float* dz,
+                                         float* dw, void* ws, int B, int X, int Y, int Z, int Cout, int accumulate,
+                                         void* stream);
+
 // ---- conv backward plumbing ----------------------------------------------- //
 extern "C" int64_t mmr_leaky_bwd_ws_bytes(int64_t nvox, int C)
 {
@@ -1606,18 +1615,24 @@ static int wgrad_impl(const float* in0, int C0, int up0, const float* in1, int C
         constexpr int LDSX = WX_A_BYTES + WX_B_BYTES;
         static bool attr_x3 = false;
         if (!attr_x3) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<2>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDSX);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<1>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDSX);
-            if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
+            const void* ks[4] = {reinterpret_cast<const void*>(wgrad_x3_kernel<2, true>),
+                                 reinterpret_cast<const void*>(wgrad_x3_kernel<1, true>),
+                                 reinterpret_cast<const void*>(wgrad_x3_kernel<2, false>),
+                                 reinterpret_cast<const void*>(wgrad_x3_kernel<1, false>)};
+            for (int i = 0; i < 4; ++i) {
+                hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDSX);
+                if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
+            }
             attr_x3 = true;
         }
-        if (Cout <= 32)
-            hipLaunchKernelGGL(wgrad_x3_kernel<1>, dim3(gx, nslices, ncob), dim3(W_THREADS), LDSX, as_stream(stream), p);
-        else
-            hipLaunchKernelGGL(wgrad_x3_kernel<2>, dim3(gx, nslices, ncob), dim3(W_THREADS), LDSX, as_stream(stream), p);
+        const dim3 g3(gx, nslices, ncob), b3(W_THREADS);
+        if (x3 == 1) {
+            if (Cout <= 32) hipLaunchKernelGGL((wgrad_x3_kernel<1, true>), g3, b3, LDSX, as_stream(stream), p);
+            else hipLaunchKernelGGL((wgrad_x3_kernel<2, true>), g3, b3, LDSX, as_stream(stream), p);
+        } else {
+            if (Cout <= 32) hipLaunchKernelGGL((wgrad_x3_kernel<1, false>), g3, b3, LDSX, as_stream(stream), p);
+            else hipLaunchKernelGGL((wgrad_x3_kernel<2, false>), g3, b3, LDSX, as_stream(stream), p);
+        }
     } else if (Cout <= 32)
         hipLaunchKernelGGL(wgrad_kernel<1>, dim3(gx, nslices, ncob), dim3(W_THREADS), LDS, as_stream(stream), p);
     else
@@ -1642,6 +1657,13 @@ extern "C" int mmr_conv3d_k3_wgrad_f32x3(const float* in0, int C0, int up0, cons
                                          void* stream)
 {
     return wgrad_impl(in0, C0, up0, in1, C1, dz, dw, ws, B, X, Y, Z, Cout, accumulate, 1, stream);
+}
+
+extern "C" int mmr_conv3d_k3_wgrad_f32x1(const float* in0, int C0, int up0, const float* in1, int C1, const float* dz,
+                                         float* dw, void* ws, int B, int X, int Y, int Z, int Cout, int accumulate,
+                                         void* stream)
+{
+    return wgrad_impl(in0, C0, up0, in1, C1, dz, dw, ws, B, X, Y, Z, Cout, accumulate, 2, stream);
 }
 
 extern "C" int64_t mmr_conv3d_k3_cin2_wgrad_ws_bytes(int Cout)

@@ -8,7 +8,7 @@ import torch
 
 from . import _lib
 
-F32, BF16, F32X3 = 0, 1, 2
+F32, BF16, F32X3, F32X1 = 0, 1, 2, 3
 LINEAR, NEAREST = 0, 1
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -18,6 +18,8 @@ def conv_mode(dtype, x3=False):
     hi/lo split with three bf16 MFMAs per product (fp32-grade accuracy at ~5x the fp32-MFMA rate)."""
     if dtype == torch.bfloat16:
         return BF16
+    if x3 == "hi":  # products of the bf16 hi halves only (opt-in for the backward pass)
+        return F32X1
     return F32X3 if x3 else F32
 
 
@@ -179,7 +181,7 @@ def conv3d_k3(in0, w_packed, bias, cout, in1=None, up0=False, leaky=True, alpha=
     odt = torch.float32 if (out_f32 or dtype == torch.float32) else torch.bfloat16
     out = torch.empty((B, X, Y, Z, cout), dtype=odt, device=in0.device)
     mode = conv_mode(dtype, x3)
-    fam = f"conv3d_k3_mfma_{('f32', 'bf16', 'f32x3')[mode]}_bn{256 if cout % 256 == 0 else 128 if cout % 128 == 0 else 64 if cout % 64 == 0 else 32}"
+    fam = f"conv3d_k3_mfma_{('f32', 'bf16', 'f32x3', 'f32x1')[mode]}_bn{256 if cout % 256 == 0 else 128 if cout % 128 == 0 else 64 if cout % 64 == 0 else 32}"
     with _Timed(fam, (C0 + C1, int(cout), X, Y, Z), 2.0 * 27 * (C0 + C1) * cout * B * X * Y * Z):
         rc = _lib.load().mmr_conv3d_k3_fwd(
             in0.data_ptr(), C0, int(up0), in1.data_ptr() if in1 is not None else None, C1,
@@ -557,8 +559,8 @@ def conv3d_k3_wgrad(in0, dz, dw, in1=None, up0=False, accumulate=False, x3=False
     C1 = in1.shape[-1] if in1 is not None else 0
     lib = _lib.load()
     ws = _ws(lib.mmr_conv3d_k3_wgrad_ws_bytes(B, X, Y, Z, C0 + C1, Cout), dz.device)
-    fn = lib.mmr_conv3d_k3_wgrad_f32x3 if x3 else lib.mmr_conv3d_k3_wgrad_f32
-    with _Timed("conv3d_k3_wgrad_mfma_f32x3" if x3 else "conv3d_k3_wgrad_mfma_f32", (C0 + C1, Cout, X, Y, Z),
+    fn = lib.mmr_conv3d_k3_wgrad_f32x1 if x3 == "hi" else (lib.mmr_conv3d_k3_wgrad_f32x3 if x3 else lib.mmr_conv3d_k3_wgrad_f32)
+    with _Timed("conv3d_k3_wgrad_mfma_" + ("f32x1" if x3 == "hi" else "f32x3" if x3 else "f32"), (C0 + C1, Cout, X, Y, Z),
                 2.0 * 27 * (C0 + C1) * Cout * B * X * Y * Z):
         rc = fn(in0.data_ptr(), C0, int(up0), in1.data_ptr() if in1 is not None else None, C1,
                                          dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, X, Y, Z, Cout, int(accumulate), _stream())

@@ -42,7 +42,10 @@ class SynthMorphTrainer:
     """model: fp32 VxmDense; gen_1/gen_2: synth.LabelsToImage (sharing the label list)."""
 
     def __init__(self, model, gen_1, gen_2, reg_param=1.0, optimizer=None, zero_pad_dice=False,
-                 process_group=None, world_size=1, rank=0):
+                 process_group=None, world_size=1, rank=0, backward_precision=None):
+        """backward_precision: None = same arithmetic as the forward (fp32 / fp32x3); 'bf16' = dgrad and wgrad
+        products on the bf16 hi halves only (one MFMA instead of three, fp32 accumulate) -- an opt-in
+        mixed-precision backward; the forward (and therefore every output and loss) keeps fp32-grade accuracy."""
         if model.dtype != torch.float32:
             raise NotImplementedError("training runs the fp32 path (the reference trains in fp32)")
         self.model, self.gen_1, self.gen_2 = model, gen_1, gen_2
@@ -50,6 +53,9 @@ class SynthMorphTrainer:
         self.reg_param = float(reg_param)
         self.opt = optimizer or Adam(1e-4)
         self.zero_pad_dice = zero_pad_dice
+        if backward_precision not in (None, "bf16"):
+            raise ValueError("backward_precision must be None or 'bf16'")
+        self.bwd_x3 = "hi" if backward_precision == "bf16" else model.x3
         self.pg, self.world, self.rank = process_group, int(world_size), int(rank)
         self.gflat = torch.zeros_like(model._flat)
         self.g, off = [], 0
@@ -136,14 +142,14 @@ class SynthMorphTrainer:
                 _, li, x, up0, in1, y, leaky = rec
                 dy = grads.pop(id(y))
                 dz = ops.leaky_bwd_bias_(y if leaky else None, dy, self.g[2 * li + 1], leaky=leaky)
-                ops.conv3d_k3_wgrad(x, dz, self.g[2 * li], in1=in1, up0=up0, x3=m.x3)
+                ops.conv3d_k3_wgrad(x, dz, self.g[2 * li], in1=in1, up0=up0, x3=self.bwd_x3)
                 C0 = x.shape[-1]
                 C1 = in1.shape[-1] if in1 is not None else 0
                 if m.plan[li][0] == "flow":
                     dcat = ops.conv3d_k3_cout3_dgrad(dz, m._w[2 * li])
                 else:
-                    wt = ops.pack_conv_weights(m._w[2 * li], torch.float32, transpose_flip=True, x3=m.x3)
-                    dcat = ops.conv3d_k3(dz, wt, None, C0 + C1, leaky=False, out_f32=True, x3=m.x3)
+                    wt = ops.pack_conv_weights(m._w[2 * li], torch.float32, transpose_flip=True, x3=self.bwd_x3)
+                    dcat = ops.conv3d_k3(dz, wt, None, C0 + C1, leaky=False, out_f32=True, x3=self.bwd_x3)
                 del dz, dy
                 if in1 is None and not up0:
                     if id(x) in grads:

@@ -304,3 +304,35 @@ def test_training_lowers_loss_and_is_reproducible(dev):
     l2, w2 = run()
     # float atomics in the gather adjoints make later steps drift in the last bits; the first steps must agree
     assert np.allclose(l1[:4], l2[:4], rtol=1e-4, atol=1e-5) and abs(l1[-1] - l2[-1]) < 0.05
+
+
+def test_optin_bf16_backward(dev):
+    """Opt-in mixed-precision backward: forward unchanged (fp32x3), weight gradients within bf16-product accuracy
+    of the fp32x3 gradients, and training still converges."""
+    import mmr
+    from mmr import synth, training
+    shape, enc, dec, L = (16, 16, 32), [32, 32], [32, 32, 32], 4
+    rng = np.random.default_rng(9)
+    mk = lambda: np.repeat(np.repeat(np.repeat(rng.integers(0, L, (1, 4, 4, 8)), 4, 1), 4, 2), 4, 3).astype(np.uint8)[..., None]
+    lab_s, lab_t = mk(), mk()
+    kw = dict(in_shape=shape, in_label_list=np.arange(L), out_label_list=np.arange(L), warp_std=1, warp_res=8, blur_std=1,
+              bias_std=0.3, bias_res=8, gamma_std=0.25)
+    grads, losses = {}, {}
+    for mode in (None, "bf16"):
+        g1, g2 = synth.labels_to_image(**kw, id=0, seed=1), synth.labels_to_image(**kw, id=1, seed=2)
+        d1, d2 = g1.draw(1), g2.draw(1)
+        model = mmr.networks.VxmDense(shape, nb_unet_features=(enc, dec), int_steps=3, int_resolution=2, svf_resolution=2,
+                                      compute_dtype="fp32x3", seed=5)
+        w = model.get_weights()
+        w[-2] = (np.random.default_rng(3).standard_normal(w[-2].shape) * 3e-2).astype(np.float32)
+        model.set_weights(w)
+        tr = training.SynthMorphTrainer(model, g1, g2, reg_param=0.1, optimizer=training.Adam(1e-3), backward_precision=mode)
+        out = tr.forward_backward(lab_s, lab_t, d1, d2)
+        grads[mode] = tr.gflat.clone()
+        losses[mode] = [float(out["loss"])] + [float(tr.train_step(lab_s, lab_t, d1, d2)["loss"]) for _ in range(20)]
+    assert losses[None][0] == losses["bf16"][0]  # identical forward
+    ref, got = grads[None], grads["bf16"]
+    cos = float((ref * got).sum() / (ref.norm() * got.norm()))
+    assert cos > 0.999, cos
+    assert float((ref - got).norm() / ref.norm()) < 3e-2
+    assert losses["bf16"][-1] < losses["bf16"][0] - 0.02
