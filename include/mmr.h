@@ -199,6 +199,16 @@ int mmr_conv3d_k3_cout3_dgrad_f32(const float* dy, const float* w_keras, float* 
 int mmr_adam_step_f32(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                       float eps, int64_t step, float grad_scale, void* stream);
 
+/* ---- evaluation metrics of eval_reg_*.py, fp64 like the reference's NumPy ---- */
+/* det(I + grad u) with 4th-order central differences (eval_reg_with_jacobian.py:62-78); ddf [X,Y,Z,3] */
+int mmr_jacobian_det_f64(const double* ddf, double* det, int X, int Y, int Z, void* stream);
+/* joint histogram with numpy.histogramdd semantics (eval_reg_with_mi.py:65-68); edges: nbins+1 each */
+int mmr_joint_hist_f64(const double* a, const double* b, const double* edges_a, const double* edges_b,
+                       unsigned long long* hist, int64_t n, int nbins, void* stream);
+/* out6 = {sum m[f==1], sum m[f==0], #f==1, #f==0, sum m, n} (eval_reg_on_sc_seg.py:80-93) */
+int64_t mmr_overlap_ws_bytes(void);
+int mmr_overlap_sums_f64(const double* fixed, const double* moved, double* out6, void* ws, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

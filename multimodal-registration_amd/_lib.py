@@ -73,6 +73,10 @@ SIGNATURES = {
     "mmr_conv3d_k3_cin2_wgrad_f32": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
     "mmr_conv3d_k3_cout3_dgrad_f32": (I, [P, P, P, I, I, I, I, I, P]),
     "mmr_adam_step_f32": (I, [P, P, P, P, c_int64, F, F, F, F, c_int64, F, P]),
+    "mmr_jacobian_det_f64": (I, [P, P, I, I, I, P]),
+    "mmr_joint_hist_f64": (I, [P, P, P, P, P, c_int64, I, P]),
+    "mmr_overlap_ws_bytes": (c_int64, []),
+    "mmr_overlap_sums_f64": (I, [P, P, P, P, c_int64, P]),
 }
 
 

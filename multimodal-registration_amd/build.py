@@ -4,7 +4,7 @@ import os
 import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["api.hip", "tail.hip", "losses.hip", "conv3d.hip", "train.hip", "synth.hip"]
+SOURCES = ["api.hip", "tail.hip", "losses.hip", "conv3d.hip", "train.hip", "synth.hip", "eval.hip"]
 LIB = os.path.join(CSRC, "libmmr_hip.so")
 
 
