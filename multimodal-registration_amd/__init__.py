@@ -8,8 +8,8 @@ kernels behind the C-ABI of include/mmr.h; there is no CPU fallback.
 """
 from . import _lib, ops  # noqa: F401
 from . import layers, losses, networks, utils  # noqa: F401
-from . import data, evaluation, parallel, py_utils, synth, tiling, training  # noqa: F401
+from . import data, evaluation, parallel, py_utils, registration, synth, tiling, training  # noqa: F401
 from ._lib import MmrError  # noqa: F401
 
-__all__ = ["ops", "layers", "losses", "networks", "utils", "data", "evaluation", "parallel", "py_utils", "synth", "tiling",
+__all__ = ["ops", "layers", "losses", "networks", "utils", "data", "evaluation", "parallel", "py_utils", "registration", "synth", "tiling",
            "training", "MmrError"]

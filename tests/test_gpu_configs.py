@@ -71,3 +71,46 @@ def test_c4_two_step_cascade_matches_oracle(dev):
     # nearest-neighbour variant applies the composed field with Transform (…:354-355)
     tr = mmr.networks.Transform(shape, interp_method="nearest", rescale=scale, nb_feats=1).predict([mov, warp[None]])
     assert tr.shape == (1,) + shape + (1,)
+
+
+def test_pair_registration_flow_files(dev, tmp_path):
+    """3d_reg.py / bids_registration.py flow end to end on synthetic NIfTI files: whole volume and sub-volumes,
+    one model and the two-step cascade; outputs written like the reference (moved image + RAI warp, intent 1007)."""
+    import scipy.ndimage as ndi
+    import mmr
+    from mmr import py_utils, registration
+    rng = np.random.default_rng(4)
+    fx = ndi.gaussian_filter(rng.random((70, 40, 52)), 2.0)
+    mv = ndi.shift(fx, (1.5, -1.0, 0.5), order=1) + 0.02 * rng.random(fx.shape)
+    aff = np.diag([1.0, 1.0, 1.0, 1.0])
+    aff[:3, 3] = [-30, -20, 10]
+    py_utils.write_nifti(fx.astype(np.float32), str(tmp_path / "fx.nii.gz"), aff)
+    py_utils.write_nifti(mv.astype(np.float32), str(tmp_path / "mv.nii.gz"), aff)
+    specs = dict(use_subvol=False, subvol_size=[32, 32, 32], min_perc_overlap=0.1, int_steps=5, int_res=2, svf_res=2,
+                 enc=[64] * 4, dec=[64] * 6, warp_interpolation="linear", resample_interpolation="linear")
+    m = mmr.networks.VxmDense((16, 16, 16), nb_unet_features=(specs["enc"], specs["dec"]), int_steps=5, int_resolution=2,
+                              svf_resolution=2, compute_dtype="fp32", seed=1)
+    w = m.get_weights()
+    w[-2] = (rng.standard_normal(w[-2].shape) * 2e-2).astype(np.float32)
+    m.set_weights(w)
+    m.save(str(tmp_path / "m1.safetensors"))
+    out = registration.run_3d_reg(specs, str(tmp_path / "m1.safetensors"), str(tmp_path / "fx.nii.gz"),
+                                  str(tmp_path / "mv.nii.gz"), res_dir=str(tmp_path / "res"), compute_dtype="fp32")
+    assert out["fixed_proc"].shape == (64, 32, 48) and out["scale"] == 2 and out["warp"].shape == (32, 16, 24, 3)
+    moved, aff2, _ = py_utils.read_nifti(str(tmp_path / "res" / "warped_im.nii.gz"))
+    field, _, hdr = py_utils.read_nifti(str(tmp_path / "res" / "deform_field.nii.gz"))
+    assert moved.shape == (70, 40, 52) and field.shape == (70, 40, 52, 1, 3) and hdr["intent_code"] == 1007
+    np.testing.assert_allclose(aff2, aff)
+    assert np.isfinite(moved).all() and np.abs(out["warp"]).max() > 0.05
+    # nearest variant re-applies the (x2-rescaled) field with Transform: consistent with the device ops
+    outn = registration.register(specs, m, registration.Volume(fx, aff), registration.Volume(mv, aff), warp_interp="nearest",
+                                 compute_dtype="fp32")
+    chk = mmr.networks.Transform((64, 32, 48), interp_method="nearest", rescale=2, nb_feats=1).predict(
+        [outn["moving_proc"].get_fdata()[None, ..., None], outn["warp"][None]])[0, ..., 0]
+    np.testing.assert_array_equal(outn["moved"].data, chk)
+    # sub-volume path and two-step cascade run and give fields of the same geometry
+    specs_sv = dict(specs, use_subvol=True)
+    outs = registration.register(specs_sv, m, registration.Volume(fx, aff), registration.Volume(mv, aff), compute_dtype="fp32")
+    assert outs["warp"].shape == (32, 16, 24, 3) and np.isfinite(outs["moved"].data).all()
+    out2 = registration.register(specs, [m, m], registration.Volume(fx, aff), registration.Volume(mv, aff), compute_dtype="fp32")
+    assert out2["warp"].shape == (32, 16, 24, 3) and out2["warp_rai"].shape == (64, 32, 48, 1, 3)
