@@ -663,7 +663,7 @@ template <bool X3, bool OUT_BF16>
 __global__ void __launch_bounds__(M2_THREADS)
 conv3d_cin2_mfma_kernel(const float* __restrict__ src, const float* __restrict__ trg, const float* __restrict__ w,
                         const float* __restrict__ bias, void* __restrict__ out, int B, int X, int Y, int Z, int Cout,
-                        int leaky, float alpha, int ntx, int nty, int ntz)
+                        int leaky, float alpha, int ntx, int nty, int ntz, int ntiles)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NPL = X3 ? 2 : 1;
@@ -674,14 +674,16 @@ conv3d_cin2_mfma_kernel(const float* __restrict__ src, const float* __restrict__
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
-    int bid = blockIdx.x;
+    const size_t nvox = (size_t)X * Y * Z;
+    // persistent over tiles: the weight image and the bias are built once per block
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int bid = tile;
     const int tzi = bid % ntz; bid /= ntz;
     const int tyi = bid % nty; bid /= nty;
     const int txi = bid % ntx;
     const int b = bid / ntx;
     const int x0 = txi * TX, y0 = tyi * TY, z0 = tzi * TZ;
-    const size_t nvox = (size_t)X * Y * Z;
-
+    __syncthreads();  // previous tile done with s_img / s_x
     for (int i = tid; i < HROWS; i += M2_THREADS) {
         const int hx = i / (HY * HZ), hy = (i / HZ) % HY, hz = i % HZ;
         const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
@@ -694,6 +696,7 @@ conv3d_cin2_mfma_kernel(const float* __restrict__ src, const float* __restrict__
         s_img[i * 2] = a;
         s_img[i * 2 + 1] = c;
     }
+    if (tile == (int)blockIdx.x) {
     for (int i = tid; i < Cout; i += M2_THREADS) s_bias[i] = bias ? bias[i] : 0.f;
     // weight image: row = cout, 64 k (k = tap*2 + ci; k >= 54 zero), chunk swizzle (row >> 1) & 7
     for (int i = tid; i < Cout * 32; i += M2_THREADS) {
@@ -711,6 +714,7 @@ conv3d_cin2_mfma_kernel(const float* __restrict__ src, const float* __restrict__
             const bf16_t l0 = f32_to_bf16(f0 - bf16_to_f32(h0)), l1 = f32_to_bf16(f1 - bf16_to_f32(h1));
             *reinterpret_cast<unsigned*>(s_w + Cout * 128 + off) = (unsigned)l0 | ((unsigned)l1 << 16);
         }
+    }
     }
     __syncthreads();
     // im2col: row = voxel (x*64 + y*8 + z), k pair kp = tap
@@ -830,6 +834,7 @@ conv3d_cin2_mfma_kernel(const float* __restrict__ src, const float* __restrict__
             }
         }
     }
+    }  // tile loop
 }
 
 // ---- flow head (Cout = 3) ---------------------------------------------------------------------------- //
@@ -1128,10 +1133,11 @@ static int launch_cin2_mfma(const float* src, const float* trg, const float* w, 
         attr_set = true;
     }
     const int ntx = (X + TX - 1) / TX, nty = (Y + TY - 1) / TY, ntz = (Z + TZ - 1) / TZ;
-    const int64_t nblk = (int64_t)B * ntx * nty * ntz;
-    if (nblk > 0x7fffffff) return MMR_EINVAL;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(M2_THREADS), lds, st, src, trg, w, bias, out, B, X, Y, Z, Cout,
-                       leaky, alpha, ntx, nty, ntz);
+    const int64_t nt = (int64_t)B * ntx * nty * ntz;
+    if (nt > 0x7fffffff) return MMR_EINVAL;
+    const int grid = nt < 2048 ? (int)nt : 2048;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(M2_THREADS), lds, st, src, trg, w, bias, out, B, X, Y, Z, Cout,
+                       leaky, alpha, ntx, nty, ntz, (int)nt);
     return check_launch();
 }
 
