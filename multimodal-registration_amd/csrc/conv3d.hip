@@ -136,7 +136,15 @@ conv3d_k3_kernel(const ConvParams p)
     const int wm = wave / WN, wn = wave % WN;
     const int h = lane >> 5;
 
+    // Optional XCD-aware tile order (VAR bit 6): blocks are dealt round-robin over the 8 XCDs (b and b+8 share
+    // one); giving every XCD a contiguous run of spatial tiles lets neighbours share halo rows in one L2.
+    // Measured on C2: 1 % SLOWER than the plain order (all XCDs then stream the same weights and halo
+    // neighbourhood at the same time through the Infinity Cache), so it is off by default.
     int bid = blockIdx.x;
+    if constexpr (((VAR >> 6) & 1) != 0) {
+        const int nwg = gridDim.x, xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
+        bid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    }
     const int tzi = bid % p.ntz; bid /= p.ntz;
     const int tyi = bid % p.nty; bid /= p.nty;
     const int txi = bid % p.ntx;
@@ -564,6 +572,7 @@ int dispatch_conv(const ConvParams& p, hipStream_t st)
             if (var == 0) return launch_conv<DT, 2, 4, 4, 2, 0>(p, nt, st);
             if (var == 2) return launch_conv<DT, 2, 4, 4, 2, 2>(p, nt, st);
             if (var == 32) return launch_conv<DT, 2, 4, 4, 2, 32>(p, nt, st);
+            if (var == 96) return launch_conv<DT, 2, 4, 4, 2, 96>(p, nt, st);
             if (var == 1) return launch_conv<DT, 2, 4, 4, 2, 1>(p, nt, st);
             if (var == 4) return launch_conv<DT, 2, 4, 4, 2, 4>(p, nt, st);
             if (var == 8) return launch_conv<DT, 2, 4, 4, 2, 8>(p, nt, st);
