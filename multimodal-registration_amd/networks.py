@@ -40,6 +40,58 @@ def _plan(enc, dec):
     return plan
 
 
+def _is_h5_name(path):
+    return str(path).lower().endswith((".h5", ".hdf5", ".keras.h5"))
+
+
+def _is_h5_file(path):
+    with open(path, "rb") as fh:
+        return fh.read(8) == b"\x89HDF\r\n\x1a\n"
+
+
+def _attr_list(group, name):
+    """Keras ``load_attributes_from_hdf5_group``: a string-array attribute, possibly split into name0, name1, ..."""
+    a = group.attrs
+    if name in a:
+        vals = list(np.atleast_1d(a[name]))
+    else:
+        vals, i = [], 0
+        while f"{name}{i}" in a:
+            vals += list(np.atleast_1d(a[f"{name}{i}"]))
+            i += 1
+    return [v.decode("utf8") if isinstance(v, bytes) else str(v) for v in vals]
+
+
+def _read_keras_weights(path):
+    """-> (names of the layers that hold weights, [[arrays in weight_names order] per layer]) of a Keras .h5 file
+    (full model: group 'model_weights'; save_weights: layer groups at the root)."""
+    from . import h5lite
+    with h5lite.File(path) as f:
+        g = f
+        if "layer_names" not in f.attrs and "layer_names0" not in f.attrs and "model_weights" in f:
+            g = f["model_weights"]
+        names, per_layer = [], []
+        for ln in _attr_list(g, "layer_names"):
+            lg = g[ln]
+            wn = _attr_list(lg, "weight_names")
+            if wn:
+                names.append(ln)
+                per_layer.append([np.asarray(lg[w][()]) for w in wn])
+    return names, per_layer
+
+
+def _write_keras_weights(g, layer_names, weights):
+    g.attrs["layer_names"] = np.array([n.encode("utf8") for n in layer_names])
+    g.attrs["backend"] = b"tensorflow"
+    g.attrs["keras_version"] = b"2.7.0"
+    for i, n in enumerate(layer_names):
+        lg = g.create_group(n)
+        wn = [f"{n}/kernel:0", f"{n}/bias:0"]
+        lg.attrs["weight_names"] = np.array([w.encode("utf8") for w in wn])
+        lg.create_dataset(wn[0], np.asarray(weights[2 * i], dtype=np.float32))
+        lg.create_dataset(wn[1], np.asarray(weights[2 * i + 1], dtype=np.float32))
+
+
 class VxmDense:
     """VoxelMorph dense registration network, forward on gfx950 HIP kernels.
 
@@ -193,23 +245,90 @@ class VxmDense:
     def get_config(self):
         return dict(self._config)
 
+    def _keras_names(self):
+        """Keras layer names of the 11 weighted layers (vxm Unet 'unet_*' convs + '<name>_flow')."""
+        return [f"{self.name}_flow" if n == "flow" else n for n, _, _ in self.plan]
+
     def save(self, path):
+        """``.h5`` / ``.hdf5`` -> the Keras 2.x full-model HDF5 layout the reference's checkpoints use
+        (train_synthmorph.py:313-317: root attrs keras_version / backend / model_config, group ``model_weights`` with
+        ``layer_names`` and per-layer ``weight_names`` + datasets), readable by ``vxm.networks.VxmDense.load``;
+        anything else -> safetensors."""
+        if _is_h5_name(path):
+            from . import h5lite
+            root = h5lite.WGroup()
+            cfg = {k: v for k, v in dict(self._config, name=self.name).items() if not (k == "fill_value" and v is None)}
+            root.attrs["keras_version"] = b"2.7.0"
+            root.attrs["backend"] = b"tensorflow"
+            root.attrs["model_config"] = json.dumps({"class_name": "VxmDense", "config": cfg}).encode("utf8")
+            _write_keras_weights(root.create_group("model_weights"), self._keras_names(), self.get_weights())
+            h5lite.write_file(path, root)
+            return
         from safetensors.torch import save_file
         tensors = {f"w{i:02d}": torch.from_numpy(np.ascontiguousarray(w)) for i, w in enumerate(self.get_weights())}
         save_file(tensors, path, metadata={"config": json.dumps(self._config), "format": "mmr-vxmdense-1"})
 
-    def load_weights(self, path):
+    def save_weights(self, path):
+        """Keras ``save_weights``: the layer groups at the file root (no model_config)."""
+        if not _is_h5_name(path):
+            return self.save(path)
+        from . import h5lite
+        root = h5lite.WGroup()
+        _write_keras_weights(root, self._keras_names(), self.get_weights())
+        h5lite.write_file(path, root)
+
+    def load_weights(self, path, by_name=False):
+        """Positional load over the layers that have weights, like Keras' ``load_weights_from_hdf5_group``
+        (``by_name=True`` matches layer names instead and leaves unmatched layers untouched)."""
+        if _is_h5_file(path):
+            names, per_layer = _read_keras_weights(path)
+            mine = self._keras_names()
+            if by_name:
+                cur = self.get_weights()
+                for n, ws in zip(names, per_layer):
+                    if n in mine:
+                        li = mine.index(n)
+                        if len(ws) != 2:
+                            raise ValueError(f"Layer {n} expects 2 weights, the file holds {len(ws)}")
+                        cur[2 * li], cur[2 * li + 1] = ws
+                self.set_weights(cur)
+                return
+            if len(per_layer) != len(mine):
+                raise ValueError(f"You are trying to load a weight file containing {len(per_layer)} layers into a model "
+                                 f"with {len(mine)} layers.")
+            flat = []
+            for n, ws in zip(names, per_layer):
+                if len(ws) != 2:
+                    raise ValueError(f"Layer {n} in the file holds {len(ws)} weight arrays, expected kernel + bias")
+                flat += ws
+            self.set_weights(flat)
+            return
         from safetensors.torch import load_file
         t = load_file(path)
         self.set_weights([t[f"w{i:02d}"] for i in range(len(self._w))])
 
     @classmethod
-    def load(cls, path, input_model=None, **kwargs):
-        from safetensors import safe_open
-        with safe_open(path, framework="pt") as f:
-            cfg = json.loads(f.metadata()["config"])
-        m = cls(input_model=input_model, **cfg, **kwargs)
-        m.load_weights(path)
+    def load(cls, path, by_name=False, input_model=None, **kwargs):
+        """``vxm.networks.VxmDense.load`` (3d_reg.py:277): constructor arguments from the file's model_config, then
+        the weights.  Accepts Keras ``.h5`` files (detected by signature) and this package's safetensors files."""
+        if _is_h5_file(path):
+            from . import h5lite
+            with h5lite.File(path) as f:
+                raw = f.attrs.get("model_config")
+            if raw is None:
+                raise ValueError(f"{path}: no model_config attribute (a save_weights file? build the model and use load_weights)")
+            cfg = json.loads(raw.decode("utf8") if isinstance(raw, bytes) else str(raw))
+            if "config" not in cfg or "inshape" not in cfg["config"]:
+                raise ValueError(f"{path}: model_config does not hold VxmDense constructor arguments "
+                                 "(saved from a plain Keras functional model?)")
+            cfg = dict(cfg["config"])
+            cfg.pop("input_model", None)
+        else:
+            from safetensors import safe_open
+            with safe_open(path, framework="pt") as f:
+                cfg = json.loads(f.metadata()["config"])
+        m = cls(input_model=input_model, **{**cfg, **kwargs})
+        m.load_weights(path, by_name=by_name)
         return m
 
     # ------------------------------------------------------------------ forward

@@ -244,8 +244,11 @@ class SynthMorphTrainer:
         return history
 
 
-def run_training(config, label_maps=None, device="cuda", rank=0, world_size=1, process_group=None, seed=0):
-    """``train_synthmorph.py __main__`` driven by the reference's 44-key JSON config (config/config.json)."""
+def run_training(config, label_maps=None, device="cuda", rank=0, world_size=1, process_group=None, seed=0,
+                 compute_dtype="fp32", checkpoint_ext=".h5"):
+    """``train_synthmorph.py __main__`` driven by the reference's 44-key JSON config (config/config.json).
+    Checkpoints are ``{epoch:04d}.h5`` in the Keras layout like the reference's ModelCheckpoint (:313-317);
+    ``checkpoint_ext='.safetensors'`` selects the native format."""
     from . import data, networks, synth
     data_cfg = config
     if label_maps is None:
@@ -281,12 +284,12 @@ def run_training(config, label_maps=None, device="cuda", rank=0, world_size=1, p
     g2 = synth.labels_to_image(**gen_args, id=1, seed=seed * 2 + 12 + rank * 1000)
     model = networks.VxmDense(in_shape, int_steps=data_cfg["int_steps"], int_resolution=data_cfg["int_res"],
                               svf_resolution=data_cfg["svf_res"], nb_unet_features=(data_cfg["enc"], data_cfg["dec"]),
-                              compute_dtype="fp32", device=device, seed=seed)
+                              compute_dtype=compute_dtype, device=device, seed=seed)
     if data_cfg["bool_init_weights"]:
         model.load_weights(data_cfg["init_weights"])
     model_dir = os.path.join(data_cfg["model_dir"], data_cfg["sub_dir"]) if data_cfg["bool_sub_dir"] else data_cfg["model_dir"]
     os.makedirs(model_dir, exist_ok=True)
-    save_name = os.path.join(model_dir, "{epoch:04d}.safetensors")
+    save_name = os.path.join(model_dir, "{epoch:04d}" + checkpoint_ext)
     trainer = SynthMorphTrainer(model, g1, g2, reg_param=data_cfg["reg_param"], optimizer=Adam(data_cfg["lr"]),
                                 zero_pad_dice=data_cfg["zero_borders_maps"] or data_cfg["zero_borders_maps_val"],
                                 process_group=process_group, world_size=world_size, rank=rank)

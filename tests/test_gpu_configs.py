@@ -29,8 +29,8 @@ def test_c1_training_from_reference_config(dev, tmp_path):
     assert "val_loss" in hist[0] and np.isfinite(hist[0]["val_loss"])
     # ModelCheckpoint-style files: initial save (epoch 0) and the epoch-1 save; reloadable with shape change
     for ep in (0, 1):
-        assert (tmp_path / "models" / f"{ep:04d}.safetensors").exists()
-    m = networks.VxmDense.load(str(tmp_path / "models" / "0001.safetensors"), compute_dtype="fp32")
+        assert (tmp_path / "models" / f"{ep:04d}.h5").exists()
+    m = networks.VxmDense.load(str(tmp_path / "models" / "0001.h5"), compute_dtype="fp32")
     assert m.inshape == (64, 64, 64) and len(m.get_weights()) == 22
     m2 = networks.VxmDense((32, 48, 32), nb_unet_features=(cfg["enc"], cfg["dec"]), int_steps=5, int_resolution=2,
                            svf_resolution=2, compute_dtype="fp32")
@@ -93,8 +93,8 @@ def test_pair_registration_flow_files(dev, tmp_path):
     w = m.get_weights()
     w[-2] = (rng.standard_normal(w[-2].shape) * 2e-2).astype(np.float32)
     m.set_weights(w)
-    m.save(str(tmp_path / "m1.safetensors"))
-    out = registration.run_3d_reg(specs, str(tmp_path / "m1.safetensors"), str(tmp_path / "fx.nii.gz"),
+    m.save(str(tmp_path / "m1.h5"))
+    out = registration.run_3d_reg(specs, str(tmp_path / "m1.h5"), str(tmp_path / "fx.nii.gz"),
                                   str(tmp_path / "mv.nii.gz"), res_dir=str(tmp_path / "res"), compute_dtype="fp32")
     assert out["fixed_proc"].shape == (64, 32, 48) and out["scale"] == 2 and out["warp"].shape == (32, 16, 24, 3)
     moved, aff2, _ = py_utils.read_nifti(str(tmp_path / "res" / "warped_im.nii.gz"))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Command-line twin of the reference's 3d_reg.py (same flags) on the MI355X engine.
 
-python tools/reg3d.py --model-path m.safetensors --config-path config_inference.json \
+python tools/reg3d.py --model-path m.h5 --config-path config_inference.json \
        --fx-img-path fixed.nii.gz --mov-img-path moving.nii.gz [--res-dir res] [--warp-interp linear]
        [--resample-interp linear] [--out-img-name warped_im] [--def-field-name deform_field]
 Extra: --model-path-2 (cascade of bids_two_steps_registration.py), --compute-dtype bf16|fp32|fp32x3.
@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     p = argparse.ArgumentParser()
-    p.add_argument("--model-path", required=True, type=str, help="path to the registration model (.safetensors)")
+    p.add_argument("--model-path", required=True, type=str, help="path to the registration model (Keras .h5 or .safetensors)")
     p.add_argument("--model-path-2", default=None, help="optional second model (two-step cascade)")
     p.add_argument("--config-path", required=True, type=str, help="inference config (config_inference.json schema)")
     p.add_argument("--fx-img-path", required=True, help="path to the fixed image")
