@@ -195,6 +195,14 @@ int mmr_conv3d_k3_cin2_wgrad_f32(const float* src, const float* trg, const float
 /* flow head (Cout = 3) input gradient */
 int mmr_conv3d_k3_cout3_dgrad_f32(const float* dy, const float* w_keras, float* dx, int B, int X, int Y, int Z, int Cin,
                                   void* stream);
+/* Data gradient of a k3 conv fused with the LeakyReLU backward + bias gradient of the layer that produced the
+ * conv's input (replaces mmr_leaky_bwd_bias_f32 after a dgrad; vxm Unet conv blocks):
+ * out = conv(in0; w_packed = transposed/flipped weights) * (ymask < 0 ? alpha : 1); dbias (+)= sum_voxels out.
+ * ymask = activated forward output of that layer, [B,X,Y,Z,Cout] fp32.  dtype: MMR_DT_F32 / F32X3 / F32X1. */
+int64_t mmr_conv3d_k3_dgrad_masked_ws_bytes(int B, int X, int Y, int Z, int Cout);
+int mmr_conv3d_k3_dgrad_masked(const void* in0, int C0, const void* w_packed, float* out, int B, int X, int Y, int Z,
+                               int Cout, const float* ymask, float alpha, float* dbias, void* ws, int accumulate,
+                               int dtype, void* stream);
 /* Keras Adam on one flat parameter buffer: g is multiplied by grad_scale first (1/world after a SUM all-reduce) */
 int mmr_adam_step_f32(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                       float eps, int64_t step, float grad_scale, void* stream);

@@ -52,6 +52,11 @@ struct ConvParams {
     float alpha;
     int out_f32;
     int ntx, nty, ntz;
+    // masked-gradient epilogue (training dgrad): out *= (ymask < 0 ? alpha : 1) and the per-block column sums of
+    // the masked output go to part[blockIdx.x][Cout] -- i.e. the LeakyReLU backward + bias gradient of the layer
+    // that PRODUCED this conv's input, fused so that the gradient never makes a separate elementwise pass
+    const float* ymask;
+    double* part;
 };
 
 template <int DT> struct Elt;
@@ -432,12 +437,14 @@ conv3d_k3_kernel(const ConvParams p)
 
     // ---- epilogue: bias + LeakyReLU, store ----
     const bool store_f32 = (DT != MMR_DT_BF16) || p.out_f32;
+    float* s_col = reinterpret_cast<float*>(smem);  // [WM][BN] column sums (sA is free after the last barrier)
     if constexpr (M16) {
 #pragma unroll
         for (int ni = 0; ni < 2 * NT; ++ni) {
             const int co = ntile * BN + wn * NT * 32 + ni * 16 + r16;
             const bool cok = co < p.Cout;
             const float bv = (cok && p.bias) ? p.bias[co] : 0.f;
+            float csum = 0.f;
 #pragma unroll
             for (int mi = 0; mi < 2 * MT; ++mi) {
                 const int mt = wm * MT + (mi >> 1);
@@ -449,10 +456,28 @@ conv3d_k3_kernel(const ConvParams p)
                         float val = acc16[mi][ni][r] + bv;
                         if (p.leaky && val < 0.f) val *= p.alpha;
                         const size_t o = ((((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz) * p.Cout + co;
+                        if (p.ymask) {
+                            if (p.ymask[o] < 0.f) val *= p.alpha;
+                            csum += val;
+                        }
                         if (store_f32) reinterpret_cast<float*>(p.out)[o] = val;
                         else reinterpret_cast<bf16_t*>(p.out)[o] = f32_to_bf16(val);
                     }
                 }
+            }
+            if (p.ymask) {
+                csum += __shfl_xor(csum, 16);
+                csum += __shfl_xor(csum, 32);
+                if (q16 == 0) s_col[wm * BN + wn * NT * 32 + ni * 16 + r16] = csum;
+            }
+        }
+        if (p.ymask) {
+            __syncthreads();
+            if (tid < BN && ntile * BN + tid < p.Cout) {
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < WM; ++k) t += (double)s_col[k * BN + tid];
+                p.part[(size_t)blockIdx.x * p.Cout + ntile * BN + tid] = t;
             }
         }
         return;
@@ -462,6 +487,7 @@ conv3d_k3_kernel(const ConvParams p)
         const int co = ntile * BN + (wn * NT + n) * 32 + (lane & 31);
         const bool cok = co < p.Cout;
         const float bv = (cok && p.bias) ? p.bias[co] : 0.f;
+        float csum = 0.f;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int mt = wm * MT + m;
@@ -473,11 +499,42 @@ conv3d_k3_kernel(const ConvParams p)
                     float val = acc[m][n][r] + bv;
                     if (p.leaky && val < 0.f) val *= p.alpha;
                     const size_t o = ((((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz) * p.Cout + co;
+                    if (p.ymask) {
+                        if (p.ymask[o] < 0.f) val *= p.alpha;
+                        csum += val;
+                    }
                     if (store_f32) reinterpret_cast<float*>(p.out)[o] = val;
                     else reinterpret_cast<bf16_t*>(p.out)[o] = f32_to_bf16(val);
                 }
             }
         }
+        if (p.ymask) {
+            csum += __shfl_xor(csum, 32);
+            if (h == 0) s_col[wm * BN + (wn * NT + n) * 32 + (lane & 31)] = csum;
+        }
+    }
+    if (p.ymask) {
+        __syncthreads();
+        if (tid < BN && ntile * BN + tid < p.Cout) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < WM; ++k) t += (double)s_col[k * BN + tid];
+            p.part[(size_t)blockIdx.x * p.Cout + ntile * BN + tid] = t;
+        }
+    }
+}
+
+// one wave per channel: ordered strided partial sums, then a wave reduction (fixed order -> reproducible)
+__global__ void __launch_bounds__(64)
+colsum_final_kernel(const double* __restrict__ part, float* __restrict__ db, int C, int nblk, int accumulate)
+{
+    const int c = blockIdx.x;
+    double r = 0.0;
+    for (int k = threadIdx.x; k < nblk; k += 64) r += part[(size_t)k * C + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o);
+    if (threadIdx.x == 0) {
+        if (accumulate) db[c] += (float)r; else db[c] = (float)r;
     }
 }
 
@@ -528,7 +585,7 @@ __global__ void pack_kernel(const float* __restrict__ w, char* __restrict__ wp, 
 }
 
 template <int DT, int WM, int WN, int MT, int NT, int VAR>
-int launch_conv(const ConvParams& p, int ntiles_n, hipStream_t st)
+int launch_conv(const ConvParams& p, int ntiles_n, hipStream_t st, int64_t* nblk_out)
 {
     constexpr int BN = WN * NT * 32;
     constexpr int TXT = WM * MT * 32 / (TY * TZ);
@@ -546,12 +603,13 @@ int launch_conv(const ConvParams& p, int ntiles_n, hipStream_t st)
     q.ntx = (p.X + TXT - 1) / TXT;
     const int64_t nblk = (int64_t)q.B * q.ntx * q.nty * q.ntz;
     if (nblk > 0x7fffffff) return MMR_EINVAL;
+    if (nblk_out) *nblk_out = nblk;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk, ntiles_n), dim3(CONV_THREADS), LDS, st, q);
     return check_launch();
 }
 
 template <int DT>
-int dispatch_conv(const ConvParams& p, hipStream_t st)
+int dispatch_conv(const ConvParams& p, hipStream_t st, int64_t* nblk_out = nullptr)
 {
     const int BN = conv_bn(p.Cout);
     const int nt = (p.Cout + BN - 1) / BN;
@@ -569,27 +627,27 @@ int dispatch_conv(const ConvParams& p, hipStream_t st)
     }
     switch (BN) {
         case 256:
-            if (var == 0) return launch_conv<DT, 2, 4, 4, 2, 0>(p, nt, st);
-            if (var == 2) return launch_conv<DT, 2, 4, 4, 2, 2>(p, nt, st);
-            if (var == 32) return launch_conv<DT, 2, 4, 4, 2, 32>(p, nt, st);
-            if (var == 96) return launch_conv<DT, 2, 4, 4, 2, 96>(p, nt, st);
-            if (var == 1) return launch_conv<DT, 2, 4, 4, 2, 1>(p, nt, st);
-            if (var == 4) return launch_conv<DT, 2, 4, 4, 2, 4>(p, nt, st);
-            if (var == 8) return launch_conv<DT, 2, 4, 4, 2, 8>(p, nt, st);
-            if (var == 12) return launch_conv<DT, 2, 4, 4, 2, 12>(p, nt, st);
-            return launch_conv<DT, 2, 4, 4, 2, 32>(p, nt, st);
+            if (var == 0) return launch_conv<DT, 2, 4, 4, 2, 0>(p, nt, st, nblk_out);
+            if (var == 2) return launch_conv<DT, 2, 4, 4, 2, 2>(p, nt, st, nblk_out);
+            if (var == 32) return launch_conv<DT, 2, 4, 4, 2, 32>(p, nt, st, nblk_out);
+            if (var == 96) return launch_conv<DT, 2, 4, 4, 2, 96>(p, nt, st, nblk_out);
+            if (var == 1) return launch_conv<DT, 2, 4, 4, 2, 1>(p, nt, st, nblk_out);
+            if (var == 4) return launch_conv<DT, 2, 4, 4, 2, 4>(p, nt, st, nblk_out);
+            if (var == 8) return launch_conv<DT, 2, 4, 4, 2, 8>(p, nt, st, nblk_out);
+            if (var == 12) return launch_conv<DT, 2, 4, 4, 2, 12>(p, nt, st, nblk_out);
+            return launch_conv<DT, 2, 4, 4, 2, 32>(p, nt, st, nblk_out);
         // narrow N: 8x8x8-voxel tiles (MT doubled); MMR_CONV_TILE=4 restores the 4x8x8 tiles for A/B runs
         case 128:
-            if (tile8 && var == 32) return launch_conv<DT, 4, 2, 4, 2, 32>(p, nt, st);
-            if (tile8) return launch_conv<DT, 4, 2, 4, 2, 0>(p, nt, st);
-            return launch_conv<DT, 4, 2, 2, 2, 3>(p, nt, st);
+            if (tile8 && var == 32) return launch_conv<DT, 4, 2, 4, 2, 32>(p, nt, st, nblk_out);
+            if (tile8) return launch_conv<DT, 4, 2, 4, 2, 0>(p, nt, st, nblk_out);
+            return launch_conv<DT, 4, 2, 2, 2, 3>(p, nt, st, nblk_out);
         case 64:
-            if (tile8 && var == 32) return launch_conv<DT, 8, 1, 2, 2, 32>(p, nt, st);
-            if (tile8) return launch_conv<DT, 8, 1, 2, 2, 0>(p, nt, st);
-            return launch_conv<DT, 8, 1, 1, 2, 3>(p, nt, st);
+            if (tile8 && var == 32) return launch_conv<DT, 8, 1, 2, 2, 32>(p, nt, st, nblk_out);
+            if (tile8) return launch_conv<DT, 8, 1, 2, 2, 0>(p, nt, st, nblk_out);
+            return launch_conv<DT, 8, 1, 1, 2, 3>(p, nt, st, nblk_out);
         default:
-            if (tile8) return launch_conv<DT, 8, 1, 2, 1, 0>(p, nt, st);
-            return launch_conv<DT, 8, 1, 1, 1, 3>(p, nt, st);
+            if (tile8) return launch_conv<DT, 8, 1, 2, 1, 0>(p, nt, st, nblk_out);
+            return launch_conv<DT, 8, 1, 1, 1, 3>(p, nt, st, nblk_out);
     }
 }
 
@@ -1118,12 +1176,46 @@ extern "C" int mmr_conv3d_k3_fwd(const void* in0, int C0, int up0, const void* i
     p.in0 = (const char*)in0; p.in1 = (const char*)in1; p.wp = (const char*)w_packed; p.bias = bias;
     p.out = (char*)out;
     p.B = B; p.X = X; p.Y = Y; p.Z = Z; p.C0 = C0; p.C1 = C1; p.up0 = up0; p.Cout = Cout;
-    p.leaky = leaky; p.alpha = alpha; p.out_f32 = out_f32;
+    p.leaky = leaky; p.alpha = alpha; p.out_f32 = out_f32; p.ymask = nullptr; p.part = nullptr;
     p.ntx = (X + TX - 1) / TX; p.nty = (Y + TY - 1) / TY; p.ntz = (Z + TZ - 1) / TZ;
     if (dtype == MMR_DT_BF16) return dispatch_conv<MMR_DT_BF16>(p, as_stream(stream));
     if (dtype == MMR_DT_F32X3) return dispatch_conv<MMR_DT_F32X3>(p, as_stream(stream));
     if (dtype == MMR_DT_F32X1) return dispatch_conv<MMR_DT_F32X1>(p, as_stream(stream));
     return dispatch_conv<MMR_DT_F32>(p, as_stream(stream));
+}
+
+extern "C" int64_t mmr_conv3d_k3_dgrad_masked_ws_bytes(int B, int X, int Y, int Z, int Cout)
+{
+    // one row of Cout doubles per spatial block; the narrowest M tile (4x8x8) bounds the block count
+    return (int64_t)B * ((X + TX - 1) / TX) * ((Y + TY - 1) / TY) * ((Z + TZ - 1) / TZ) * Cout * (int64_t)sizeof(double);
+}
+
+// Data gradient of a k3 conv (w_packed = transposed / flipped weights, no bias) whose result is at once pushed
+// through the LeakyReLU backward of the layer that produced the conv's input: out = conv(in) * (ymask < 0 ? alpha : 1),
+// dbias (+)= sum over voxels of out.  ymask = that layer's activated output [B,X,Y,Z,Cout] fp32.
+extern "C" int mmr_conv3d_k3_dgrad_masked(const void* in0, int C0, const void* w_packed, float* out, int B, int X, int Y,
+                                          int Z, int Cout, const float* ymask, float alpha, float* dbias, void* ws,
+                                          int accumulate, int dtype, void* stream)
+{
+    if (!in0 || !w_packed || !out || !ymask || !dbias || !ws || B < 1 || X < 1 || Y < 1 || Z < 1 || Cout < 1 || C0 < 1)
+        return MMR_EINVAL;
+    if (dtype != MMR_DT_F32 && dtype != MMR_DT_F32X3 && dtype != MMR_DT_F32X1) return MMR_EINVAL;
+    if (C0 % 32) return MMR_EINVAL;
+    ConvParams p;
+    p.in0 = (const char*)in0; p.in1 = nullptr; p.wp = (const char*)w_packed; p.bias = nullptr;
+    p.out = (char*)out;
+    p.B = B; p.X = X; p.Y = Y; p.Z = Z; p.C0 = C0; p.C1 = 0; p.up0 = 0; p.Cout = Cout;
+    p.leaky = 0; p.alpha = alpha; p.out_f32 = 1; p.ymask = ymask; p.part = (double*)ws;
+    p.ntx = (X + TX - 1) / TX; p.nty = (Y + TY - 1) / TY; p.ntz = (Z + TZ - 1) / TZ;
+    int64_t nblk = 0;
+    int rc;
+    if (dtype == MMR_DT_F32X3) rc = dispatch_conv<MMR_DT_F32X3>(p, as_stream(stream), &nblk);
+    else if (dtype == MMR_DT_F32X1) rc = dispatch_conv<MMR_DT_F32X1>(p, as_stream(stream), &nblk);
+    else rc = dispatch_conv<MMR_DT_F32>(p, as_stream(stream), &nblk);
+    if (rc != MMR_OK) return rc;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(Cout), dim3(64), 0, as_stream(stream), (const double*)ws, dbias, Cout,
+                       (int)nblk, accumulate);
+    return check_launch();
 }
 
 template <bool X3, bool OUT_BF16>

@@ -191,6 +191,28 @@ def conv3d_k3(in0, w_packed, bias, cout, in1=None, up0=False, leaky=True, alpha=
     return out
 
 
+def conv3d_k3_dgrad_masked(dz, wt_packed, cin, ymask, dbias, alpha=0.2, accumulate=False, x3=False):
+    """d(input) of a k3 conv, already multiplied by LeakyReLU'(ymask) of the layer that produced that input, whose
+    bias gradient (column sums of the result) lands in ``dbias``: the dgrad + leaky_bwd_bias_ pair in one kernel."""
+    _chk(dz, torch.float32, "dz")
+    _chk(ymask, torch.float32, "ymask")
+    _chk(dbias, torch.float32, "dbias")
+    B, X, Y, Z, C0 = dz.shape
+    if tuple(ymask.shape) != (B, X, Y, Z, cin) or dbias.numel() != cin:
+        raise _lib.MmrError(f"ymask {tuple(ymask.shape)} / dbias {tuple(dbias.shape)} do not match {(B, X, Y, Z, cin)}")
+    out = torch.empty((B, X, Y, Z, cin), dtype=torch.float32, device=dz.device)
+    lib = _lib.load()
+    ws = _ws(lib.mmr_conv3d_k3_dgrad_masked_ws_bytes(B, X, Y, Z, int(cin)), dz.device)
+    mode = conv_mode(torch.float32, x3)
+    fam = f"conv3d_k3_mfma_{('f32', 'bf16', 'f32x3', 'f32x1')[mode]}_bn{256 if cin % 256 == 0 else 128 if cin % 128 == 0 else 64 if cin % 64 == 0 else 32}"
+    with _Timed(fam, (C0, int(cin), X, Y, Z), 2.0 * 27 * C0 * cin * B * X * Y * Z):
+        rc = lib.mmr_conv3d_k3_dgrad_masked(dz.data_ptr(), C0, wt_packed.data_ptr(), out.data_ptr(), B, X, Y, Z, int(cin),
+                                            ymask.data_ptr(), float(alpha), dbias.data_ptr(), ws.data_ptr(),
+                                            int(accumulate), mode, _stream())
+    _lib.check(rc, "mmr_conv3d_k3_dgrad_masked")
+    return out
+
+
 def conv3d_k3_cin2(src, trg, w_keras, bias, out_dtype, leaky=True, alpha=0.2, x3=False):
     """First U-Net layer on concat([src, trg]) ([B,X,Y,Z,1] each, f32)."""
     _chk(src, torch.float32, "src")

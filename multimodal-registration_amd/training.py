@@ -136,12 +136,20 @@ class SynthMorphTrainer:
             """g_new_fn(existing_or_None) -> tensor holding the (accumulated) gradient of t."""
             grads[id(t)] = g_new_fn(grads.get(id(t)))
 
+        # activated conv outputs -> index of the layer that made them; a gradient stored for such a tensor may already
+        # be "pre-masked": multiplied by LeakyReLU'(y), its bias gradient written, by the kernel that produced it
+        act = {id(r[5]): r[1] for r in tape if r[0] == "conv" and r[6]}
+        premasked = set()
+
         for rec in reversed(tape):
             kind = rec[0]
             if kind == "conv":
                 _, li, x, up0, in1, y, leaky = rec
                 dy = grads.pop(id(y))
-                dz = ops.leaky_bwd_bias_(y if leaky else None, dy, self.g[2 * li + 1], leaky=leaky)
+                if id(y) in premasked:
+                    dz = dy
+                else:
+                    dz = ops.leaky_bwd_bias_(y if leaky else None, dy, self.g[2 * li + 1], leaky=leaky)
                 ops.conv3d_k3_wgrad(x, dz, self.g[2 * li], in1=in1, up0=up0, x3=self.bwd_x3)
                 C0 = x.shape[-1]
                 C1 = in1.shape[-1] if in1 is not None else 0
@@ -149,7 +157,12 @@ class SynthMorphTrainer:
                     dcat = ops.conv3d_k3_cout3_dgrad(dz, m._w[2 * li])
                 else:
                     wt = ops.pack_conv_weights(m._w[2 * li], torch.float32, transpose_flip=True, x3=self.bwd_x3)
-                    dcat = ops.conv3d_k3(dz, wt, None, C0 + C1, leaky=False, out_f32=True, x3=self.bwd_x3)
+                    if in1 is None and not up0 and id(x) in act and id(x) not in grads:
+                        # x feeds only this conv: fuse its LeakyReLU backward + bias gradient into the dgrad epilogue
+                        dcat = ops.conv3d_k3_dgrad_masked(dz, wt, C0, x, self.g[2 * act[id(x)] + 1], x3=self.bwd_x3)
+                        premasked.add(id(x))
+                    else:
+                        dcat = ops.conv3d_k3(dz, wt, None, C0 + C1, leaky=False, out_f32=True, x3=self.bwd_x3)
                 del dz, dy
                 if in1 is None and not up0:
                     if id(x) in grads:

@@ -336,3 +336,27 @@ def test_optin_bf16_backward(dev):
     assert cos > 0.999, cos
     assert float((ref - got).norm() / ref.norm()) < 3e-2
     assert losses["bf16"][-1] < losses["bf16"][0] - 0.02
+
+
+@pytest.mark.parametrize("shape,Cmid,Cin", [((8, 8, 8), 64, 64), ((6, 10, 12), 32, 128), ((9, 7, 5), 64, 32), ((8, 16, 8), 32, 256)])
+@pytest.mark.parametrize("x3", [False, True, "hi"])
+def test_dgrad_masked_equals_dgrad_then_leaky_bwd(dev, shape, Cmid, Cin, x3):
+    """The fused epilogue (LeakyReLU backward + bias gradient of the producing layer) against the two-kernel path:
+    same conv arithmetic, so the masked values must agree to fp32 rounding and the bias gradient to 1e-5."""
+    import mmr
+    ops = mmr.ops
+    rng = np.random.default_rng(3)
+    dz = _t(rng.standard_normal((1,) + shape + (Cmid,)).astype(np.float32), dev)
+    w = _t((rng.standard_normal((3, 3, 3, Cin, Cmid)) * 0.05).astype(np.float32), dev)  # forward kernel Cin -> Cmid
+    y = _t(rng.standard_normal((1,) + shape + (Cin,)).astype(np.float32), dev)           # activated output of the producer
+    wt = ops.pack_conv_weights(w, torch.float32, transpose_flip=True, x3=x3)
+    ref = ops.conv3d_k3(dz, wt, None, Cin, leaky=False, out_f32=True, x3=x3)
+    db_ref = torch.zeros(Cin, device=dev)
+    ref = ops.leaky_bwd_bias_(y, ref, db_ref, leaky=True)
+    db = torch.full((Cin,), 7.0, device=dev)
+    got = ops.conv3d_k3_dgrad_masked(dz, wt, Cin, y, db, x3=x3)
+    assert torch.equal(got, ref)
+    assert _rel(db, db_ref) < 1e-5
+    db2 = db.clone()
+    ops.conv3d_k3_dgrad_masked(dz, wt, Cin, y, db2, accumulate=True, x3=x3)
+    assert _rel(db2, 2 * db_ref) < 1e-5
