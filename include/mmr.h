@@ -195,6 +195,22 @@ int mmr_conv3d_k3_cin2_wgrad_f32(const float* src, const float* trg, const float
 /* flow head (Cout = 3) input gradient */
 int mmr_conv3d_k3_cout3_dgrad_f32(const float* dy, const float* w_keras, float* dx, int B, int X, int Y, int Z, int Cin,
                                   void* stream);
+/* Concat / upsample and max-pool backward with the same fusion: every gradient contribution to an activated tensor is
+ * multiplied by LeakyReLU'(y) where it is produced and its column sums are added to that layer's bias gradient, so
+ * no separate leaky-backward pass runs.  Channel counts must be multiples of 4 (else MMR_EUNSUPPORTED). */
+int64_t mmr_upcat_bwd_masked_ws_bytes(int C0, int C1);
+int mmr_upcat_bwd_masked_f32(const float* dcat, float* d_in0, float* d_in1, int B, int X, int Y, int Z, int C0, int C1,
+                             int up0, int accumulate_in1, const float* y0, const float* y1, float alpha,
+                             float* dbias0, int acc_b0, float* dbias1, int acc_b1, void* ws, void* stream);
+int64_t mmr_maxpool3d2_bwd_masked_ws_bytes(int C);
+int mmr_maxpool3d2_bwd_masked_f32(const float* x, const float* dpool, float* dx, int B, int X, int Y, int Z, int C,
+                                  int accumulate, int masked, float alpha, float* dbias, int acc_b, void* ws,
+                                  void* stream);
+/* Same fusion for the flow head's data gradient (Cin % 64 == 0, else MMR_EUNSUPPORTED -> use the unfused pair). */
+int64_t mmr_conv3d_k3_cout3_dgrad_masked_ws_bytes(int B, int X, int Y, int Z, int Cin);
+int mmr_conv3d_k3_cout3_dgrad_masked_f32(const float* dy, const float* w_keras, float* dx, int B, int X, int Y, int Z,
+                                         int Cin, const float* ymask, float alpha, float* dbias, void* ws,
+                                         int accumulate, void* stream);
 /* Data gradient of a k3 conv fused with the LeakyReLU backward + bias gradient of the layer that produced the
  * conv's input (replaces mmr_leaky_bwd_bias_f32 after a dgrad; vxm Unet conv blocks):
  * out = conv(in0; w_packed = transposed/flipped weights) * (ymask < 0 ? alpha : 1); dbias (+)= sum_voxels out.

@@ -65,6 +65,12 @@ SIGNATURES = {
     "mmr_leaky_bwd_bias_f32": (I, [P, P, P, P, P, c_int64, I, I, F, I, P]),
     "mmr_conv3d_k3_dgrad_masked_ws_bytes": (c_int64, [I, I, I, I, I]),
     "mmr_conv3d_k3_dgrad_masked": (I, [P, I, P, P, I, I, I, I, I, P, F, P, P, I, I, P]),
+    "mmr_conv3d_k3_cout3_dgrad_masked_ws_bytes": (c_int64, [I, I, I, I, I]),
+    "mmr_conv3d_k3_cout3_dgrad_masked_f32": (I, [P, P, P, I, I, I, I, I, P, F, P, P, I, P]),
+    "mmr_upcat_bwd_masked_ws_bytes": (c_int64, [I, I]),
+    "mmr_upcat_bwd_masked_f32": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P, F, P, I, P, I, P, P]),
+    "mmr_maxpool3d2_bwd_masked_ws_bytes": (c_int64, [I]),
+    "mmr_maxpool3d2_bwd_masked_f32": (I, [P, P, P, I, I, I, I, I, I, I, F, P, I, P, P]),
     "mmr_upcat_bwd_f32": (I, [P, P, P, I, I, I, I, I, I, I, I, P]),
     "mmr_maxpool3d2_bwd_f32": (I, [P, P, P, I, I, I, I, I, I, P]),
     "mmr_conv3d_k3_wgrad_ws_bytes": (c_int64, [I, I, I, I, I, I]),

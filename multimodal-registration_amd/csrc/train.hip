@@ -496,6 +496,154 @@ maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dpool,
     }
 }
 
+// ---- float4 versions with the LeakyReLU backward of the receiving layers fused in ------------------------- //
+// A gradient contribution c to an activated tensor y reaches the layer's pre-activation as c * L'(y) and its bias
+// as sum_v c * L'(y): both are linear in c, so every producer of a contribution can apply them itself and the
+// separate leaky_bwd_bias pass disappears.  y pointers may be null (plain split / routing).
+__device__ __forceinline__ float4 mask4(float4 g, float4 y, float alpha)
+{
+    if (y.x < 0.f) g.x *= alpha;
+    if (y.y < 0.f) g.y *= alpha;
+    if (y.z < 0.f) g.z *= alpha;
+    if (y.w < 0.f) g.w *= alpha;
+    return g;
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// block-level column sums: thread t < T owns channel quad t % Q; part[blockIdx.x][4 Q] in double
+__device__ __forceinline__ void quad_colsum(float4 cs, float4* s4, int Q, int T, double* __restrict__ part)
+{
+    __syncthreads();
+    s4[threadIdx.x] = cs;
+    __syncthreads();
+    if ((int)threadIdx.x < Q) {
+        double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+        for (int k = threadIdx.x; k < T; k += Q) {
+            const float4 v = s4[k];
+            r0 += (double)v.x; r1 += (double)v.y; r2 += (double)v.z; r3 += (double)v.w;
+        }
+        double* o = part + (int64_t)blockIdx.x * (4 * Q) + 4 * threadIdx.x;
+        o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3;
+    }
+}
+
+__global__ void __launch_bounds__(TB)
+upcat_bwd_v4_kernel(const float* __restrict__ dcat, float* __restrict__ d0, float* __restrict__ d1, int B, int X, int Y,
+                    int Z, int C0, int C1, int up0, int acc1, const float* __restrict__ y0, const float* __restrict__ y1,
+                    float alpha, double* __restrict__ part0, double* __restrict__ part1)
+{
+    __shared__ float4 s4[TB];
+    const int C = C0 + C1;
+    const int64_t nvox = (int64_t)B * X * Y * Z;
+    const int tid = threadIdx.x;
+    if (C1 > 0) {  // skip channels: d1 (+)= dcat[..., C0:] * L'(y1)
+        const int Q = C1 >> 2, T = (TB / Q) * Q, vpb = T / Q;
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < T) {
+            const int q = tid % Q;
+            for (int64_t v = (int64_t)blockIdx.x * vpb + tid / Q; v < nvox; v += (int64_t)gridDim.x * vpb) {
+                float4 g = *reinterpret_cast<const float4*>(dcat + v * C + C0 + 4 * q);
+                if (y1) {
+                    g = mask4(g, *reinterpret_cast<const float4*>(y1 + v * C1 + 4 * q), alpha);
+                    cs = add4(cs, g);
+                }
+                float4* o = reinterpret_cast<float4*>(d1 + v * C1 + 4 * q);
+                *o = acc1 ? add4(*o, g) : g;
+            }
+        }
+        if (y1) quad_colsum(cs, s4, Q, T, part1);
+    }
+    const int Q = C0 >> 2, T = (TB / Q) * Q, vpb = T / Q;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!up0) {
+        if (tid < T) {
+            const int q = tid % Q;
+            for (int64_t v = (int64_t)blockIdx.x * vpb + tid / Q; v < nvox; v += (int64_t)gridDim.x * vpb) {
+                float4 g = *reinterpret_cast<const float4*>(dcat + v * C + 4 * q);
+                if (y0) {
+                    g = mask4(g, *reinterpret_cast<const float4*>(y0 + v * C0 + 4 * q), alpha);
+                    cs = add4(cs, g);
+                }
+                *reinterpret_cast<float4*>(d0 + v * C0 + 4 * q) = g;
+            }
+        }
+    } else {
+        const int Xh = X / 2, Yh = Y / 2, Zh = Z / 2;
+        const int64_t nh = (int64_t)B * Xh * Yh * Zh;
+        if (tid < T) {
+            const int q = tid % Q;
+            for (int64_t v = (int64_t)blockIdx.x * vpb + tid / Q; v < nh; v += (int64_t)gridDim.x * vpb) {
+                int64_t r = v;
+                const int z = (int)(r % Zh); r /= Zh;
+                const int y = (int)(r % Yh); r /= Yh;
+                const int x = (int)(r % Xh);
+                const int b = (int)(r / Xh);
+                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int gx = 2 * x + (k >> 2), gy = 2 * y + ((k >> 1) & 1), gz = 2 * z + (k & 1);
+                    g = add4(g, *reinterpret_cast<const float4*>(dcat + ((((int64_t)b * X + gx) * Y + gy) * Z + gz) * C + 4 * q));
+                }
+                if (y0) {
+                    g = mask4(g, *reinterpret_cast<const float4*>(y0 + v * C0 + 4 * q), alpha);
+                    cs = add4(cs, g);
+                }
+                *reinterpret_cast<float4*>(d0 + v * C0 + 4 * q) = g;
+            }
+        }
+    }
+    if (y0) quad_colsum(cs, s4, Q, T, part0);
+}
+
+// dx (+)= route(dpool) to the first maximum of each 2x2x2 window, times L'(x at that maximum) when `masked`
+// (x is then the activated output whose gradient dx is)
+__global__ void __launch_bounds__(TB)
+maxpool_bwd_v4_kernel(const float* __restrict__ x, const float* __restrict__ dpool, float* __restrict__ dx, int B, int X,
+                      int Y, int Z, int C, int accumulate, int masked, float alpha, double* __restrict__ part)
+{
+    __shared__ float4 s4[TB];
+    const int Xo = X / 2, Yo = Y / 2, Zo = Z / 2;
+    const int64_t nh = (int64_t)B * Xo * Yo * Zo;
+    const int Q = C >> 2, T = (TB / Q) * Q, vpb = T / Q;
+    const int tid = threadIdx.x;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < T) {
+        const int q = tid % Q;
+        for (int64_t v = (int64_t)blockIdx.x * vpb + tid / Q; v < nh; v += (int64_t)gridDim.x * vpb) {
+            int64_t r = v;
+            const int z = (int)(r % Zo); r /= Zo;
+            const int y = (int)(r % Yo); r /= Yo;
+            const int xx = (int)(r % Xo);
+            const int b = (int)(r / Xo);
+            float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            int k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+            int64_t offs[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int gx = 2 * xx + (k >> 2), gy = 2 * y + ((k >> 1) & 1), gz = 2 * z + (k & 1);
+                offs[k] = ((((int64_t)b * X + gx) * Y + gy) * Z + gz) * C + 4 * q;
+                const float4 val = *reinterpret_cast<const float4*>(x + offs[k]);
+                if (val.x > best.x) { best.x = val.x; k0 = k; }
+                if (val.y > best.y) { best.y = val.y; k1 = k; }
+                if (val.z > best.z) { best.z = val.z; k2 = k; }
+                if (val.w > best.w) { best.w = val.w; k3 = k; }
+            }
+            float4 g = *reinterpret_cast<const float4*>(dpool + v * C + 4 * q);
+            if (masked) {
+                g = mask4(g, best, alpha);
+                cs = add4(cs, g);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float4 val = make_float4(k == k0 ? g.x : 0.f, k == k1 ? g.y : 0.f, k == k2 ? g.z : 0.f, k == k3 ? g.w : 0.f);
+                float4* o = reinterpret_cast<float4*>(dx + offs[k]);
+                *o = accumulate ? add4(*o, val) : val;
+            }
+        }
+    }
+    if (masked) quad_colsum(cs, s4, Q, T, part);
+}
+
 // ------------------------------------------------------------------------- //
 // wgrad on the matrix cores: dW[tap][ci][co] = sum_v Xpad[v+tap][ci] * dZ[v][co]
 // ------------------------------------------------------------------------- //
@@ -1238,7 +1386,8 @@ smallch_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ 
 // (M = 256 voxels per block, N = 64 input channels per blockIdx.y, K = 81 padded to 82)
 __global__ void __launch_bounds__(SM_THREADS, 2)
 flow_dgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int B, int X,
-                       int Y, int Z, int Cin, int ntx, int nty, int ntz)
+                       int Y, int Z, int Cin, int ntx, int nty, int ntz, const float* __restrict__ ymask, float alpha,
+                       double* __restrict__ part)
 {
     __shared__ float sS[W_HROWS * 3];
     __shared__ float sW[82 * 64];
@@ -1294,6 +1443,7 @@ flow_dgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ w
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
+    float cs0 = 0.f, cs1 = 0.f;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1301,11 +1451,31 @@ flow_dgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ w
             const int v = wave * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             const int gx = x0 + (v >> 6), gy = y0 + ((v >> 3) & 7), gz = z0 + (v & 7);
             if (gx < X && gy < Y && gz < Z) {
-                float* o = dx + ((size_t)b * nvox + ((size_t)gx * Y + gy) * Z + gz) * Cin + cb * 64 + (lane & 31);
-                o[0] = acc[m][0][r];
-                o[32] = acc[m][1][r];
+                const size_t e = ((size_t)b * nvox + ((size_t)gx * Y + gy) * Z + gz) * Cin + cb * 64 + (lane & 31);
+                float v0 = acc[m][0][r], v1 = acc[m][1][r];
+                if (ymask) {  // LeakyReLU backward of the layer that made the flow head's input, and its bias gradient
+                    if (ymask[e] < 0.f) v0 *= alpha;
+                    if (ymask[e + 32] < 0.f) v1 *= alpha;
+                    cs0 += v0;
+                    cs1 += v1;
+                }
+                dx[e] = v0;
+                dx[e + 32] = v1;
             }
         }
+    if (ymask) {
+        cs0 += __shfl_xor(cs0, 32);
+        cs1 += __shfl_xor(cs1, 32);
+        __syncthreads();  // every wave is past its sS reads
+        if (h == 0) {
+            sS[wave * 64 + (lane & 31)] = cs0;
+            sS[wave * 64 + 32 + (lane & 31)] = cs1;
+        }
+        __syncthreads();
+        if (tid < 64)
+            part[(size_t)blockIdx.x * Cin + cb * 64 + tid] =
+                (double)sS[tid] + (double)sS[64 + tid] + (double)sS[128 + tid] + (double)sS[192 + tid];
+    }
 }
 
 // ------------------------------------------------------------------------- //
@@ -1520,13 +1690,75 @@ extern "C" int mmr_leaky_bwd_bias_f32(const float* y, const float* dy, float* dz
     return check_launch();
 }
 
+namespace {
+constexpr int V4_BLOCKS = 2048;
+inline bool v4_ok(int c) { return c > 0 && c % 4 == 0 && c <= 4 * TB; }
+}  // namespace
+
+extern "C" int64_t mmr_upcat_bwd_masked_ws_bytes(int C0, int C1)
+{
+    return (int64_t)V4_BLOCKS * (C0 + C1) * (int64_t)sizeof(double);
+}
+
+// Split the gradient of concat([up2(in0) | in0, in1]) and push each part through the LeakyReLU backward of the layer
+// that produced it: d_in0 = pool-sum(dcat[..., :C0]) * L'(y0), d_in1 (+)= dcat[..., C0:] * L'(y1); the bias gradients
+// of those layers (+)= the column sums.  y0 / y1 (activated outputs, same shapes as d_in0 / d_in1) may be null.
+extern "C" int mmr_upcat_bwd_masked_f32(const float* dcat, float* d_in0, float* d_in1, int B, int X, int Y, int Z, int C0,
+                                        int C1, int up0, int accumulate_in1, const float* y0, const float* y1, float alpha,
+                                        float* dbias0, int acc_b0, float* dbias1, int acc_b1, void* ws, void* stream)
+{
+    if (!dcat || !d_in0 || B < 1 || X < 1 || Y < 1 || Z < 1 || C0 < 1 || C1 < 0 || (C1 > 0 && !d_in1)) return MMR_EINVAL;
+    if (up0 && ((X | Y | Z) & 1)) return MMR_EINVAL;
+    if ((y0 && !dbias0) || (y1 && (!dbias1 || C1 == 0)) || ((y0 || y1) && !ws)) return MMR_EINVAL;
+    if (!v4_ok(C0) || (C1 > 0 && !v4_ok(C1))) return MMR_EUNSUPPORTED;
+    const int64_t nvox = (int64_t)B * X * Y * Z;
+    int64_t g = (nvox * ((C0 + C1) / 4) + TB * 4 - 1) / (TB * 4);
+    const int nblk = (int)(g < 1 ? 1 : (g > V4_BLOCKS ? V4_BLOCKS : g));
+    double* part0 = (double*)ws;
+    double* part1 = part0 + (int64_t)V4_BLOCKS * C0;
+    hipLaunchKernelGGL(upcat_bwd_v4_kernel, dim3(nblk), dim3(TB), 0, as_stream(stream), dcat, d_in0, d_in1, B, X, Y, Z, C0,
+                       C1, up0, accumulate_in1, y0, y1, alpha, part0, part1);
+    if (y0)
+        hipLaunchKernelGGL(bias_final_kernel, dim3(C0), dim3(64), 0, as_stream(stream), (const double*)part0, dbias0, C0,
+                           nblk, acc_b0);
+    if (y1)
+        hipLaunchKernelGGL(bias_final_kernel, dim3(C1), dim3(64), 0, as_stream(stream), (const double*)part1, dbias1, C1,
+                           nblk, acc_b1);
+    return check_launch();
+}
+
 extern "C" int mmr_upcat_bwd_f32(const float* dcat, float* d_in0, float* d_in1, int B, int X, int Y, int Z, int C0,
                                  int C1, int up0, int accumulate_in1, void* stream)
 {
     if (!dcat || !d_in0 || B < 1 || X < 1 || Y < 1 || Z < 1 || C0 < 1 || C1 < 0 || (C1 > 0 && !d_in1)) return MMR_EINVAL;
     if (up0 && ((X | Y | Z) & 1)) return MMR_EINVAL;
+    if (v4_ok(C0) && (C1 == 0 || v4_ok(C1)))
+        return mmr_upcat_bwd_masked_f32(dcat, d_in0, d_in1, B, X, Y, Z, C0, C1, up0, accumulate_in1, nullptr, nullptr, 0.f,
+                                        nullptr, 0, nullptr, 0, nullptr, stream);
     hipLaunchKernelGGL(upcat_bwd_kernel, dim3(stream_grid((int64_t)B * X * Y * Z * (C0 + C1), TB)), dim3(TB), 0,
                        as_stream(stream), dcat, d_in0, d_in1, B, X, Y, Z, C0, C1, up0, accumulate_in1);
+    return check_launch();
+}
+
+extern "C" int64_t mmr_maxpool3d2_bwd_masked_ws_bytes(int C) { return (int64_t)V4_BLOCKS * C * (int64_t)sizeof(double); }
+
+// MaxPooling3D(2) backward; with ymask semantics (`masked`): x is the activated output of a LeakyReLU layer and dx its
+// PRE-activation gradient: the routed value is multiplied by L'(x at the maximum) and dbias (+)= its column sums.
+extern "C" int mmr_maxpool3d2_bwd_masked_f32(const float* x, const float* dpool, float* dx, int B, int X, int Y, int Z,
+                                             int C, int accumulate, int masked, float alpha, float* dbias, int acc_b,
+                                             void* ws, void* stream)
+{
+    if (!x || !dpool || !dx || B < 1 || X < 2 || Y < 2 || Z < 2 || C < 1 || ((X | Y | Z) & 1)) return MMR_EINVAL;
+    if (masked && (!dbias || !ws)) return MMR_EINVAL;
+    if (!v4_ok(C)) return MMR_EUNSUPPORTED;
+    const int64_t nh = (int64_t)B * (X / 2) * (Y / 2) * (Z / 2);
+    int64_t g = (nh * (C / 4) + TB - 1) / TB;
+    const int nblk = (int)(g < 1 ? 1 : (g > V4_BLOCKS ? V4_BLOCKS : g));
+    hipLaunchKernelGGL(maxpool_bwd_v4_kernel, dim3(nblk), dim3(TB), 0, as_stream(stream), x, dpool, dx, B, X, Y, Z, C,
+                       accumulate, masked, alpha, (double*)ws);
+    if (masked)
+        hipLaunchKernelGGL(bias_final_kernel, dim3(C), dim3(64), 0, as_stream(stream), (const double*)ws, dbias, C, nblk,
+                           acc_b);
     return check_launch();
 }
 
@@ -1534,6 +1766,8 @@ extern "C" int mmr_maxpool3d2_bwd_f32(const float* x, const float* dpool, float*
                                       int accumulate, void* stream)
 {
     if (!x || !dpool || !dx || B < 1 || X < 2 || Y < 2 || Z < 2 || C < 1 || ((X | Y | Z) & 1)) return MMR_EINVAL;
+    if (v4_ok(C))
+        return mmr_maxpool3d2_bwd_masked_f32(x, dpool, dx, B, X, Y, Z, C, accumulate, 0, 0.f, nullptr, 0, nullptr, stream);
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(stream_grid((int64_t)B * (X / 2) * (Y / 2) * (Z / 2) * C, TB)),
                        dim3(TB), 0, as_stream(stream), x, dpool, dx, B, X, Y, Z, C, accumulate);
     return check_launch();
@@ -1723,7 +1957,7 @@ extern "C" int mmr_conv3d_k3_cout3_dgrad_f32(const float* dy, const float* w_ker
         const int64_t nblk = (int64_t)B * ntx * nty * ntz;
         if (nblk > 0x7fffffff) return MMR_EINVAL;
         hipLaunchKernelGGL(flow_dgrad_mfma_kernel, dim3((unsigned)nblk, Cin / 64), dim3(SM_THREADS), 0, as_stream(stream),
-                           dy, w_keras, dx, B, X, Y, Z, Cin, ntx, nty, ntz);
+                           dy, w_keras, dx, B, X, Y, Z, Cin, ntx, nty, ntz, (const float*)nullptr, 0.f, (double*)nullptr);
         return check_launch();
     }
     if (Cin % 4 == 0) {
@@ -1743,6 +1977,30 @@ extern "C" int mmr_conv3d_k3_cout3_dgrad_f32(const float* dy, const float* w_ker
     }
     hipLaunchKernelGGL(dgrad_cout3_generic_kernel, dim3(stream_grid((int64_t)B * X * Y * Z * Cin, TB)), dim3(TB), lds,
                        as_stream(stream), dy, w_keras, dx, B, X, Y, Z, Cin);
+    return check_launch();
+}
+
+extern "C" int64_t mmr_conv3d_k3_cout3_dgrad_masked_ws_bytes(int B, int X, int Y, int Z, int Cin)
+{
+    return (int64_t)B * ((X + W_TX - 1) / W_TX) * ((Y + W_TY - 1) / W_TY) * ((Z + W_TZ - 1) / W_TZ) * Cin * (int64_t)sizeof(double);
+}
+
+// flow-head data gradient fused with the LeakyReLU backward + bias gradient of the layer feeding the flow head:
+// dx = dgrad(dy) * (ymask < 0 ? alpha : 1); dbias (+)= sum_voxels dx.  Cin must be a multiple of 64 (MFMA kernel).
+extern "C" int mmr_conv3d_k3_cout3_dgrad_masked_f32(const float* dy, const float* w_keras, float* dx, int B, int X, int Y,
+                                                    int Z, int Cin, const float* ymask, float alpha, float* dbias, void* ws,
+                                                    int accumulate, void* stream)
+{
+    if (!dy || !w_keras || !dx || !ymask || !dbias || !ws || B < 1 || X < 1 || Y < 1 || Z < 1 || Cin < 1 || Cin > 512)
+        return MMR_EINVAL;
+    if (Cin % 64) return MMR_EUNSUPPORTED;
+    const int ntx = (X + W_TX - 1) / W_TX, nty = (Y + W_TY - 1) / W_TY, ntz = (Z + W_TZ - 1) / W_TZ;
+    const int64_t nblk = (int64_t)B * ntx * nty * ntz;
+    if (nblk > 0x7fffffff) return MMR_EINVAL;
+    hipLaunchKernelGGL(flow_dgrad_mfma_kernel, dim3((unsigned)nblk, Cin / 64), dim3(SM_THREADS), 0, as_stream(stream),
+                       dy, w_keras, dx, B, X, Y, Z, Cin, ntx, nty, ntz, ymask, alpha, (double*)ws);
+    hipLaunchKernelGGL(bias_final_kernel, dim3(Cin), dim3(64), 0, as_stream(stream), (const double*)ws, dbias, Cin,
+                       (int)nblk, accumulate);
     return check_launch();
 }
 

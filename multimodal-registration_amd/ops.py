@@ -544,8 +544,11 @@ def leaky_bwd_bias_(y, dy, dbias, leaky=True, alpha=0.2, accumulate=False):
     return dy
 
 
-def upcat_bwd(dcat, C0, C1, up0, d_in1=None):
-    """Split d concat([up2(in0)|in0, in1]) -> (d_in0, d_in1); accumulates into d_in1 when given."""
+def upcat_bwd(dcat, C0, C1, up0, d_in1=None, y0=None, dbias0=None, acc_b0=False, y1=None, dbias1=None, acc_b1=False,
+              alpha=0.2):
+    """Split d concat([up2(in0)|in0, in1]) -> (d_in0, d_in1); accumulates into d_in1 when given.  With y0 / y1 (the
+    activated outputs of the layers that made in0 / in1) the parts come out multiplied by LeakyReLU'(y) and
+    dbias0 / dbias1 (+)= their column sums (fused leaky_bwd_bias_)."""
     _chk(dcat, torch.float32, "dcat")
     B, X, Y, Z, C = dcat.shape
     s0 = (B, X // 2, Y // 2, Z // 2, C0) if up0 else (B, X, Y, Z, C0)
@@ -553,21 +556,45 @@ def upcat_bwd(dcat, C0, C1, up0, d_in1=None):
     acc = d_in1 is not None
     if C1 > 0 and d_in1 is None:
         d_in1 = torch.empty((B, X, Y, Z, C1), dtype=torch.float32, device=dcat.device)
-    rc = _lib.load().mmr_upcat_bwd_f32(dcat.data_ptr(), d0.data_ptr(), d_in1.data_ptr() if C1 > 0 else None,
-                                       B, X, Y, Z, C0, C1, int(up0), int(acc), _stream())
-    _lib.check(rc, "mmr_upcat_bwd_f32")
+    lib = _lib.load()
+    if y0 is None and y1 is None:
+        rc = lib.mmr_upcat_bwd_f32(dcat.data_ptr(), d0.data_ptr(), d_in1.data_ptr() if C1 > 0 else None,
+                                   B, X, Y, Z, C0, C1, int(up0), int(acc), _stream())
+        _lib.check(rc, "mmr_upcat_bwd_f32")
+        return d0, d_in1
+    for t, shp, nm in ((y0, s0, "y0"), (y1, (B, X, Y, Z, C1), "y1")):
+        if t is not None:
+            _chk(t, torch.float32, nm)
+            if tuple(t.shape) != tuple(shp):
+                raise _lib.MmrError(f"{nm} shape {tuple(t.shape)} != {tuple(shp)}")
+    ws = _ws(lib.mmr_upcat_bwd_masked_ws_bytes(C0, C1), dcat.device)
+    rc = lib.mmr_upcat_bwd_masked_f32(dcat.data_ptr(), d0.data_ptr(), d_in1.data_ptr() if C1 > 0 else None, B, X, Y, Z, C0, C1,
+                                      int(up0), int(acc), y0.data_ptr() if y0 is not None else None,
+                                      y1.data_ptr() if y1 is not None else None, float(alpha),
+                                      dbias0.data_ptr() if y0 is not None else None, int(acc_b0),
+                                      dbias1.data_ptr() if y1 is not None else None, int(acc_b1), ws.data_ptr(), _stream())
+    _lib.check(rc, "mmr_upcat_bwd_masked_f32")
     return d0, d_in1
 
 
-def maxpool3d2_bwd(x, dpool, dx=None):
+def maxpool3d2_bwd(x, dpool, dx=None, masked=False, dbias=None, acc_b=False, alpha=0.2):
+    """dx (+)= dpool routed to each window's first maximum; ``masked``: x is an activated LeakyReLU output, dx its
+    pre-activation gradient -> routed values times LeakyReLU'(x), dbias (+)= their column sums."""
     _chk(x, torch.float32, "x")
     _chk(dpool, torch.float32, "dpool")
     B, X, Y, Z, C = x.shape
     acc = dx is not None
     if dx is None:
         dx = torch.empty_like(x)
-    rc = _lib.load().mmr_maxpool3d2_bwd_f32(x.data_ptr(), dpool.data_ptr(), dx.data_ptr(), B, X, Y, Z, C, int(acc), _stream())
-    _lib.check(rc, "mmr_maxpool3d2_bwd_f32")
+    lib = _lib.load()
+    if not masked:
+        rc = lib.mmr_maxpool3d2_bwd_f32(x.data_ptr(), dpool.data_ptr(), dx.data_ptr(), B, X, Y, Z, C, int(acc), _stream())
+        _lib.check(rc, "mmr_maxpool3d2_bwd_f32")
+        return dx
+    ws = _ws(lib.mmr_maxpool3d2_bwd_masked_ws_bytes(C), x.device)
+    rc = lib.mmr_maxpool3d2_bwd_masked_f32(x.data_ptr(), dpool.data_ptr(), dx.data_ptr(), B, X, Y, Z, C, int(acc), 1,
+                                           float(alpha), dbias.data_ptr(), int(acc_b), ws.data_ptr(), _stream())
+    _lib.check(rc, "mmr_maxpool3d2_bwd_masked_f32")
     return dx
 
 
@@ -607,6 +634,27 @@ def conv3d_k3_cout3_dgrad(dy, w_keras):
     dx = torch.empty((B, X, Y, Z, Cin), dtype=torch.float32, device=dy.device)
     rc = _lib.load().mmr_conv3d_k3_cout3_dgrad_f32(dy.data_ptr(), w_keras.data_ptr(), dx.data_ptr(), B, X, Y, Z, Cin, _stream())
     _lib.check(rc, "mmr_conv3d_k3_cout3_dgrad_f32")
+    return dx
+
+
+def conv3d_k3_cout3_dgrad_masked(dy, w_keras, ymask, dbias, alpha=0.2, accumulate=False):
+    """Flow-head dgrad with the producing layer's LeakyReLU backward + bias gradient fused (Cin % 64 == 0);
+    returns None when the fused kernel does not cover the width (caller uses the unfused pair)."""
+    _chk(dy, torch.float32, "dy")
+    _chk(ymask, torch.float32, "ymask")
+    B, X, Y, Z, _ = dy.shape
+    Cin = w_keras.shape[3]
+    if Cin % 64:
+        return None
+    if tuple(ymask.shape) != (B, X, Y, Z, Cin):
+        raise _lib.MmrError(f"ymask {tuple(ymask.shape)} does not match {(B, X, Y, Z, Cin)}")
+    dx = torch.empty((B, X, Y, Z, Cin), dtype=torch.float32, device=dy.device)
+    lib = _lib.load()
+    ws = _ws(lib.mmr_conv3d_k3_cout3_dgrad_masked_ws_bytes(B, X, Y, Z, Cin), dy.device)
+    rc = lib.mmr_conv3d_k3_cout3_dgrad_masked_f32(dy.data_ptr(), w_keras.data_ptr(), dx.data_ptr(), B, X, Y, Z, Cin,
+                                                  ymask.data_ptr(), float(alpha), dbias.data_ptr(), ws.data_ptr(),
+                                                  int(accumulate), _stream())
+    _lib.check(rc, "mmr_conv3d_k3_cout3_dgrad_masked_f32")
     return dx
 
 

@@ -132,14 +132,30 @@ class SynthMorphTrainer:
         first = tape[-1]
         grads[id(first[5])] = dflow
 
-        def give(t, g_new_fn):
-            """g_new_fn(existing_or_None) -> tensor holding the (accumulated) gradient of t."""
-            grads[id(t)] = g_new_fn(grads.get(id(t)))
-
-        # activated conv outputs -> index of the layer that made them; a gradient stored for such a tensor may already
-        # be "pre-masked": multiplied by LeakyReLU'(y), its bias gradient written, by the kernel that produced it
+        # activated conv outputs -> index of the layer that made them.  A gradient stored for such a tensor is kept
+        # "pre-masked" where possible: every kernel that produces a contribution multiplies it by LeakyReLU'(y) and adds
+        # its column sums to that layer's bias gradient (both are linear in the contribution), so no separate
+        # leaky-backward pass runs over it.
         act = {id(r[5]): r[1] for r in tape if r[0] == "conv" and r[6]}
-        premasked = set()
+        act.update({id(r[4]): 0 for r in tape if r[0] == "conv0"})
+        premasked, bias_started = set(), set()
+
+        def want_mask(t):
+            return (t is not None and id(t) in act and t.shape[-1] % 4 == 0
+                    and (id(t) not in grads or id(t) in premasked))
+
+        def bias_of(t):
+            """(bias-gradient view, accumulate?) of the layer that produced t; the first contribution writes."""
+            l = act[id(t)]
+            acc = l in bias_started
+            bias_started.add(l)
+            return self.g[2 * l + 1], acc
+
+        def add_grad(t, g):
+            if id(t) in grads:
+                ops.axpy_(grads[id(t)], g, 1.0)
+            else:
+                grads[id(t)] = g
 
         for rec in reversed(tape):
             kind = rec[0]
@@ -153,39 +169,54 @@ class SynthMorphTrainer:
                 ops.conv3d_k3_wgrad(x, dz, self.g[2 * li], in1=in1, up0=up0, x3=self.bwd_x3)
                 C0 = x.shape[-1]
                 C1 = in1.shape[-1] if in1 is not None else 0
+                plain = in1 is None and not up0
                 if m.plan[li][0] == "flow":
-                    dcat = ops.conv3d_k3_cout3_dgrad(dz, m._w[2 * li])
+                    dcat = None
+                    if plain and want_mask(x) and C0 % 64 == 0:
+                        db, acc = bias_of(x)
+                        dcat = ops.conv3d_k3_cout3_dgrad_masked(dz, m._w[2 * li], x, db, accumulate=acc)
+                        premasked.add(id(x))
+                    if dcat is None:
+                        dcat = ops.conv3d_k3_cout3_dgrad(dz, m._w[2 * li])
                 else:
                     wt = ops.pack_conv_weights(m._w[2 * li], torch.float32, transpose_flip=True, x3=self.bwd_x3)
-                    if in1 is None and not up0 and id(x) in act and id(x) not in grads:
-                        # x feeds only this conv: fuse its LeakyReLU backward + bias gradient into the dgrad epilogue
-                        dcat = ops.conv3d_k3_dgrad_masked(dz, wt, C0, x, self.g[2 * act[id(x)] + 1], x3=self.bwd_x3)
+                    if plain and want_mask(x):
+                        db, acc = bias_of(x)
+                        dcat = ops.conv3d_k3_dgrad_masked(dz, wt, C0, x, db, accumulate=acc, x3=self.bwd_x3)
                         premasked.add(id(x))
                     else:
                         dcat = ops.conv3d_k3(dz, wt, None, C0 + C1, leaky=False, out_f32=True, x3=self.bwd_x3)
                 del dz, dy
-                if in1 is None and not up0:
-                    if id(x) in grads:
-                        ops.axpy_(grads[id(x)], dcat, 1.0)
-                    else:
-                        grads[id(x)] = dcat
+                if plain:
+                    add_grad(x, dcat)
                 else:
-                    d0, d1 = ops.upcat_bwd(dcat, C0, C1, up0, d_in1=grads.get(id(in1)) if in1 is not None else None)
-                    if id(x) in grads:
-                        ops.axpy_(grads[id(x)], d0, 1.0)
-                    else:
-                        grads[id(x)] = d0
+                    kw = {}
+                    if want_mask(x) and (C1 == 0 or C1 % 4 == 0):
+                        kw["y0"] = x
+                        kw["dbias0"], kw["acc_b0"] = bias_of(x)
+                        premasked.add(id(x))
+                    if in1 is not None and want_mask(in1) and C0 % 4 == 0:
+                        kw["y1"] = in1
+                        kw["dbias1"], kw["acc_b1"] = bias_of(in1)
+                        premasked.add(id(in1))
+                    d0, d1 = ops.upcat_bwd(dcat, C0, C1, up0, d_in1=grads.get(id(in1)) if in1 is not None else None, **kw)
+                    add_grad(x, d0)
                     if in1 is not None:
                         grads[id(in1)] = d1
                     del dcat
             elif kind == "pool":
                 _, x, p = rec
                 dp = grads.pop(id(p))
-                give(x, lambda ex: ops.maxpool3d2_bwd(x, dp, dx=ex))
+                if want_mask(x):
+                    db, acc = bias_of(x)
+                    grads[id(x)] = ops.maxpool3d2_bwd(x, dp, dx=grads.get(id(x)), masked=True, dbias=db, acc_b=acc)
+                    premasked.add(id(x))
+                else:
+                    grads[id(x)] = ops.maxpool3d2_bwd(x, dp, dx=grads.get(id(x)))
             elif kind == "conv0":
                 _, li, src, trg, y = rec
                 dy = grads.pop(id(y))
-                dz = ops.leaky_bwd_bias_(y, dy, self.g[1], leaky=True)
+                dz = dy if id(y) in premasked else ops.leaky_bwd_bias_(y, dy, self.g[1], leaky=True)
                 ops.conv3d_k3_cin2_wgrad(src, trg, dz, self.g[0])
         return grads
 

@@ -360,3 +360,70 @@ def test_dgrad_masked_equals_dgrad_then_leaky_bwd(dev, shape, Cmid, Cin, x3):
     db2 = db.clone()
     ops.conv3d_k3_dgrad_masked(dz, wt, Cin, y, db2, accumulate=True, x3=x3)
     assert _rel(db2, 2 * db_ref) < 1e-5
+
+
+@pytest.mark.parametrize("shape,Cin", [((8, 8, 8), 64), ((5, 9, 11), 128)])
+def test_flow_dgrad_masked_equals_unfused(dev, shape, Cin):
+    import mmr
+    ops = mmr.ops
+    rng = np.random.default_rng(4)
+    dy = _t(rng.standard_normal((1,) + shape + (3,)).astype(np.float32), dev)
+    w = _t((rng.standard_normal((3, 3, 3, Cin, 3)) * 0.1).astype(np.float32), dev)
+    y = _t(rng.standard_normal((1,) + shape + (Cin,)).astype(np.float32), dev)
+    db_ref = torch.zeros(Cin, device=dev)
+    ref = ops.leaky_bwd_bias_(y, ops.conv3d_k3_cout3_dgrad(dy, w), db_ref, leaky=True)
+    db = torch.full((Cin,), -3.0, device=dev)
+    got = ops.conv3d_k3_cout3_dgrad_masked(dy, w, y, db)
+    assert torch.equal(got, ref) and _rel(db, db_ref) < 1e-5
+    assert ops.conv3d_k3_cout3_dgrad_masked(dy[..., :3], w[:, :, :, :32], y[..., :32].contiguous(), db[:32]) is None
+
+
+@pytest.mark.parametrize("shape,C0,C1,up0", [((8, 8, 8), 32, 32, True), ((6, 10, 4), 64, 32, True), ((5, 7, 3), 32, 0, False),
+                                              ((4, 6, 8), 36, 20, True)])
+def test_upcat_bwd_masked_equals_unfused(dev, shape, C0, C1, up0):
+    import mmr
+    ops = mmr.ops
+    rng = np.random.default_rng(5)
+    dcat = _t(rng.standard_normal((1,) + shape + (C0 + C1,)).astype(np.float32), dev)
+    s0 = tuple(s // 2 for s in shape) if up0 else shape
+    y0 = _t(rng.standard_normal((1,) + s0 + (C0,)).astype(np.float32), dev)
+    y1 = _t(rng.standard_normal((1,) + shape + (C1,)).astype(np.float32), dev) if C1 else None
+    prev1 = _t(rng.standard_normal((1,) + shape + (C1,)).astype(np.float32), dev) if C1 else None
+    # reference: scalar split, then the separate leaky-backward passes
+    r0, r1 = ops.upcat_bwd(dcat, C0, C1, up0)
+    b0_ref, b1_ref = torch.zeros(C0, device=dev), torch.zeros(max(C1, 1), device=dev)
+    r0 = ops.leaky_bwd_bias_(y0, r0.clone(), b0_ref)
+    if C1:
+        r1 = ops.leaky_bwd_bias_(y1, r1.clone(), b1_ref[:C1]) + prev1
+    b0 = torch.full((C0,), 5.0, device=dev)
+    b1 = torch.full((max(C1, 1),), 1.0, device=dev)
+    g0, g1 = ops.upcat_bwd(dcat, C0, C1, up0, d_in1=prev1.clone() if C1 else None, y0=y0, dbias0=b0, acc_b0=False,
+                           y1=y1, dbias1=b1[:C1] if C1 else None, acc_b1=True)
+    assert _rel(g0, r0) < 1e-6 and _rel(b0, b0_ref) < 1e-5
+    if C1:
+        assert _rel(g1, r1) < 1e-6 and _rel(b1[:C1] - 1.0, b1_ref[:C1]) < 1e-4
+    # plain (unmasked) float4 path against the torch formulation
+    p0, p1 = ops.upcat_bwd(dcat, C0, C1, up0)
+    d = dcat[..., :C0]
+    if up0:
+        d = d.reshape(1, s0[0], 2, s0[1], 2, s0[2], 2, C0).sum(dim=(2, 4, 6))
+    assert _rel(p0, d) < 1e-6 and (not C1 or torch.equal(p1, dcat[..., C0:].contiguous()))
+
+
+@pytest.mark.parametrize("shape,C", [((8, 8, 8), 32), ((6, 4, 10), 64), ((4, 4, 4), 20)])
+def test_maxpool_bwd_masked_equals_unfused(dev, shape, C):
+    import mmr
+    ops = mmr.ops
+    rng = np.random.default_rng(6)
+    x = _t(rng.standard_normal((1,) + shape + (C,)).astype(np.float32), dev)
+    dp = _t(rng.standard_normal((1,) + tuple(s // 2 for s in shape) + (C,)).astype(np.float32), dev)
+    prev = _t(rng.standard_normal((1,) + shape + (C,)).astype(np.float32), dev)
+    xt = x.detach().clone().requires_grad_(True)
+    torch.nn.functional.max_pool3d(xt.permute(0, 4, 1, 2, 3), 2).permute(0, 2, 3, 4, 1).backward(dp)
+    plain = ops.maxpool3d2_bwd(x, dp)
+    assert torch.equal(plain, xt.grad)
+    db_ref = torch.zeros(C, device=dev)
+    ref = ops.leaky_bwd_bias_(x, plain.clone(), db_ref) + prev
+    db = torch.full((C,), 2.0, device=dev)
+    got = ops.maxpool3d2_bwd(x, dp, dx=prev.clone(), masked=True, dbias=db, acc_b=True)
+    assert _rel(got, ref) < 1e-6 and _rel(db - 2.0, db_ref) < 1e-4
