@@ -238,33 +238,62 @@ grad_l2_bwd_kernel(const float* __restrict__ f, float* __restrict__ df, int B, i
 }
 
 // ------------------------------------------------------------------------- //
-// adjoint of the align-corners resize: d_in[corner] += w * mul * d_out      //
+// adjoint of the align-corners resize: d_in[j] = sum_i w_i(j) * mul * d_out[i]
+// Gather form: the sampling positions i * st are a regular lattice, so the outputs whose two corners touch input
+// index j are a short index range per axis (about 2 / st of them); no atomics -> one pass, fixed summation order.
+// The weights are recomputed exactly as the forward computes them (axis_setup_g of (float)i * st).
 // ------------------------------------------------------------------------- //
+__device__ __forceinline__ void axis_range(int j, float st, int no, int& lo, int& hi)
+{
+    if (st > 0.f) {
+        lo = (int)floorf((float)(j - 1) / st) - 1;
+        hi = (int)ceilf((float)(j + 1) / st) + 1;
+        lo = lo < 0 ? 0 : lo;
+        hi = hi > no - 1 ? no - 1 : hi;
+    } else {  // single input sample along this axis: every output reads index 0
+        lo = 0;
+        hi = no - 1;
+    }
+}
+__device__ __forceinline__ float axis_weight(int i, float st, int maxi, int j)
+{
+    const AxisG a = axis_setup_g((float)i * st, maxi);
+    return (a.i0 == j ? a.w0 : 0.f) + (a.i1 == j ? a.w1 : 0.f);
+}
+
 __global__ void __launch_bounds__(TB)
 resize_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int B, int X, int Y, int Z, int C, int Xo,
                   int Yo, int Zo, float stx, float sty, float stz, float mul)
 {
     const int64_t nvo = (int64_t)Xo * Yo * Zo, nvi = (int64_t)X * Y * Z;
-    const int64_t total = (int64_t)B * nvo * C;
-    const int64_t sz = C, sy = (int64_t)Z * C, sx = (int64_t)Y * Z * C;
+    const int64_t total = (int64_t)B * nvi * C;
     for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TB) {
         const int c = (int)(i % C);
         const int64_t v = i / C;
-        const int64_t b = v / nvo;
-        const int64_t r = v - b * nvo;
-        const int z = (int)(r % Zo), y = (int)((r / Zo) % Yo), x = (int)(r / ((int64_t)Zo * Yo));
-        const AxisG ax = axis_setup_g((float)x * stx, X - 1);
-        const AxisG ay = axis_setup_g((float)y * sty, Y - 1);
-        const AxisG az = axis_setup_g((float)z * stz, Z - 1);
-        const float g = dout[i] * mul;
-        float* base = din + b * nvi * C + c;
-#pragma unroll
-        for (int cc = 0; cc < 8; ++cc) {
-            const int qx = cc >> 2, qy = (cc >> 1) & 1, qz = cc & 1;
-            const float w = ((qx ? ax.w1 : ax.w0) * (qy ? ay.w1 : ay.w0)) * (qz ? az.w1 : az.w0);
-            if (w != 0.f)
-                atomicAdd(base + (qx ? ax.i1 : ax.i0) * sx + (qy ? ay.i1 : ay.i0) * sy + (qz ? az.i1 : az.i0) * sz, w * g);
+        const int64_t b = v / nvi;
+        const int64_t r = v - b * nvi;
+        const int z = (int)(r % Z), y = (int)((r / Z) % Y), x = (int)(r / ((int64_t)Z * Y));
+        int x0, x1, y0, y1, z0, z1;
+        axis_range(x, stx, Xo, x0, x1);
+        axis_range(y, sty, Yo, y0, y1);
+        axis_range(z, stz, Zo, z0, z1);
+        const float* src = dout + b * nvo * C + c;
+        float acc = 0.f;
+        for (int ix = x0; ix <= x1; ++ix) {
+            const float wx = axis_weight(ix, stx, X - 1, x);
+            if (wx == 0.f) continue;
+            for (int iy = y0; iy <= y1; ++iy) {
+                const float wy = axis_weight(iy, sty, Y - 1, y);
+                if (wy == 0.f) continue;
+                const float wxy = wx * wy;
+                const float* row = src + ((int64_t)ix * Yo + iy) * Zo * C;
+                for (int iz = z0; iz <= z1; ++iz) {
+                    const float wz = axis_weight(iz, stz, Z - 1, z);
+                    if (wz != 0.f) acc += (wxy * wz) * (row[(int64_t)iz * C] * mul);
+                }
+            }
         }
+        din[i] = acc;
     }
 }
 
@@ -1589,11 +1618,10 @@ extern "C" int mmr_resize_trilinear_bwd_f32(const float* dout, float* din, int B
 {
     if (!dout || !din || B < 1 || X < 1 || Y < 1 || Z < 1 || C < 1 || Xo < 1 || Yo < 1 || Zo < 1) return MMR_EINVAL;
     hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(din, 0, (size_t)B * X * Y * Z * C * sizeof(float), st) != hipSuccess) return MMR_EHIP;
     const float stx = (float)(X - 1) / (float)(Xo > 1 ? Xo - 1 : 1);
     const float sty = (float)(Y - 1) / (float)(Yo > 1 ? Yo - 1 : 1);
     const float stz = (float)(Z - 1) / (float)(Zo > 1 ? Zo - 1 : 1);
-    hipLaunchKernelGGL(resize_bwd_kernel, dim3(stream_grid((int64_t)B * Xo * Yo * Zo * C, TB)), dim3(TB), 0, st, dout,
+    hipLaunchKernelGGL(resize_bwd_kernel, dim3(stream_grid((int64_t)B * X * Y * Z * C, TB)), dim3(TB), 0, st, dout,
                        din, B, X, Y, Z, C, Xo, Yo, Zo, stx, sty, stz, mul);
     return check_launch();
 }

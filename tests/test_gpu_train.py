@@ -92,7 +92,8 @@ def test_grad_l2_bwd(dev):
     assert _rel(mmr.ops.grad_l2_bwd(_t(flow, dev), 0.7), f.grad) < 1e-5
 
 
-@pytest.mark.parametrize("shape,new,mul", [((6, 8, 10), (12, 16, 20), 2.0), ((12, 16, 20), (6, 8, 10), 0.5), ((5, 7, 4), (9, 8, 11), 1.5)])
+@pytest.mark.parametrize("shape,new,mul", [((6, 8, 10), (12, 16, 20), 2.0), ((12, 16, 20), (6, 8, 10), 0.5), ((5, 7, 4), (9, 8, 11), 1.5),
+                                           ((1, 4, 3), (3, 8, 5), 1.0), ((4, 5, 6), (16, 5, 1), 1.0)])
 def test_resize_bwd_is_adjoint(dev, shape, new, mul):
     import mmr
     from oracle import grad_torch as G
