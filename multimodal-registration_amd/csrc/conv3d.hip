@@ -1073,6 +1073,183 @@ flow_head_kernel(const char* __restrict__ in, const float* __restrict__ w, const
     }
 }
 
+// ---- flow head, marching variant ----------------------------------------------------------------------- //
+// Same P-GEMM, but the block walks along x: one input plane of an 8(y) x 16(z) haloed patch = 128 rows = 8 MFMA
+// row tiles exactly is contracted per step (P plane [128][81] in LDS, double buffered), and every output thread
+// (6 x 14 voxels x 3 channels = 252 of 256 threads) keeps the accumulators of the three output planes that
+// input plane touches in registers: plane xp feeds out[xp+1] (dx = 0 taps), out[xp] (dx = 1), out[xp-1] (dx = 2,
+// which completes it).  Halo redundancy of the input reads / P-GEMM drops from 3.75x (2x4x8 tiles) to 1.52x
+// (+2 planes per x segment); one barrier per plane.
+constexpr int MH_TY = 6, MH_TZ = 14, MH_HY = 8, MH_HZ = 16;
+constexpr int MH_ROWS = MH_HY * MH_HZ;  // 128
+constexpr int MH_THREADS = 256;
+
+template <bool X3>
+__global__ void __launch_bounds__(MH_THREADS, 1)
+flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+                       float* __restrict__ out, int B, int X, int Y, int Z, int Cin, int nseg, int seglen, int nty, int ntz,
+                       int ntiles)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nkc = Cin / 8;                       // 16-B k-chunks
+    char* sW = smem;                               // [X3 ? 2 : 1][nkc][96][16 B]
+    float* sP = reinterpret_cast<float*>(smem + (X3 ? 2 : 1) * nkc * 96 * 16);  // [2][128][81]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q16 = lane >> 4;
+    constexpr int ES = X3 ? 4 : 2;
+
+    for (int i = tid; i < nkc * 96; i += MH_THREADS) {  // weight image W'[k = ci][n = tap*3+co], once per block
+        const int n = i % 96, kc = i / 96;
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float f0 = 0.f, f1 = 0.f;
+            if (n < 81) {
+                f0 = w[((size_t)(n / 3) * Cin + kc * 8 + 2 * e) * 3 + n % 3];
+                f1 = w[((size_t)(n / 3) * Cin + kc * 8 + 2 * e + 1) * 3 + n % 3];
+            }
+            const bf16_t h0 = f32_to_bf16(f0), h1 = f32_to_bf16(f1);
+            hi[e] = (unsigned)h0 | ((unsigned)h1 << 16);
+            if constexpr (X3) {
+                const bf16_t l0 = f32_to_bf16(f0 - bf16_to_f32(h0)), l1 = f32_to_bf16(f1 - bf16_to_f32(h1));
+                lo[e] = (unsigned)l0 | ((unsigned)l1 << 16);
+            }
+        }
+        *reinterpret_cast<uint4*>(sW + (size_t)i * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        if constexpr (X3) *reinterpret_cast<uint4*>(sW + (size_t)(nkc * 96 + i) * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+    // output role of this thread
+    const int co = tid % 3, ov = tid / 3;
+    const int vz = ov % MH_TZ, vy = ov / MH_TZ;  // vy < 6 for tid < 252
+    const bool outthr = tid < MH_TY * MH_TZ * 3;
+    const float bco = bias ? bias[co] : 0.f;
+    const int nsteps = Cin / 32;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tzi = t % ntz; t /= ntz;
+        const int tyi = t % nty; t /= nty;
+        const int seg = t % nseg;
+        const int b = t / nseg;
+        const int y0 = tyi * MH_TY, z0 = tzi * MH_TZ;
+        const int xs = seg * seglen, xe = (xs + seglen < X) ? xs + seglen : X;
+        // this wave's two row tiles = halo y-rows hy = 2 wave + j, lane r16 = halo z
+        size_t rowoff[2];
+        bool rowok[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gy = y0 + 2 * wave + j - 1, gz = z0 + r16 - 1;
+            rowok[j] = gy >= 0 && gy < Y && gz >= 0 && gz < Z;
+            rowoff[j] = rowok[j] ? ((size_t)gy * Z + gz) * Cin * ES + q16 * (X3 ? 32 : 16) : 0;
+        }
+        const int gyo = y0 + vy, gzo = z0 + vz;
+        const bool ook = outthr && gyo < Y && gzo < Z;
+        float a_prev = 0.f, a_cur = 0.f;
+        for (int xp = xs - 1; xp <= xe; ++xp) {
+            const int buf = (xp - xs + 1) & 1;
+            float* P = sP + buf * (MH_ROWS * 81);
+            const bool inside = xp >= 0 && xp < X;
+            if (inside) {
+                const char* plane = in + ((size_t)b * X + xp) * Y * Z * Cin * ES;
+                f32x4 acc[2][6];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int n = 0; n < 6; ++n) acc[j][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                uint4 raw0[2], raw1[2];
+                auto load_raw = [&](int s, uint4* r0, uint4* r1) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        r0[j] = make_uint4(0, 0, 0, 0);
+                        r1[j] = make_uint4(0, 0, 0, 0);
+                        if (rowok[j]) {
+                            r0[j] = *reinterpret_cast<const uint4*>(plane + rowoff[j] + (size_t)s * (X3 ? 128 : 64));
+                            if constexpr (X3) r1[j] = *reinterpret_cast<const uint4*>(plane + rowoff[j] + (size_t)s * 128 + 16);
+                        }
+                    }
+                };
+                load_raw(0, raw0, raw1);
+                for (int s = 0; s < nsteps; ++s) {
+                    uint4 ah[2], al[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if constexpr (X3) {
+                            const unsigned u[8] = {raw0[j].x, raw0[j].y, raw0[j].z, raw0[j].w, raw1[j].x, raw1[j].y, raw1[j].z, raw1[j].w};
+                            unsigned hh[4], ll[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float f0 = __uint_as_float(u[2 * e]), f1 = __uint_as_float(u[2 * e + 1]);
+                                const bf16_t h0 = f32_to_bf16(f0), h1 = f32_to_bf16(f1);
+                                const bf16_t l0 = f32_to_bf16(f0 - bf16_to_f32(h0)), l1 = f32_to_bf16(f1 - bf16_to_f32(h1));
+                                hh[e] = (unsigned)h0 | ((unsigned)h1 << 16);
+                                ll[e] = (unsigned)l0 | ((unsigned)l1 << 16);
+                            }
+                            ah[j] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+                            al[j] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+                        } else {
+                            ah[j] = raw0[j];
+                        }
+                    }
+                    if (s + 1 < nsteps) load_raw(s + 1, raw0, raw1);
+#pragma unroll
+                    for (int n = 0; n < 6; ++n) {
+                        const int boff = ((4 * s + q16) * 96 + n * 16 + r16) * 16;
+                        const uint4 bh = *reinterpret_cast<const uint4*>(sW + boff);
+                        if constexpr (X3) {
+                            const uint4 bl = *reinterpret_cast<const uint4*>(sW + (size_t)nkc * 96 * 16 + boff);
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[j]),
+                                                                                  __builtin_bit_cast(bf16x8, bh), acc[j][n], 0, 0, 0);
+                                acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[j]),
+                                                                                  __builtin_bit_cast(bf16x8, bl), acc[j][n], 0, 0, 0);
+                                acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[j]),
+                                                                                  __builtin_bit_cast(bf16x8, bh), acc[j][n], 0, 0, 0);
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[j]),
+                                                                                  __builtin_bit_cast(bf16x8, bh), acc[j][n], 0, 0, 0);
+                        }
+                    }
+                }
+                // C/D layout of the 16x16 tile: lane holds rows q16*4 + r (= halo z), column r16
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int n = 0; n < 6; ++n) {
+                        const int col = n * 16 + r16;
+                        if (col < 81) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) P[((2 * wave + j) * 16 + q16 * 4 + r) * 81 + col] = acc[j][n][r];
+                        }
+                    }
+            }
+            __syncthreads();  // P[buf] complete; the other buffer may still be read by slower waves (not written here)
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+            if (inside && outthr) {
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dz = 0; dz < 3; ++dz) {
+                        const float* pr = P + ((vy + dy) * MH_HZ + vz + dz) * 81 + (dy * 3 + dz) * 3 + co;
+                        c0 += pr[0];
+                        c1 += pr[27];
+                        c2 += pr[54];
+                    }
+            }
+            const float done = a_prev + c2;  // out plane xp - 1 has now seen its three input planes
+            if (ook && xp - 1 >= xs && xp - 1 < xe)
+                out[((((size_t)b * X + (xp - 1)) * Y + gyo) * Z + gzo) * 3 + co] = done;
+            a_prev = a_cur + c1;
+            a_cur = bco + c0;
+        }
+        __syncthreads();  // the next tile's first plane reuses buffer 0/1
+    }
+}
+
 // ---- MaxPooling3D(2), 16 B per lane -------------------------------------- //
 template <int DT>
 __global__ void __launch_bounds__(256)
@@ -1277,22 +1454,48 @@ extern "C" int mmr_conv3d_k3_cout3_fwd(const void* in, const float* w_keras, con
     if (!in || !w_keras || !out || B < 1 || X < 1 || Y < 1 || Z < 1 || Cin < 32 || Cin % 32) return MMR_EINVAL;
     if (dtype != MMR_DT_BF16 && dtype != MMR_DT_F32X3) return MMR_EUNSUPPORTED;
     const int npl = dtype == MMR_DT_F32X3 ? 2 : 1;
+    static int use_march = -1;  // MMR_FLOW_HEAD=tile selects the older 2x4x8-tile kernel (A/B runs)
+    if (use_march < 0) {
+        const char* e = getenv("MMR_FLOW_HEAD");
+        use_march = (e && e[0] == 't') ? 0 : 1;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipSuccess;
+        const void* ks[4] = {reinterpret_cast<const void*>(flow_head_kernel<false>), reinterpret_cast<const void*>(flow_head_kernel<true>),
+                             reinterpret_cast<const void*>(flow_head_march_kernel<false>),
+                             reinterpret_cast<const void*>(flow_head_march_kernel<true>)};
+        for (int i = 0; i < 4 && e == hipSuccess; ++i)
+            e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
+        attr_set = true;
+    }
+    const int lds_m = npl * (Cin / 8) * 96 * 16 + 2 * MH_ROWS * 81 * 4;
+    if (use_march && lds_m <= 160 * 1024) {
+        const int nty = (Y + MH_TY - 1) / MH_TY, ntz = (Z + MH_TZ - 1) / MH_TZ;
+        const int64_t tyz = (int64_t)B * nty * ntz;
+        int nseg = (int)((1024 + tyz - 1) / tyz);  // enough tiles to balance 256 persistent blocks
+        if (nseg > (X + 7) / 8) nseg = (X + 7) / 8;
+        if (nseg < 1) nseg = 1;
+        const int seglen = (X + nseg - 1) / nseg;
+        nseg = (X + seglen - 1) / seglen;
+        const int64_t nt = tyz * nseg;
+        if (nt > 0x7fffffff) return MMR_EINVAL;
+        const int grid = nt < 256 ? (int)nt : 256;
+        if (dtype == MMR_DT_F32X3)
+            hipLaunchKernelGGL(flow_head_march_kernel<true>, dim3(grid), dim3(MH_THREADS), lds_m, as_stream(stream),
+                               (const char*)in, w_keras, bias, out, B, X, Y, Z, Cin, nseg, seglen, nty, ntz, (int)nt);
+        else
+            hipLaunchKernelGGL(flow_head_march_kernel<false>, dim3(grid), dim3(MH_THREADS), lds_m, as_stream(stream),
+                               (const char*)in, w_keras, bias, out, B, X, Y, Z, Cin, nseg, seglen, nty, ntz, (int)nt);
+        return check_launch();
+    }
     const int lds = npl * (Cin / 8) * 96 * 16 + FH_ROWS * 81 * 4;
     if (lds > 160 * 1024) return MMR_EUNSUPPORTED;
     const int ntx = (X + FH_TX - 1) / FH_TX, nty = (Y + FH_TY - 1) / FH_TY, ntz = (Z + FH_TZ - 1) / FH_TZ;
     const int64_t nt = (int64_t)B * ntx * nty * ntz;
     if (nt > 0x7fffffff) return MMR_EINVAL;
     const int grid = nt < 1024 ? (int)nt : 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flow_head_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(flow_head_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
-        attr_set = true;
-    }
     if (dtype == MMR_DT_F32X3)
         hipLaunchKernelGGL(flow_head_kernel<true>, dim3(grid), dim3(FH_THREADS), lds, as_stream(stream), (const char*)in,
                            w_keras, bias, out, B, X, Y, Z, Cin, ntx, nty, ntz, (int)nt);
