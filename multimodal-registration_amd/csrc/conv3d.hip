@@ -178,7 +178,9 @@ conv3d_k3_kernel(const ConvParams p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
     }
-    // 16x16x32 path: 16-row tiles = 2 y-rows x 8 z; lane l: row l & 15, k-chunk l >> 4
+    // 16x16x32 path: 16-voxel tiles = 2 y-rows x 8 z; operand lane l: voxel (or cout) l & 15, k-chunk l >> 4.
+    // The product is formed TRANSPOSED (weights as the MFMA's A operand, voxels as B): the C/D layout then gives
+    // lane (r16, q16) the four consecutive couts q16*4 .. +3 of voxel r16 -> 8-B (bf16) / 16-B (fp32) stores.
     f32x4 acc16[M16 ? 2 * MT : 1][M16 ? 2 * NT : 1];
     int a16_off[M16 ? 2 * MT : 1], b16_off[M16 ? 2 * NT : 1];
     const int r16 = lane & 15, q16 = lane >> 4;
@@ -311,12 +313,12 @@ conv3d_k3_kernel(const ConvParams p)
                     for (int ni = 0; ni < 2 * NT; ++ni) {
                         if constexpr (LO) {
                             acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8, al16[mi]), __builtin_bit_cast(bf16x8, bh16[ni]), acc16[mi][ni], 0, 0, 0);
+                                __builtin_bit_cast(bf16x8, bh16[ni]), __builtin_bit_cast(bf16x8, al16[mi]), acc16[mi][ni], 0, 0, 0);
                             acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8, ah16[mi]), __builtin_bit_cast(bf16x8, bl16[ni]), acc16[mi][ni], 0, 0, 0);
+                                __builtin_bit_cast(bf16x8, bl16[ni]), __builtin_bit_cast(bf16x8, ah16[mi]), acc16[mi][ni], 0, 0, 0);
                         }
                         acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, ah16[mi]), __builtin_bit_cast(bf16x8, bh16[ni]), acc16[mi][ni], 0, 0, 0);
+                            __builtin_bit_cast(bf16x8, bh16[ni]), __builtin_bit_cast(bf16x8, ah16[mi]), acc16[mi][ni], 0, 0, 0);
                     }
             } else {
 #pragma unroll
@@ -333,7 +335,7 @@ conv3d_k3_kernel(const ConvParams p)
 #pragma unroll
                         for (int ni = 0; ni < 2 * NT; ++ni)
                             acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8, fa16[mi]), __builtin_bit_cast(bf16x8, fb16[ni]), acc16[mi][ni], 0, 0, 0);
+                                __builtin_bit_cast(bf16x8, fb16[ni]), __builtin_bit_cast(bf16x8, fa16[mi]), acc16[mi][ni], 0, 0, 0);
                 }
             }
         } else if constexpr (X3) {
@@ -441,34 +443,67 @@ conv3d_k3_kernel(const ConvParams p)
     if constexpr (M16) {
 #pragma unroll
         for (int ni = 0; ni < 2 * NT; ++ni) {
-            const int co = ntile * BN + wn * NT * 32 + ni * 16 + r16;
-            const bool cok = co < p.Cout;
-            const float bv = (cok && p.bias) ? p.bias[co] : 0.f;
-            float csum = 0.f;
+            const int cl = wn * NT * 32 + ni * 16 + q16 * 4;  // first of this lane's 4 couts inside the N tile
+            const int co = ntile * BN + cl;
+            const bool vec = (co + 3 < p.Cout) && !(p.Cout & 3);
+            float bv[4], csum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = (p.bias && co + r < p.Cout) ? p.bias[co + r] : 0.f;
 #pragma unroll
             for (int mi = 0; mi < 2 * MT; ++mi) {
                 const int mt = wm * MT + (mi >> 1);
+                const int gx = x0 + (mt >> 1), gy = y0 + (mt & 1) * 4 + 2 * (mi & 1) + (r16 >> 3), gz = z0 + (r16 & 7);
+                if (co < p.Cout && gx < p.X && gy < p.Y && gz < p.Z) {
+                    const size_t o = ((((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz) * p.Cout + co;
+                    float val[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = q16 * 4 + r;  // C/D row of the 16x16 tile
-                    const int gx = x0 + (mt >> 1), gy = y0 + (mt & 1) * 4 + 2 * (mi & 1) + (row >> 3), gz = z0 + (row & 7);
-                    if (cok && gx < p.X && gy < p.Y && gz < p.Z) {
-                        float val = acc16[mi][ni][r] + bv;
-                        if (p.leaky && val < 0.f) val *= p.alpha;
-                        const size_t o = ((((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz) * p.Cout + co;
+                    for (int r = 0; r < 4; ++r) {
+                        val[r] = acc16[mi][ni][r] + bv[r];
+                        if (p.leaky && val[r] < 0.f) val[r] *= p.alpha;
+                    }
+                    if (vec) {
                         if (p.ymask) {
-                            if (p.ymask[o] < 0.f) val *= p.alpha;
-                            csum += val;
+                            const float4 ym = *reinterpret_cast<const float4*>(p.ymask + o);
+                            if (ym.x < 0.f) val[0] *= p.alpha;
+                            if (ym.y < 0.f) val[1] *= p.alpha;
+                            if (ym.z < 0.f) val[2] *= p.alpha;
+                            if (ym.w < 0.f) val[3] *= p.alpha;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) csum[r] += val[r];
                         }
-                        if (store_f32) reinterpret_cast<float*>(p.out)[o] = val;
-                        else reinterpret_cast<bf16_t*>(p.out)[o] = f32_to_bf16(val);
+                        if (store_f32) {
+                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(val[0], val[1], val[2], val[3]);
+                        } else {
+                            uint2 pk;
+                            pk.x = (unsigned)f32_to_bf16(val[0]) | ((unsigned)f32_to_bf16(val[1]) << 16);
+                            pk.y = (unsigned)f32_to_bf16(val[2]) | ((unsigned)f32_to_bf16(val[3]) << 16);
+                            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + o) = pk;
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (co + r < p.Cout) {
+                                if (p.ymask) {
+                                    if (p.ymask[o + r] < 0.f) val[r] *= p.alpha;
+                                    csum[r] += val[r];
+                                }
+                                if (store_f32) reinterpret_cast<float*>(p.out)[o + r] = val[r];
+                                else reinterpret_cast<bf16_t*>(p.out)[o + r] = f32_to_bf16(val[r]);
+                            }
+                        }
                     }
                 }
             }
             if (p.ymask) {
-                csum += __shfl_xor(csum, 16);
-                csum += __shfl_xor(csum, 32);
-                if (q16 == 0) s_col[wm * BN + wn * NT * 32 + ni * 16 + r16] = csum;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float c = csum[r];
+                    c += __shfl_xor(c, 1);
+                    c += __shfl_xor(c, 2);
+                    c += __shfl_xor(c, 4);
+                    c += __shfl_xor(c, 8);
+                    if (r16 == 0) s_col[wm * BN + cl + r] = c;
+                }
             }
         }
         if (p.ymask) {
