@@ -441,70 +441,95 @@ conv3d_k3_kernel(const ConvParams p)
     const bool store_f32 = (DT != MMR_DT_BF16) || p.out_f32;
     float* s_col = reinterpret_cast<float*>(smem);  // [WM][BN] column sums (sA is free after the last barrier)
     if constexpr (M16) {
+        // Physical weight column ni*16 + i of this wave's 64-column group holds cout (i >> 2)*16 + ni*4 + (i & 3)
+        // (pack_kernel, conv_cout_of_col): lane (r16, q16) therefore owns the 16 CONSECUTIVE couts q16*16 .. +15
+        // of voxel r16 across its four accumulator tiles -> 32-B (bf16) / 64-B (fp32) per lane, full 128-B lines.
+        static_assert(NT == 2, "16x16x32 path: 64 columns per wave");
+        const int cl = wn * 64 + q16 * 16;
+        const int co = ntile * BN + cl;
+        const bool vec = (co + 15 < p.Cout) && !(p.Cout & 7);
+        float bv[4][4], csum[4][4];
 #pragma unroll
-        for (int ni = 0; ni < 2 * NT; ++ni) {
-            const int cl = wn * NT * 32 + ni * 16 + q16 * 4;  // first of this lane's 4 couts inside the N tile
-            const int co = ntile * BN + cl;
-            const bool vec = (co + 3 < p.Cout) && !(p.Cout & 3);
-            float bv[4], csum[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bv[r] = (p.bias && co + r < p.Cout) ? p.bias[co + r] : 0.f;
+            for (int r = 0; r < 4; ++r) {
+                bv[ni][r] = (p.bias && co + ni * 4 + r < p.Cout) ? p.bias[co + ni * 4 + r] : 0.f;
+                csum[ni][r] = 0.f;
+            }
 #pragma unroll
-            for (int mi = 0; mi < 2 * MT; ++mi) {
-                const int mt = wm * MT + (mi >> 1);
-                const int gx = x0 + (mt >> 1), gy = y0 + (mt & 1) * 4 + 2 * (mi & 1) + (r16 >> 3), gz = z0 + (r16 & 7);
-                if (co < p.Cout && gx < p.X && gy < p.Y && gz < p.Z) {
-                    const size_t o = ((((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz) * p.Cout + co;
-                    float val[4];
+        for (int mi = 0; mi < 2 * MT; ++mi) {
+            const int mt = wm * MT + (mi >> 1);
+            const int gx = x0 + (mt >> 1), gy = y0 + (mt & 1) * 4 + 2 * (mi & 1) + (r16 >> 3), gz = z0 + (r16 & 7);
+            if (co < p.Cout && gx < p.X && gy < p.Y && gz < p.Z) {
+                const size_t o = ((((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz) * p.Cout + co;
+                float val[4][4];
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        val[r] = acc16[mi][ni][r] + bv[r];
-                        if (p.leaky && val[r] < 0.f) val[r] *= p.alpha;
+                        val[ni][r] = acc16[mi][ni][r] + bv[ni][r];
+                        if (p.leaky && val[ni][r] < 0.f) val[ni][r] *= p.alpha;
                     }
-                    if (vec) {
-                        if (p.ymask) {
-                            const float4 ym = *reinterpret_cast<const float4*>(p.ymask + o);
-                            if (ym.x < 0.f) val[0] *= p.alpha;
-                            if (ym.y < 0.f) val[1] *= p.alpha;
-                            if (ym.z < 0.f) val[2] *= p.alpha;
-                            if (ym.w < 0.f) val[3] *= p.alpha;
+                if (vec) {
+                    if (p.ymask) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) csum[r] += val[r];
+                        for (int ni = 0; ni < 4; ++ni) {
+                            const float4 ym = *reinterpret_cast<const float4*>(p.ymask + o + ni * 4);
+                            if (ym.x < 0.f) val[ni][0] *= p.alpha;
+                            if (ym.y < 0.f) val[ni][1] *= p.alpha;
+                            if (ym.z < 0.f) val[ni][2] *= p.alpha;
+                            if (ym.w < 0.f) val[ni][3] *= p.alpha;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) csum[ni][r] += val[ni][r];
                         }
-                        if (store_f32) {
-                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + o) = make_float4(val[0], val[1], val[2], val[3]);
-                        } else {
-                            uint2 pk;
-                            pk.x = (unsigned)f32_to_bf16(val[0]) | ((unsigned)f32_to_bf16(val[1]) << 16);
-                            pk.y = (unsigned)f32_to_bf16(val[2]) | ((unsigned)f32_to_bf16(val[3]) << 16);
-                            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + o) = pk;
-                        }
+                    }
+                    if (store_f32) {
+                        float* po = reinterpret_cast<float*>(p.out) + o;
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+                            *reinterpret_cast<float4*>(po + ni * 4) = make_float4(val[ni][0], val[ni][1], val[ni][2], val[ni][3]);
                     } else {
+                        bf16_t* po = reinterpret_cast<bf16_t*>(p.out) + o;
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            uint4 pk;
+                            pk.x = (unsigned)f32_to_bf16(val[2 * k][0]) | ((unsigned)f32_to_bf16(val[2 * k][1]) << 16);
+                            pk.y = (unsigned)f32_to_bf16(val[2 * k][2]) | ((unsigned)f32_to_bf16(val[2 * k][3]) << 16);
+                            pk.z = (unsigned)f32_to_bf16(val[2 * k + 1][0]) | ((unsigned)f32_to_bf16(val[2 * k + 1][1]) << 16);
+                            pk.w = (unsigned)f32_to_bf16(val[2 * k + 1][2]) | ((unsigned)f32_to_bf16(val[2 * k + 1][3]) << 16);
+                            *reinterpret_cast<uint4*>(po + 8 * k) = pk;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            if (co + r < p.Cout) {
+                            const int e = ni * 4 + r;
+                            if (co + e < p.Cout) {
                                 if (p.ymask) {
-                                    if (p.ymask[o + r] < 0.f) val[r] *= p.alpha;
-                                    csum[r] += val[r];
+                                    if (p.ymask[o + e] < 0.f) val[ni][r] *= p.alpha;
+                                    csum[ni][r] += val[ni][r];
                                 }
-                                if (store_f32) reinterpret_cast<float*>(p.out)[o + r] = val[r];
-                                else reinterpret_cast<bf16_t*>(p.out)[o + r] = f32_to_bf16(val[r]);
+                                if (store_f32) reinterpret_cast<float*>(p.out)[o + e] = val[ni][r];
+                                else reinterpret_cast<bf16_t*>(p.out)[o + e] = f32_to_bf16(val[ni][r]);
                             }
                         }
-                    }
                 }
             }
-            if (p.ymask) {
+        }
+        if (p.ymask) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float c = csum[r];
+                    float c = csum[ni][r];
                     c += __shfl_xor(c, 1);
                     c += __shfl_xor(c, 2);
                     c += __shfl_xor(c, 4);
                     c += __shfl_xor(c, 8);
-                    if (r16 == 0) s_col[wm * BN + cl + r] = c;
+                    if (r16 == 0) s_col[wm * BN + cl + ni * 4 + r] = c;
                 }
-            }
         }
         if (p.ymask) {
             __syncthreads();
@@ -582,6 +607,16 @@ __host__ __device__ inline int conv_bn(int Cout)
     return 32;
 }
 
+// The 16x16x32 kernels (every dtype but exact fp32, N tiles of 64 columns and wider) keep their weight columns
+// permuted inside each wave's 64-column group so that the transposed accumulator layout hands every lane 16
+// consecutive couts (see the epilogue): physical column ni*16 + i  <->  cout (i >> 2)*16 + ni*4 + (i & 3).
+__host__ __device__ inline bool conv_uses_m16(int dtype, int BN) { return dtype != MMR_DT_F32 && BN >= 64; }
+__host__ __device__ inline int conv_cout_of_col(int col)
+{
+    const int g = col >> 6, ni = (col >> 4) & 3, i = col & 15;
+    return (g << 6) + ((i >> 2) << 4) + (ni << 2) + (i & 3);
+}
+
 template <int DT>
 __global__ void pack_kernel(const float* __restrict__ w, char* __restrict__ wp, int Cin, int Cout, int BN, int ntiles,
                             int transpose_flip)
@@ -597,7 +632,7 @@ __global__ void pack_kernel(const float* __restrict__ w, char* __restrict__ wp, 
         const int tap = (int)(r % 27); r /= 27;
         const int s = (int)(r % nslices);
         const int t = (int)(r / nslices);
-        const int co = t * BN + col;
+        const int co = t * BN + (conv_uses_m16(DT, BN) ? conv_cout_of_col(col) : col);
         char* dst = wp + i * 16;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
@@ -648,41 +683,21 @@ int dispatch_conv(const ConvParams& p, hipStream_t st, int64_t* nblk_out = nullp
 {
     const int BN = conv_bn(p.Cout);
     const int nt = (p.Cout + BN - 1) / BN;
-    // MMR_CONV_VARIANT (A/B testing): 0 plain 32x32x16, 1 + fragment double-buffer, 2 + A-slice register prefetch,
-    // 32 = 16x16x32 MFMA (default; +6.6 % on C2: the chip holds a higher clock on this shape), 4/8/12 timing-only
+    // MMR_CONV_VARIANT=96: XCD-aware tile order for the 256-wide tile (A/B runs; measured 1 % slower).  The earlier
+    // 32x32x16 / fragment-double-buffer / A-prefetch / timing-only variants and the 4x8x8 narrow tiles were retired
+    // once measured; for exact fp32 the same instantiations run the 32x32x2 f32 path.
     static int var = -1;
     if (var < 0) {
         const char* e = getenv("MMR_CONV_VARIANT");
         var = e ? atoi(e) : 32;
     }
-    static int tile8 = -1;
-    if (tile8 < 0) {
-        const char* e = getenv("MMR_CONV_TILE");
-        tile8 = (e && atoi(e) == 4) ? 0 : 1;
-    }
     switch (BN) {
         case 256:
-            if (var == 0) return launch_conv<DT, 2, 4, 4, 2, 0>(p, nt, st, nblk_out);
-            if (var == 2) return launch_conv<DT, 2, 4, 4, 2, 2>(p, nt, st, nblk_out);
-            if (var == 32) return launch_conv<DT, 2, 4, 4, 2, 32>(p, nt, st, nblk_out);
             if (var == 96) return launch_conv<DT, 2, 4, 4, 2, 96>(p, nt, st, nblk_out);
-            if (var == 1) return launch_conv<DT, 2, 4, 4, 2, 1>(p, nt, st, nblk_out);
-            if (var == 4) return launch_conv<DT, 2, 4, 4, 2, 4>(p, nt, st, nblk_out);
-            if (var == 8) return launch_conv<DT, 2, 4, 4, 2, 8>(p, nt, st, nblk_out);
-            if (var == 12) return launch_conv<DT, 2, 4, 4, 2, 12>(p, nt, st, nblk_out);
             return launch_conv<DT, 2, 4, 4, 2, 32>(p, nt, st, nblk_out);
-        // narrow N: 8x8x8-voxel tiles (MT doubled); MMR_CONV_TILE=4 restores the 4x8x8 tiles for A/B runs
-        case 128:
-            if (tile8 && var == 32) return launch_conv<DT, 4, 2, 4, 2, 32>(p, nt, st, nblk_out);
-            if (tile8) return launch_conv<DT, 4, 2, 4, 2, 0>(p, nt, st, nblk_out);
-            return launch_conv<DT, 4, 2, 2, 2, 3>(p, nt, st, nblk_out);
-        case 64:
-            if (tile8 && var == 32) return launch_conv<DT, 8, 1, 2, 2, 32>(p, nt, st, nblk_out);
-            if (tile8) return launch_conv<DT, 8, 1, 2, 2, 0>(p, nt, st, nblk_out);
-            return launch_conv<DT, 8, 1, 1, 2, 3>(p, nt, st, nblk_out);
-        default:
-            if (tile8) return launch_conv<DT, 8, 1, 2, 1, 0>(p, nt, st, nblk_out);
-            return launch_conv<DT, 8, 1, 1, 1, 3>(p, nt, st, nblk_out);
+        case 128: return launch_conv<DT, 4, 2, 4, 2, 32>(p, nt, st, nblk_out);  // 8x8x8-voxel tiles for the narrow N
+        case 64: return launch_conv<DT, 8, 1, 2, 2, 32>(p, nt, st, nblk_out);
+        default: return launch_conv<DT, 8, 1, 2, 1, 0>(p, nt, st, nblk_out);
     }
 }
 
