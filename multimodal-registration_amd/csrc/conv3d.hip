@@ -105,8 +105,9 @@ __device__ __forceinline__ int row_perm(int r)
     return r + d;
 }
 
-// VAR bit 0: double-buffer the MFMA operand fragments inside a tap; bit 1: prefetch the next channel
-// slice of A into registers during tap 25 (both together exceed 256 VGPRs at the 128x64 wave tile).
+// VAR bit 5: 16x16x32 MFMA with the transposed product (default for N tiles >= 64); bit 6: XCD-aware tile order.
+// (Retired after measurement, see DESIGN.md 2.2: fragment double-buffering, A-slice register prefetch -- together
+// they exceed 256 VGPRs at the 128x64 wave tile --, dz-shifted fragment reuse, cross-barrier A prefetch.)
 template <int DT, int WM, int WN, int MT, int NT, int VAR>
 __global__ void __launch_bounds__(CONV_THREADS, 2)
 conv3d_k3_kernel(const ConvParams p)
@@ -117,7 +118,6 @@ conv3d_k3_kernel(const ConvParams p)
     constexpr int HXT = TXT + 2;
     constexpr int HROWS_T = HXT * HY * HZ;
     constexpr int A_BYTES_T = HROWS_T * ROWB;
-    constexpr bool FRAG_DB = VAR & 1, PREF_A = (VAR >> 1) & 1;
     // VAR bit 5: v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (bf16 only): same bytes per flop, the chip holds
     // a higher clock on this shape (MI355X_MICROARCH.md, DVFS give-back item 7)
     constexpr bool M16 = ((VAR >> 5) & 1) && (DT == MMR_DT_BF16 || DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1);
@@ -276,17 +276,10 @@ conv3d_k3_kernel(const ConvParams p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    AItem pre[PREF_A ? A_ITERS : 1];
     int cur = 0, tap = 0, s = 0;
     for (int g = 0; g < G; ++g) {
         const bool more = g + 1 < G;
-        if (more && !((VAR & 4) && g > 0)) issue_b(g + 1, cur ^ 1);  // VAR&4: timing-only diagnostic (stale B)
-        const bool prefetch = PREF_A && (tap == 25) && (s + 1 < nslices);
-        if constexpr (PREF_A) if (prefetch) {
-            asm volatile("" ::: "memory");  // keep the A loads younger than the LDS-DMA above (vmcnt is in issue order)
-#pragma unroll
-            for (int it = 0; it < A_ITERS; ++it) pre[it] = load_a(s + 1, it);
-        }
+        if (more) issue_b(g + 1, cur ^ 1);
         const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
         const int tapoff = (dx * (HY * HZ) + dy * HZ + dz) * ROWB;
         const int sw = (swz(vyl + dy, vz + dz) ^ h) << 4;
@@ -368,40 +361,20 @@ conv3d_k3_kernel(const ConvParams p)
                     }
             }
         } else {
-        uint4 fa[2][MT], fb[2][NT];
-        if constexpr (FRAG_DB) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) fa[0][m] = *reinterpret_cast<const uint4*>(bA + a_off[m] + sw);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) fb[0][n] = *reinterpret_cast<const uint4*>(bB + b_off[n]);
-        }
+        uint4 fa[MT], fb[NT];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int c = FRAG_DB ? (ks & 1) : 0, nx = c ^ 1;
-            if constexpr (FRAG_DB) {
-                if (ks < 3) {
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
-                        fa[nx][m] = *reinterpret_cast<const uint4*>(bA + a_off[m] + (((ks + 1) << 5) ^ sw));
+            for (int m = 0; m < MT; ++m) fa[m] = *reinterpret_cast<const uint4*>(bA + a_off[m] + ((ks << 5) ^ sw));
 #pragma unroll
-                    for (int n = 0; n < NT; ++n)
-                        fb[nx][n] = *reinterpret_cast<const uint4*>(bB + b_off[n] + (ks + 1) * 2 * BN * 16);
-                }
-            } else {
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    fa[0][m] = *reinterpret_cast<const uint4*>(bA + a_off[m] + ((ks << 5) ^ sw));
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    fb[0][n] = *reinterpret_cast<const uint4*>(bB + b_off[n] + ks * 2 * BN * 16);
-            }
+            for (int n = 0; n < NT; ++n) fb[n] = *reinterpret_cast<const uint4*>(bB + b_off[n] + ks * 2 * BN * 16);
             if constexpr (DT == MMR_DT_BF16) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, fa[c][m]), __builtin_bit_cast(bf16x8, fb[c][n]), acc[m][n], 0, 0, 0);
+                            __builtin_bit_cast(bf16x8, fa[m]), __builtin_bit_cast(bf16x8, fb[n]), acc[m][n], 0, 0, 0);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -410,28 +383,19 @@ conv3d_k3_kernel(const ConvParams p)
 #pragma unroll
                         for (int n = 0; n < NT; ++n)
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                                __builtin_bit_cast(f32x4, fa[c][m])[j], __builtin_bit_cast(f32x4, fb[c][n])[j], acc[m][n], 0, 0, 0);
+                                __builtin_bit_cast(f32x4, fa[m])[j], __builtin_bit_cast(f32x4, fb[n])[j], acc[m][n], 0, 0, 0);
             }
         }
         }
-        if (prefetch) {
-            // retire this tap's LDS-DMA (older) but leave the A_ITERS register loads in flight across the barrier
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(X3 ? 2 * A_ITERS : A_ITERS) : "memory");
-            __builtin_amdgcn_s_barrier();
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA of tap g+1 has landed (this wave's share)
-            __syncthreads();                                  // ... everyone's has; buffer `cur` is free
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA of tap g+1 has landed (this wave's share)
+        __syncthreads();                                  // ... everyone's has; buffer `cur` is free
         cur ^= 1;
         if (++tap == 27) {
             tap = 0;
             ++s;
-            if (s < nslices && !(VAR & 8)) {  // every wave is past its last read of sA: install the next slice (VAR&8: diagnostic)
+            if (s < nslices) {  // every wave is past its last read of sA: install the next slice
 #pragma unroll
-                for (int it = 0; it < A_ITERS; ++it) {
-                    if constexpr (PREF_A) store_a(it, pre[it]);
-                    else store_a(it, load_a(s, it));
-                }
+                for (int it = 0; it < A_ITERS; ++it) store_a(it, load_a(s, it));
                 __syncthreads();
             }
         }
