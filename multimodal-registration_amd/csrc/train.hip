@@ -1048,6 +1048,14 @@ wgrad_x3_kernel(const WgradParams p)
                 }
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[j], 0, 0, 0);
             }
+            if constexpr (LO && COT == 2) {
+                // fragment pipeline: dZ + the first two X units' reads up front, then each unit's three MFMAs with the
+                // reads of the unit two ahead behind them (hipcc alone waits lgkmcnt(0) in front of every unit)
+                __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#define MMR_WG(rd) __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); if (rd) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0)
+                MMR_WG(1); MMR_WG(1); MMR_WG(1); MMR_WG(1); MMR_WG(1); MMR_WG(0); MMR_WG(0);
+#undef MMR_WG
+            }
         }
     }
     float* out = p.slab + (((size_t)blockIdx.x * gridDim.y + slice) * gridDim.z + cob) * (27 * 32 * 64);
