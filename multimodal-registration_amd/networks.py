@@ -95,15 +95,16 @@ def _write_keras_weights(g, layer_names, weights):
 class VxmDense:
     """VoxelMorph dense registration network, forward on gfx950 HIP kernels.
 
-    ``compute_dtype``: 'bf16' (bf16 activations/weights, fp32 MFMA accumulate;
-    BASELINE.json config 2) or 'fp32' (exact-fp32 MFMA; the 1e-4 parity path).
+    ``compute_dtype``: 'fp32x3' (default: fp32 tensors, every product as three bf16 MFMAs on hi/lo splits, measured
+    3-5e-6 relative error -- inside the 1e-4 fp32 parity bar at 3/16 of the exact-fp32 time), 'fp32' (exact-fp32
+    MFMA) or 'bf16' (bf16 activations/weights, fp32 accumulate: the throughput setting of BASELINE.json config 2).
     """
 
     def __init__(self, inshape, nb_unet_features=None, nb_unet_levels=None, unet_feat_mult=1,
                  nb_unet_conv_per_level=1, int_steps=7, svf_resolution=1, int_resolution=2,
                  int_downsize=None, bidir=False, use_probs=False, src_feats=1, trg_feats=1,
                  unet_half_res=False, input_model=None, hyp_model=None, fill_value=None,
-                 reg_field="preintegrated", name="vxm_dense", compute_dtype="bf16", device="cuda", seed=0):
+                 reg_field="preintegrated", name="vxm_dense", compute_dtype="fp32x3", device="cuda", seed=0):
         if len(inshape) != 3:
             raise ValueError("VxmDense here is 3-D only (the reference registers 3-D volumes)")
         if bidir or use_probs or unet_half_res or hyp_model is not None or nb_unet_conv_per_level != 1:

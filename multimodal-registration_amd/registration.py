@@ -146,7 +146,7 @@ def _pair(a, b):
     return [a[None, ..., None], b[None, ..., None]]
 
 
-def register(specs, models, fixed, moving, warp_interp="linear", resample_interp="linear", compute_dtype="bf16"):
+def register(specs, models, fixed, moving, warp_interp="linear", resample_interp="linear", compute_dtype="fp32x3"):
     """Register ``moving`` to ``fixed`` (Volume objects) with one model (3d_reg.py / bids_registration.py) or a
     cascade of two (bids_two_steps_registration.py).  Returns dict(fixed_proc, moving_proc, moved, moved_original,
     warp (half-res field as the reference keeps it), warp_rai, warp_rai_original, scale)."""
@@ -205,7 +205,7 @@ def register(specs, models, fixed, moving, warp_interp="linear", resample_interp
 
 
 def run_3d_reg(specs, model_path, fx_im_path, mov_im_path, res_dir="res", warp_interp="linear", resample_interp="linear",
-               out_im_path="warped_im", out_field_path="deform_field", compute_dtype="bf16", model_path_2=None):
+               out_im_path="warped_im", out_field_path="deform_field", compute_dtype="fp32x3", model_path_2=None):
     """File-level entry with 3d_reg.py's arguments; unlike the reference (NameError at 3d_reg.py:421)
     it also writes the deformation field."""
     import os

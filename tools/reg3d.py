@@ -26,7 +26,7 @@ def main():
     p.add_argument("--resample-interp", default="linear", help="linear, spline or nearest (default: linear)")
     p.add_argument("--out-img-name", default="warped_im")
     p.add_argument("--def-field-name", default="deform_field")
-    p.add_argument("--compute-dtype", default="bf16", choices=["bf16", "fp32", "fp32x3"])
+    p.add_argument("--compute-dtype", default="fp32x3", choices=["bf16", "fp32", "fp32x3"])
     a = p.parse_args()
     with open(a.config_path) as f:
         specs = json.load(f)
