@@ -115,6 +115,13 @@ int mmr_ncc_fwd_f32(const float* I, const float* J, float* out, void* ws,
 int64_t mmr_bending_ws_bytes(int B, int X, int Y, int Z);
 int mmr_bending_fwd_f32(const float* flow, float* out, void* ws,
                         int B, int X, int Y, int Z, void* stream);
+/* Backward of the two losses (SURVEY 8b families ncc_bwd / bending_bwd): gradients of out[b] scaled by gout[b]
+ * (gout == NULL: 1).  NCC: dI and/or dJ [B,X,Y,Z] (either may be NULL); workspace mmr_ncc_bwd_ws_bytes. */
+int64_t mmr_ncc_bwd_ws_bytes(int B, int X, int Y, int Z);
+int mmr_ncc_bwd_f32(const float* I, const float* J, const float* gout, float* dI, float* dJ, void* ws,
+                    int B, int X, int Y, int Z, int win, float eps, void* stream);
+int mmr_bending_bwd_f32(const float* flow, const float* gout, float* dflow, int B, int X, int Y, int Z,
+                        int accumulate, void* stream);
 
 /* ---- SynthMorph generator (ne.models.labels_to_image / ne.utils.augment.draw_perlin,
  * train_synthmorph.py:57-64,258-268,288-291; stages SURVEY.md Appendix A9/A10) ---- */

@@ -341,6 +341,227 @@ bending_partial_kernel(const float* __restrict__ u, double* __restrict__ part, i
     if (threadIdx.x == 0) part[((size_t)b * nseg + seg) * gridDim.x + blockIdx.x] = r;
 }
 
+// ------------------------------ NCC backward ---------------------------- //
+// With S = box sums of (I, J, I^2, J^2, IJ) at window centre c and cc = cross^2 / (Iv Jv + eps):
+//   A = d cc/d cross = 2 cross / (Iv Jv + eps),  Bc = d cc/d Iv = -cross^2 Jv / (Iv Jv + eps)^2,  Cc likewise with Iv;
+//   d cross / d I_p = J_p - uJ(c),  d Iv / d I_p = 2 (I_p - uI(c))   for every window c that contains p, hence
+//   dL/dI_p = -g/N [ J_p box(A) - box(A uJ) + 2 I_p box(Bc) - 2 box(Bc uI) ],  dL/dJ_p symmetric,
+// i.e. seven more 9^3 box filters (zero padded like the forward) of per-window coefficient fields.
+// pass 2': the x box of the forward sums, writing the seven coefficient fields instead of reducing cc
+__global__ void __launch_bounds__(256)
+ncc_xcoef_kernel(const float* __restrict__ zy, float* __restrict__ F, int X, int Y, int Z, int xseg, int nseg, float eps)
+{
+    const int b = blockIdx.z / nseg, seg = blockIdx.z % nseg;
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int ncol = Y * Z;
+    if (col >= ncol) return;
+    const int x0 = seg * xseg;
+    const int x1 = (x0 + xseg < X) ? x0 + xseg : X;
+    const size_t nvox = (size_t)X * Y * Z;
+    const float* base = zy + (size_t)b * 5 * nvox + col;
+    float* out = F + (size_t)b * 7 * nvox + col;
+    const float ws = 729.f;
+    float ring[9][5];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) ring[k][q] = 0.f;
+    for (int xb = x0 - 4; xb < x1 + 4; xb += 9) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int xs = xb + k;
+            if (xs < x1 + 4) {
+                const bool xin = xs >= 0 && xs < X;
+#pragma unroll
+                for (int q = 0; q < 5; ++q) ring[k][q] = xin ? base[(size_t)q * nvox + (size_t)xs * ncol] : 0.f;
+                const int xo = xs - 4;
+                if (xo >= x0 && xo < x1) {
+                    float S[5];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) {
+                        float t = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 9; ++j) t += ring[j][q];
+                        S[q] = t;
+                    }
+                    const float uI = S[0] / ws, uJ = S[1] / ws;
+                    const float cross = S[4] - uJ * S[0] - uI * S[1] + uI * uJ * ws;
+                    const float Iv = S[2] - 2.f * uI * S[0] + uI * uI * ws;
+                    const float Jv = S[3] - 2.f * uJ * S[1] + uJ * uJ * ws;
+                    const float den = Iv * Jv + eps;
+                    const float A = 2.f * cross / den;
+                    const float r = cross / den;
+                    const float Bc = -r * r * Jv, Cc = -r * r * Iv;
+                    float* o = out + (size_t)xo * ncol;
+                    o[0] = A; o[nvox] = A * uJ; o[2 * nvox] = A * uI;
+                    o[3 * nvox] = Bc; o[4 * nvox] = Bc * uI; o[5 * nvox] = Cc; o[6 * nvox] = Cc * uJ;
+                }
+            }
+        }
+    }
+}
+
+// z + y box of NF stored fields (same wave layout as ncc_zybox_kernel): F [B][NF][X][Y][Z] -> zy [B][NF][X][Y][Z]
+template <int NF>
+__global__ void __launch_bounds__(256)
+box_zy_kernel(const float* __restrict__ F, float* __restrict__ zy, int B, int X, int Y, int Z, int nzs, int nys)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)B * X * nys * nzs;
+    if (wid >= nw) return;
+    int64_t t = wid;
+    const int zs = (int)(t % nzs); t /= nzs;
+    const int ys = (int)(t % nys); t /= nys;
+    const int x = (int)(t % X);
+    const int b = (int)(t / X);
+    const int z = zs * NCC_ZOUT + lane - 4;
+    const int y0 = ys * NCC_ROWS;
+    const int y1 = (y0 + NCC_ROWS < Y) ? y0 + NCC_ROWS : Y;
+    const bool zin = z >= 0 && z < Z;
+    const size_t nvox = (size_t)X * Y * Z;
+    const float* Fp = F + (size_t)b * NF * nvox + (size_t)x * Y * Z;
+    float ring[9][NF];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int q = 0; q < NF; ++q) ring[k][q] = 0.f;
+    const int zc = z + 4;
+    const bool zout = lane < NCC_ZOUT && zc < Z;
+    for (int yb = y0 - 4; yb < y1 + 4; yb += 9) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int yy = yb + k;
+            if (yy < y1 + 4) {
+                const bool in = zin && yy >= 0 && yy < Y;
+#pragma unroll
+                for (int q = 0; q < NF; ++q) ring[k][q] = box9_lanes(in ? Fp[(size_t)q * nvox + (size_t)yy * Z + z] : 0.f);
+                const int yo = yy - 4;
+                if (yo >= y0 && yo < y1 && zout) {
+                    float* o = zy + ((((size_t)b * NF) * X + x) * Y + yo) * Z + zc;
+#pragma unroll
+                    for (int q = 0; q < NF; ++q) {
+                        float sum = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 9; ++j) sum += ring[j][q];
+                        o[(size_t)q * nvox] = sum;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// x box of the seven zy-filtered coefficient fields, combined with I_p, J_p into the two gradients
+__global__ void __launch_bounds__(256)
+ncc_xgrad_kernel(const float* __restrict__ zy, const float* __restrict__ I, const float* __restrict__ J,
+                 const float* __restrict__ gout, float* __restrict__ dI, float* __restrict__ dJ, int X, int Y, int Z,
+                 int xseg, int nseg)
+{
+    const int b = blockIdx.z / nseg, seg = blockIdx.z % nseg;
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int ncol = Y * Z;
+    if (col >= ncol) return;
+    const int x0 = seg * xseg;
+    const int x1 = (x0 + xseg < X) ? x0 + xseg : X;
+    const size_t nvox = (size_t)X * Y * Z;
+    const float* base = zy + (size_t)b * 7 * nvox + col;
+    const float scale = -(gout ? gout[b] : 1.f) / (float)nvox;  // loss_b = -mean(cc)
+    float ring[9][7];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int q = 0; q < 7; ++q) ring[k][q] = 0.f;
+    for (int xb = x0 - 4; xb < x1 + 4; xb += 9) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int xs = xb + k;
+            if (xs < x1 + 4) {
+                const bool xin = xs >= 0 && xs < X;
+#pragma unroll
+                for (int q = 0; q < 7; ++q) ring[k][q] = xin ? base[(size_t)q * nvox + (size_t)xs * ncol] : 0.f;
+                const int xo = xs - 4;
+                if (xo >= x0 && xo < x1) {
+                    float S[7];
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) {
+                        float t = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 9; ++j) t += ring[j][q];
+                        S[q] = t;
+                    }
+                    const size_t o = (size_t)b * nvox + (size_t)xo * ncol + col;
+                    const float ip = I[o], jp = J[o];
+                    if (dI) dI[o] = scale * (jp * S[0] - S[1] + 2.f * ip * S[3] - 2.f * S[4]);
+                    if (dJ) dJ[o] = scale * (ip * S[0] - S[2] + 2.f * jp * S[5] - 2.f * S[6]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------ bending backward ------------------------ //
+// E = 1/M sum_{c interior,k} dxx^2 + dyy^2 + dzz^2 + 2 (dxy^2 + dxz^2 + dyz^2); gather form of dE/du[w,k]: every
+// second difference that touches w, recomputed from u (all reads hit L1/L2; this is not on the training path of
+// the reference, which uses Dice + Grad-l2).
+struct BendCtx { const float* u; int X, Y, Z, k; };
+__device__ __forceinline__ bool bend_interior(const BendCtx& c, int x, int y, int z)
+{
+    return x >= 1 && x < c.X - 1 && y >= 1 && y < c.Y - 1 && z >= 1 && z < c.Z - 1;
+}
+__device__ __forceinline__ float bend_at(const BendCtx& c, int x, int y, int z)
+{
+    return c.u[(((size_t)x * c.Y + y) * c.Z + z) * 3 + c.k];
+}
+// pure second difference along axis a (0,1,2) at centre (x,y,z), 0 outside the interior
+__device__ __forceinline__ float bend_daa(const BendCtx& c, int x, int y, int z, int a)
+{
+    if (!bend_interior(c, x, y, z)) return 0.f;
+    const int ex = a == 0, ey = a == 1, ez = a == 2;
+    return bend_at(c, x + ex, y + ey, z + ez) - 2.f * bend_at(c, x, y, z) + bend_at(c, x - ex, y - ey, z - ez);
+}
+// mixed difference for the axis pair (a,b), including its 1/4
+__device__ __forceinline__ float bend_dab(const BendCtx& c, int x, int y, int z, int a, int b)
+{
+    if (!bend_interior(c, x, y, z)) return 0.f;
+    const int ax = a == 0, ay = a == 1, az = a == 2, bx = b == 0, by = b == 1, bz = b == 2;
+    return 0.25f * (bend_at(c, x + ax + bx, y + ay + by, z + az + bz) - bend_at(c, x + ax - bx, y + ay - by, z + az - bz) -
+                    bend_at(c, x - ax + bx, y - ay + by, z - az + bz) + bend_at(c, x - ax - bx, y - ay - by, z - az - bz));
+}
+
+__global__ void __launch_bounds__(256)
+bending_bwd_kernel(const float* __restrict__ u, const float* __restrict__ gout, float* __restrict__ du, int B, int X, int Y,
+                   int Z, int accumulate)
+{
+    const int64_t nvox = (int64_t)X * Y * Z;
+    const int64_t total = (int64_t)B * nvox * 3;
+    const double M = (double)(X - 2) * (Y - 2) * (Z - 2) * 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int k = (int)(i % 3);
+        int64_t v = i / 3;
+        const int b = (int)(v / nvox);
+        v -= (int64_t)b * nvox;
+        const int z = (int)(v % Z), y = (int)((v / Z) % Y), x = (int)(v / ((int64_t)Y * Z));
+        BendCtx c{u + (size_t)b * nvox * 3, X, Y, Z, k};
+        float g = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int ex = a == 0, ey = a == 1, ez = a == 2;
+            g += 2.f * (bend_daa(c, x - ex, y - ey, z - ez, a) - 2.f * bend_daa(c, x, y, z, a) + bend_daa(c, x + ex, y + ey, z + ez, a));
+        }
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr) {
+            const int a = pr == 2 ? 1 : 0, bb = pr == 0 ? 1 : 2;  // (x,y), (x,z), (y,z)
+            const int ax = a == 0, ay = a == 1, bx = 0, by = bb == 1, bz = bb == 2, az = 0;
+            // e has 2 d_ab^2 -> 4 d_ab * (+-1/4)
+            g += (bend_dab(c, x - ax - bx, y - ay - by, z - az - bz, a, bb) - bend_dab(c, x - ax + bx, y - ay + by, z - az + bz, a, bb) -
+                  bend_dab(c, x + ax - bx, y + ay - by, z + az - bz, a, bb) + bend_dab(c, x + ax + bx, y + ay + by, z + az + bz, a, bb));
+        }
+        const float val = (float)((double)(gout ? gout[b] : 1.f) / M) * g;
+        if (accumulate) du[i] += val; else du[i] = val;
+    }
+}
+
 inline int red_blocks(int64_t n_el)
 {
     int64_t g = (n_el + RED_BLOCK * 8 - 1) / (RED_BLOCK * 8);
@@ -471,5 +692,46 @@ extern "C" int mmr_bending_fwd_f32(const float* flow, float* out, void* ws, int 
     const int64_t n = (int64_t)(X - 2) * (Y - 2) * (Z - 2) * 3;
     hipLaunchKernelGGL(mean_final_kernel, dim3(B), dim3(RED_BLOCK), 0, as_stream(stream), (const double*)ws, out, B,
                        (int64_t)nseg * ncolblk, (double)n, 1.0f);
+    return check_launch();
+}
+
+// d(-mean cc)/dI and /dJ, scaled by gout[b] (null = 1); dI / dJ may be null.  Workspace: 19 volumes of fp32.
+extern "C" int64_t mmr_ncc_bwd_ws_bytes(int B, int X, int Y, int Z)
+{
+    if (B < 1 || X < 1 || Y < 1 || Z < 1) return MMR_EINVAL;
+    return (int64_t)B * 19 * X * Y * Z * (int64_t)sizeof(float);
+}
+
+extern "C" int mmr_ncc_bwd_f32(const float* I, const float* J, const float* gout, float* dI, float* dJ, void* ws, int B,
+                               int X, int Y, int Z, int win, float eps, void* stream)
+{
+    if (!I || !J || !ws || (!dI && !dJ) || B < 1 || X < 1 || Y < 1 || Z < 1) return MMR_EINVAL;
+    if (win != 9) return MMR_EUNSUPPORTED;
+    int nseg, ncolblk;
+    ncc_geom(X, Y, Z, nseg, ncolblk);
+    if ((int64_t)B * nseg > 65535) return MMR_EINVAL;
+    const size_t nv = (size_t)B * X * Y * Z;
+    float* zy5 = (float*)ws;
+    float* F = zy5 + 5 * nv;
+    float* zy7 = F + 7 * nv;
+    const int nzs = (Z + NCC_ZOUT - 1) / NCC_ZOUT, nys = (Y + NCC_ROWS - 1) / NCC_ROWS;
+    const int64_t nb1 = ((int64_t)B * X * nys * nzs + 3) / 4;
+    if (nb1 > 0x7fffffff) return MMR_EINVAL;
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(ncc_zybox_kernel, dim3((unsigned)nb1), dim3(256), 0, st, I, J, zy5, B, X, Y, Z, nzs, nys);
+    hipLaunchKernelGGL(ncc_xcoef_kernel, dim3(ncolblk, 1, B * nseg), dim3(256), 0, st, (const float*)zy5, F, X, Y, Z,
+                       NCC_XSEG, nseg, eps);
+    hipLaunchKernelGGL(box_zy_kernel<7>, dim3((unsigned)nb1), dim3(256), 0, st, (const float*)F, zy7, B, X, Y, Z, nzs, nys);
+    hipLaunchKernelGGL(ncc_xgrad_kernel, dim3(ncolblk, 1, B * nseg), dim3(256), 0, st, (const float*)zy7, I, J, gout, dI, dJ,
+                       X, Y, Z, NCC_XSEG, nseg);
+    return check_launch();
+}
+
+extern "C" int mmr_bending_bwd_f32(const float* flow, const float* gout, float* dflow, int B, int X, int Y, int Z,
+                                   int accumulate, void* stream)
+{
+    if (!flow || !dflow || B < 1 || X < 3 || Y < 3 || Z < 3) return MMR_EINVAL;
+    hipLaunchKernelGGL(bending_bwd_kernel, dim3(stream_grid((int64_t)B * X * Y * Z * 3, 256)), dim3(256), 0,
+                       as_stream(stream), flow, gout, dflow, B, X, Y, Z, accumulate);
     return check_launch();
 }

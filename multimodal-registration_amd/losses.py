@@ -35,12 +35,19 @@ class NCC:
     def loss(self, y_true, y_pred):
         return ops.ncc_loss(to_device(y_true), to_device(y_pred), self.win, self.eps)
 
+    def grad(self, y_true, y_pred, gout=None):
+        """d loss / d y_pred (the moved image), [B,*S,1]."""
+        return ops.ncc_loss_bwd(to_device(y_true), to_device(y_pred), gout, self.win, self.eps, want=("J",))[1]
+
 
 class BendingEnergy:
     """Mean squared second differences of a displacement field -> [B] (defined by this build)."""
 
     def loss(self, _, y_pred):
         return ops.bending_energy(to_device(y_pred))
+
+    def grad(self, _, y_pred, gout=None):
+        return ops.bending_energy_bwd(to_device(y_pred), gout)
 
 
 def dice_loss_zeropad(y_true, y_pred):

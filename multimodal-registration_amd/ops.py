@@ -323,6 +323,41 @@ def bending_energy(flow):
     return out
 
 
+def ncc_loss_bwd(I, J, gout=None, win=9, eps=1e-5, want=("I", "J")):
+    """Gradients of ``ncc_loss`` [B] w.r.t. I and / or J, scaled by ``gout`` [B] (None = ones) -> (dI, dJ)."""
+    _chk(I, torch.float32, "I")
+    _chk(J, torch.float32, "J")
+    if I.shape != J.shape or I.shape[-1] != 1:
+        raise _lib.MmrError("ncc: inputs must be [B,X,Y,Z,1] of equal shape")
+    B, X, Y, Z, _ = I.shape
+    lib = _lib.load()
+    ws = _ws(lib.mmr_ncc_bwd_ws_bytes(B, X, Y, Z), I.device)
+    dI = torch.empty_like(I) if "I" in want else None
+    dJ = torch.empty_like(J) if "J" in want else None
+    if gout is not None:
+        _chk(gout, torch.float32, "gout")
+    rc = lib.mmr_ncc_bwd_f32(I.data_ptr(), J.data_ptr(), gout.data_ptr() if gout is not None else None,
+                             dI.data_ptr() if dI is not None else None, dJ.data_ptr() if dJ is not None else None,
+                             ws.data_ptr(), B, X, Y, Z, int(win), float(eps), _stream())
+    _lib.check(rc, "mmr_ncc_bwd_f32")
+    return dI, dJ
+
+
+def bending_energy_bwd(flow, gout=None, out=None):
+    """Gradient of ``bending_energy`` [B] w.r.t. the field, scaled by ``gout``; accumulates into ``out`` when given."""
+    _chk(flow, torch.float32, "flow")
+    B, X, Y, Z, C = flow.shape
+    if C != 3:
+        raise _lib.MmrError("bending energy needs [B,X,Y,Z,3]")
+    acc = out is not None
+    if out is None:
+        out = torch.empty_like(flow)
+    rc = _lib.load().mmr_bending_bwd_f32(flow.data_ptr(), gout.data_ptr() if gout is not None else None, out.data_ptr(),
+                                         B, X, Y, Z, int(acc), _stream())
+    _lib.check(rc, "mmr_bending_bwd_f32")
+    return out
+
+
 # ------------------------------- generator ------------------------------ #
 def philox_normal(shape, seed, stream_id=0, mean=0.0, std=1.0, device="cuda"):
     out = torch.empty(tuple(int(s) for s in shape), dtype=torch.float32, device=device)

@@ -121,3 +121,33 @@ def synthmorph_loss(src, trg, onehot1, onehot2, ws, enc, dec, int_steps, reg_par
     gl = grad_l2(pos, reg_param)
     total = (dice + 1) * B + gl.sum()
     return total, dice, gl, pos, flow
+
+
+def ncc_loss(I, J, win=9, eps=1e-5):
+    """A8 ``vxm.losses.NCC(win).loss`` on [B,*S,1] (float64 tensors): -mean(cross^2 / (Iv*Jv + eps)) per batch item,
+    window sums by a ones-kernel conv with zero ('SAME') padding -- the same formula as oracle/ops_np.py::ncc_loss."""
+    import torch.nn.functional as F
+    Ii, Ji = I[..., 0][:, None], J[..., 0][:, None]
+    k = torch.ones((1, 1, win, win, win), dtype=I.dtype)
+    box = lambda t: F.conv3d(t, k, padding=win // 2)
+    ws = float(win ** 3)
+    Is, Js, I2, J2, IJ = box(Ii), box(Ji), box(Ii * Ii), box(Ji * Ji), box(Ii * Ji)
+    uI, uJ = Is / ws, Js / ws
+    cross = IJ - uJ * Is - uI * Js + uI * uJ * ws
+    Iv = I2 - 2 * uI * Is + uI * uI * ws
+    Jv = J2 - 2 * uJ * Js + uJ * uJ * ws
+    cc = cross * cross / (Iv * Jv + eps)
+    return -cc.flatten(1).mean(1)
+
+
+def bending_energy(u):
+    """Same definition as oracle/ops_np.py::bending_energy on a float64 tensor [B,*S,3] -> [B]."""
+    c = u[:, 1:-1, 1:-1, 1:-1]
+    dxx = u[:, 2:, 1:-1, 1:-1] - 2 * c + u[:, :-2, 1:-1, 1:-1]
+    dyy = u[:, 1:-1, 2:, 1:-1] - 2 * c + u[:, 1:-1, :-2, 1:-1]
+    dzz = u[:, 1:-1, 1:-1, 2:] - 2 * c + u[:, 1:-1, 1:-1, :-2]
+    dxy = (u[:, 2:, 2:, 1:-1] - u[:, 2:, :-2, 1:-1] - u[:, :-2, 2:, 1:-1] + u[:, :-2, :-2, 1:-1]) / 4
+    dxz = (u[:, 2:, 1:-1, 2:] - u[:, 2:, 1:-1, :-2] - u[:, :-2, 1:-1, 2:] + u[:, :-2, 1:-1, :-2]) / 4
+    dyz = (u[:, 1:-1, 2:, 2:] - u[:, 1:-1, 2:, :-2] - u[:, 1:-1, :-2, 2:] + u[:, 1:-1, :-2, :-2]) / 4
+    e = dxx ** 2 + dyy ** 2 + dzz ** 2 + 2 * dxy ** 2 + 2 * dxz ** 2 + 2 * dyz ** 2
+    return e.flatten(1).mean(1)

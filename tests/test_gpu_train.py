@@ -428,3 +428,36 @@ def test_maxpool_bwd_masked_equals_unfused(dev, shape, C):
     db = torch.full((C,), 2.0, device=dev)
     got = ops.maxpool3d2_bwd(x, dp, dx=prev.clone(), masked=True, dbias=db, acc_b=True)
     assert _rel(got, ref) < 1e-6 and _rel(db - 2.0, db_ref) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(12, 17, 60), (9, 9, 9), (20, 70, 13)])
+def test_ncc_and_bending_backward(dev, shape):
+    """Loss gradients vs torch-CPU float64 autograd of the restated formulas (which equal the numpy oracle's)."""
+    import mmr
+    from oracle import grad_torch as G, ops_np as O
+    rng = np.random.default_rng(11)
+    B = 2
+    I = rng.random((B,) + shape + (1,)).astype(np.float32)
+    J = (0.6 * I + 0.4 * rng.random((B,) + shape + (1,))).astype(np.float32)
+    gout = np.array([1.0, -0.5], np.float32)
+    It, Jt = torch.from_numpy(I).double().requires_grad_(True), torch.from_numpy(J).double().requires_grad_(True)
+    loss = G.ncc_loss(It, Jt)
+    assert np.allclose(loss.detach().numpy(), O.ncc_loss(I, J, 9), rtol=1e-9)  # the torch restatement IS the oracle formula
+    (loss * torch.from_numpy(gout).double()).sum().backward()
+    dI, dJ = mmr.ops.ncc_loss_bwd(_t(I, dev), _t(J, dev), _t(gout, dev))
+    assert _rel(dI, It.grad) < 2e-4 and _rel(dJ, Jt.grad) < 2e-4
+    only_j = mmr.losses.NCC(9).grad(_t(I, dev), _t(J, dev))
+    Jt.grad = None
+    It.grad = None
+    G.ncc_loss(It, Jt).sum().backward()
+    assert _rel(only_j, Jt.grad) < 2e-4
+
+    u = (rng.standard_normal((B,) + shape + (3,)) * 2).astype(np.float32)
+    ut = torch.from_numpy(u).double().requires_grad_(True)
+    e = G.bending_energy(ut)
+    assert np.allclose(e.detach().numpy(), O.bending_energy(u), rtol=1e-9)
+    (e * torch.from_numpy(gout).double()).sum().backward()
+    du = mmr.ops.bending_energy_bwd(_t(u, dev), _t(gout, dev))
+    assert _rel(du, ut.grad) < 1e-5
+    acc = mmr.ops.bending_energy_bwd(_t(u, dev), _t(gout, dev), out=du.clone())
+    assert _rel(acc, 2 * ut.grad) < 1e-5
