@@ -103,6 +103,9 @@ int mmr_maxpool3d2_fwd(const void* in, void* out, int B, int X, int Y, int Z, in
 int64_t mmr_dice_ws_bytes(int B, int64_t nvox, int L);
 int mmr_dice_fwd_f32(const float* y_true, const float* y_pred, float* loss_out, float* top_bot,
                      void* ws, int B, int64_t nvox, int L, void* stream);
+/* d loss / d y_pred from the forward's (top, bot) sums [B,L,2]; dpred (+)= scale * gradient. */
+int mmr_dice_bwd_f32(const float* y_true, const float* top_bot, float* dpred, int B, int64_t nvox, int L,
+                     float scale, int accumulate, void* stream);
 /* vxm.losses.Grad('l2', loss_mult).loss(None, flow) (train_synthmorph.py:307) -> out[B]. */
 int64_t mmr_grad_l2_ws_bytes(int B, int X, int Y, int Z, int C);
 int mmr_grad_l2_fwd_f32(const float* flow, float* out, void* ws,

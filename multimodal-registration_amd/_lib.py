@@ -67,6 +67,7 @@ SIGNATURES = {
     "mmr_conv3d_k3_dgrad_masked": (I, [P, I, P, P, I, I, I, I, I, P, F, P, P, I, I, P]),
     "mmr_conv3d_k3_cout3_dgrad_masked_ws_bytes": (c_int64, [I, I, I, I, I]),
     "mmr_conv3d_k3_cout3_dgrad_masked_f32": (I, [P, P, P, I, I, I, I, I, P, F, P, P, I, P]),
+    "mmr_dice_bwd_f32": (I, [P, P, P, I, c_int64, I, F, I, P]),
     "mmr_ncc_bwd_ws_bytes": (c_int64, [I, I, I, I]),
     "mmr_ncc_bwd_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, F, P]),
     "mmr_bending_bwd_f32": (I, [P, P, P, I, I, I, I, I, P]),

@@ -97,6 +97,22 @@ dice_final_kernel(const float* __restrict__ top_bot, float* __restrict__ loss, i
     if (threadIdx.x == 0) loss[0] = (float)(-s / (double)(B * L));
 }
 
+// d dice / d y_pred[b,v,l] = -scale/(B L) * (2 t / bot - top / bot^2), 0 where bot == 0 (divide_no_nan)
+__global__ void __launch_bounds__(256)
+dice_bwd_kernel(const float* __restrict__ y_true, const float* __restrict__ top_bot, float* __restrict__ dpred, int B,
+                int64_t nvox, int L, float scale, int accumulate)
+{
+    const int64_t total = (int64_t)B * nvox * L;
+    const float c = -scale / (float)(B * L);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int l = (int)(i % L);
+        const int b = (int)(i / (nvox * L));
+        const float top = top_bot[(b * L + l) * 2], bot = top_bot[(b * L + l) * 2 + 1];
+        const float g = (bot != 0.f) ? c * (2.f * y_true[i] / bot - top / (bot * bot)) : 0.f;
+        if (accumulate) dpred[i] += g; else dpred[i] = g;
+    }
+}
+
 // ------------------------------ Grad-l2 --------------------------------- //
 __global__ void __launch_bounds__(RED_BLOCK)
 grad_l2_partial_kernel(const float* __restrict__ f, double* __restrict__ part, int X, int Y, int Z, int C, int nblk)
@@ -733,5 +749,15 @@ extern "C" int mmr_bending_bwd_f32(const float* flow, const float* gout, float* 
     if (!flow || !dflow || B < 1 || X < 3 || Y < 3 || Z < 3) return MMR_EINVAL;
     hipLaunchKernelGGL(bending_bwd_kernel, dim3(stream_grid((int64_t)B * X * Y * Z * 3, 256)), dim3(256), 0,
                        as_stream(stream), flow, gout, dflow, B, X, Y, Z, accumulate);
+    return check_launch();
+}
+
+// gradient of mmr_dice_fwd_f32's loss w.r.t. y_pred, from the (top, bot) sums the forward returned
+extern "C" int mmr_dice_bwd_f32(const float* y_true, const float* top_bot, float* dpred, int B, int64_t nvox, int L,
+                                float scale, int accumulate, void* stream)
+{
+    if (!y_true || !top_bot || !dpred || B < 1 || nvox < 1 || L < 1) return MMR_EINVAL;
+    hipLaunchKernelGGL(dice_bwd_kernel, dim3(stream_grid((int64_t)B * nvox * L, 256)), dim3(256), 0, as_stream(stream),
+                       y_true, top_bot, dpred, B, nvox, L, scale, accumulate);
     return check_launch();
 }

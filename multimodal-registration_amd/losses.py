@@ -12,6 +12,12 @@ class Dice:
     def loss(self, y_true, y_pred):
         return ops.dice_loss(to_device(y_true), to_device(y_pred))
 
+    def grad(self, y_true, y_pred, scale=1.0):
+        """d loss / d y_pred, [B,*S,L]."""
+        t = to_device(y_true)
+        _, tb = ops.dice_loss(t, to_device(y_pred), return_parts=True)
+        return ops.dice_loss_bwd(t, tb, scale)
+
 
 class Grad:
     """``vxm.losses.Grad('l2', loss_mult=).loss(None, flow)`` -> [B] (Appendix A7)."""

@@ -285,6 +285,21 @@ def dice_loss(y_true, y_pred, return_parts=False):
     return (loss[0], tb) if return_parts else loss[0]
 
 
+def dice_loss_bwd(y_true, top_bot, scale=1.0, out=None):
+    """d dice_loss / d y_pred from the forward's (top, bot) sums; accumulates into ``out`` when given."""
+    _chk(y_true, torch.float32, "y_true")
+    _chk(top_bot, torch.float32, "top_bot")
+    B, L = y_true.shape[0], y_true.shape[-1]
+    nvox = y_true.numel() // (B * L)
+    acc = out is not None
+    if out is None:
+        out = torch.empty_like(y_true)
+    rc = _lib.load().mmr_dice_bwd_f32(y_true.data_ptr(), top_bot.data_ptr(), out.data_ptr(), B, nvox, L, float(scale),
+                                      int(acc), _stream())
+    _lib.check(rc, "mmr_dice_bwd_f32")
+    return out
+
+
 def grad_l2_loss(flow, loss_mult=1.0):
     _chk(flow, torch.float32, "flow")
     B, X, Y, Z, C = flow.shape

@@ -461,3 +461,17 @@ def test_ncc_and_bending_backward(dev, shape):
     assert _rel(du, ut.grad) < 1e-5
     acc = mmr.ops.bending_energy_bwd(_t(u, dev), _t(gout, dev), out=du.clone())
     assert _rel(acc, 2 * ut.grad) < 1e-5
+
+
+def test_dense_dice_backward(dev):
+    import mmr
+    from oracle import grad_torch as G
+    rng = np.random.default_rng(12)
+    B, S, L = 2, (7, 9, 11), 5
+    t = np.eye(L, dtype=np.float32)[rng.integers(0, L - 1, (B,) + S)]  # label L-1 never true
+    p = rng.random((B,) + S + (L,)).astype(np.float32)
+    p[..., L - 1] = 0  # ... nor predicted: bot == 0 -> divide_no_nan -> zero gradient
+    pt = torch.from_numpy(p).double().requires_grad_(True)
+    G.dice_loss(torch.from_numpy(t).double(), pt).backward()
+    got = mmr.losses.Dice().grad(_t(t, dev), _t(p, dev))
+    assert _rel(got, pt.grad) < 1e-5 and float(got[..., L - 1].abs().max()) == 0.0
