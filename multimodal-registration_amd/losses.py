@@ -30,6 +30,10 @@ class Grad:
     def loss(self, _, y_pred):
         return ops.grad_l2_loss(to_device(y_pred), self.loss_mult)
 
+    def grad(self, _, y_pred, scale=1.0):
+        """d sum_b loss[b] / d y_pred."""
+        return ops.grad_l2_bwd(to_device(y_pred), self.loss_mult, scale)
+
 
 class NCC:
     """``vxm.losses.NCC(win).loss(I, J)`` -> [B]; cc = cross^2/(I_var*J_var+eps) (Appendix A8)."""
