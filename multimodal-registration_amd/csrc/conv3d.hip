@@ -1184,12 +1184,12 @@ template <bool X3>
 __global__ void __launch_bounds__(MH_THREADS, 1)
 flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
                        float* __restrict__ out, int B, int X, int Y, int Z, int Cin, int nseg, int seglen, int nty, int ntz,
-                       int ntiles)
+                       int ntiles, int pbufs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nkc = Cin / 8;                       // 16-B k-chunks
     char* sW = smem;                               // [X3 ? 2 : 1][nkc][96][16 B]
-    float* sP = reinterpret_cast<float*>(smem + (X3 ? 2 : 1) * nkc * 96 * 16);  // [2][128][81]
+    float* sP = reinterpret_cast<float*>(smem + (X3 ? 2 : 1) * nkc * 96 * 16);  // [pbufs][128][81]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, q16 = lane >> 4;
@@ -1243,7 +1243,7 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
         const bool ook = outthr && gyo < Y && gzo < Z;
         float a_prev = 0.f, a_cur = 0.f;
         for (int xp = xs - 1; xp <= xe; ++xp) {
-            const int buf = (xp - xs + 1) & 1;
+            const int buf = (pbufs == 2) ? ((xp - xs + 1) & 1) : 0;
             float* P = sP + buf * (MH_ROWS * 81);
             const bool inside = xp >= 0 && xp < X;
             if (inside) {
@@ -1341,6 +1341,7 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
                 out[((((size_t)b * X + (xp - 1)) * Y + gyo) * Z + gzo) * 3 + co] = done;
             a_prev = a_cur + c1;
             a_cur = bco + c0;
+            if (pbufs == 1) __syncthreads();  // single P buffer (wide fp32x3 inputs): gather done before the next plane lands
         }
         __syncthreads();  // the next tile's first plane reuses buffer 0/1
     }
@@ -1566,7 +1567,10 @@ extern "C" int mmr_conv3d_k3_cout3_fwd(const void* in, const float* w_keras, con
         if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
         attr_set = true;
     }
-    const int lds_m = npl * (Cin / 8) * 96 * 16 + 2 * MH_ROWS * 81 * 4;
+    // double-buffered P plane when it fits, else a single buffer (one more barrier per plane): fp32x3 at Cin = 256
+    const int lds_w = npl * (Cin / 8) * 96 * 16;
+    const int pbufs = (lds_w + 2 * MH_ROWS * 81 * 4 <= 160 * 1024) ? 2 : 1;
+    const int lds_m = lds_w + pbufs * MH_ROWS * 81 * 4;
     if (use_march && lds_m <= 160 * 1024) {
         const int nty = (Y + MH_TY - 1) / MH_TY, ntz = (Z + MH_TZ - 1) / MH_TZ;
         const int64_t tyz = (int64_t)B * nty * ntz;
@@ -1580,10 +1584,10 @@ extern "C" int mmr_conv3d_k3_cout3_fwd(const void* in, const float* w_keras, con
         const int grid = nt < 256 ? (int)nt : 256;
         if (dtype == MMR_DT_F32X3)
             hipLaunchKernelGGL(flow_head_march_kernel<true>, dim3(grid), dim3(MH_THREADS), lds_m, as_stream(stream),
-                               (const char*)in, w_keras, bias, out, B, X, Y, Z, Cin, nseg, seglen, nty, ntz, (int)nt);
+                               (const char*)in, w_keras, bias, out, B, X, Y, Z, Cin, nseg, seglen, nty, ntz, (int)nt, pbufs);
         else
             hipLaunchKernelGGL(flow_head_march_kernel<false>, dim3(grid), dim3(MH_THREADS), lds_m, as_stream(stream),
-                               (const char*)in, w_keras, bias, out, B, X, Y, Z, Cin, nseg, seglen, nty, ntz, (int)nt);
+                               (const char*)in, w_keras, bias, out, B, X, Y, Z, Cin, nseg, seglen, nty, ntz, (int)nt, pbufs);
         return check_launch();
     }
     const int lds = npl * (Cin / 8) * 96 * 16 + FH_ROWS * 81 * 4;

@@ -229,11 +229,11 @@ def conv3d_k3_cin2(src, trg, w_keras, bias, out_dtype, leaky=True, alpha=0.2, x3
 
 
 def flow_head_supported(cin, dtype, x3=False):
-    """The folded-tap flow-head kernel keeps its weight image (Cin x 96 bf16, twice for fp32x3) plus a 76 KB
-    P tile in LDS; wider inputs fall back to the generic MFMA conv."""
+    """The folded-tap flow-head kernel keeps its weight image (Cin x 96 bf16, twice for fp32x3) plus at least one
+    128-row P plane (41 KB) in LDS; wider inputs fall back to the generic MFMA conv."""
     if cin % 32 or (dtype == torch.float32 and not x3):
         return False
-    return (2 if x3 else 1) * (cin // 8) * 96 * 16 + 240 * 81 * 4 <= 160 * 1024
+    return (2 if x3 else 1) * (cin // 8) * 96 * 16 + 128 * 81 * 4 <= 160 * 1024
 
 
 def conv3d_k3_cout3(x, w_keras, bias, x3=False):
