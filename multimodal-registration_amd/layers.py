@@ -5,11 +5,21 @@ import torch
 from . import ops
 
 
+_ASYNC_H2D_BYTES = 1 << 20
+
+
 def to_device(a, dtype=torch.float32, device="cuda"):
     """NumPy / tensor -> contiguous device tensor (Keras casts float64 inputs to fp32)."""
     if isinstance(a, torch.Tensor):
         return a.to(device=device, dtype=dtype).contiguous()
-    return torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dtype).contiguous()
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if torch.device(device).type == "cuda" and t.numel() * t.element_size() <= _ASYNC_H2D_BYTES:
+        # small per-step parameters (generator draws, blur kernels, ...): a pageable copy would block the host until the
+        # stream reaches it, i.e. until the previous step has finished, and the GPU then idles between the generator's
+        # small kernels; pinned + non_blocking keeps the host running ahead (the pinned block is recycled by torch's
+        # caching host allocator only after the copy's event)
+        return t.to(dtype).pin_memory().to(device=device, non_blocking=True).contiguous()
+    return t.to(device=device, dtype=dtype).contiguous()
 
 
 class SpatialTransformer:
