@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="infer", choices=["infer", "train", "ncc"])
+    ap.add_argument("--workload", default="infer", choices=["infer", "train", "ncc", "cascade"])
     ap.add_argument("--features", type=int, default=None)
     ap.add_argument("--shape", type=int, nargs=3, default=None)
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp32", "fp32x3"])
@@ -173,6 +173,29 @@ def main():
             par = f"replicas x{world} (single-pair inference does not shard)"
             cpu_fn = lambda: cpu_baseline_infer(enc, dec, shape)
             metric, unit, pairs_per_step = "volume-pairs/sec", "pairs/s", 1
+        elif wl == "cascade":
+            # BASELINE configs[3]: two-step cascade of bids_two_steps_registration.py:311-325,484-499 on one pair --
+            # model 1 on (moving, fixed), model 2 on (moved_1, fixed), compose the two half-res fields, rescale x2, warp
+            shape = tuple(shape_arg or (160, 160, 192))
+            feats = feats_arg or 256
+            dtype = dtype_arg or "bf16"
+            enc, dec = [feats] * 4, [feats] * 6
+            m1 = mmr.networks.VxmDense(shape, nb_unet_features=(enc, dec), int_steps=5, int_resolution=2, svf_resolution=2,
+                                       compute_dtype=dtype, device=dev, seed=0)
+            m2 = mmr.networks.VxmDense(shape, nb_unet_features=(enc, dec), int_steps=5, int_resolution=2, svf_resolution=2,
+                                       compute_dtype=dtype, device=dev, seed=1)
+            mov, fix = synth_pair(shape, dev, seed=rank)
+
+            def step():
+                o1 = m1.forward(mov, fix)
+                o2 = m2.forward(o1["y_source"], fix)
+                warp = mmr.ops.compose(o1["preint_flow"], o2["preint_flow"])
+                full = mmr.ops.rescale_transform(warp, 2)
+                return mmr.ops.warp3d(mov, full, "linear", None)
+            workload = (f"bids_two_steps_registration.py cascade (BASELINE configs[3]): 2 x VxmDense {shape[0]}x{shape[1]}x{shape[2]}, "
+                        f"enc/dec={feats}, compose + rescale + warp, inputs resident in HBM, 1 pair/step")
+            par = f"replicas x{world}"
+            cpu_fn = None
         elif wl == "train":
             from mmr import synth, training
             shape = tuple(shape_arg or (160, 160, 160))
