@@ -87,6 +87,14 @@ int mmr_conv3d_k3_fwd(const void* in0, int C0, int up0, const void* in1, int C1,
                       const void* w_packed, const float* bias, void* out, void* pool_out,
                       int B, int X, int Y, int Z, int Cout,
                       int leaky, float alpha, int dtype, int out_f32, void* stream);
+/* Same, with an optional scratch buffer of mmr_conv3d_k3_ksplit_ws_bytes(): launches with too few workgroups to
+ * fill the chip (deep U-Net levels, small volumes) then split the K walk over several workgroups per tile and add
+ * the partial tiles in a fixed order (bitwise reproducible).  ws == NULL behaves like mmr_conv3d_k3_fwd. */
+int64_t mmr_conv3d_k3_ksplit_ws_bytes(int B, int X, int Y, int Z, int Cin, int Cout, int dtype);
+int mmr_conv3d_k3_fwd_ws(const void* in0, int C0, int up0, const void* in1, int C1,
+                         const void* w_packed, const float* bias, void* out, void* pool_out,
+                         int B, int X, int Y, int Z, int Cout,
+                         int leaky, float alpha, int dtype, int out_f32, void* ws, void* stream);
 /* First layer: concatenate([moving, fixed]) (2 x 1 channel, fp32) -> Cout. */
 int mmr_conv3d_k3_cin2_fwd(const float* src, const float* trg, const float* w_keras, const float* bias,
                            void* out, void* pool_out, int B, int X, int Y, int Z, int Cout,

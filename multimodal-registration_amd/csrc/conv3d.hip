@@ -57,6 +57,11 @@ struct ConvParams {
     // that PRODUCED this conv's input, fused so that the gradient never makes a separate elementwise pass
     const float* ymask;
     double* part;
+    // split-K for launches with too few workgroups to fill the chip (the 1/8- and 1/16-resolution U-Net levels, small
+    // volumes): blockIdx.z = kz handles the (slice, tap) steps [kz*gsplit, (kz+1)*gsplit) and stores its raw fp32
+    // partial tile to kpart[kz]; a fixed-order finalize kernel adds them, then bias / LeakyReLU / store (reproducible).
+    float* kpart;
+    int gsplit;
 };
 
 template <int DT> struct Elt;
@@ -271,16 +276,18 @@ conv3d_k3_kernel(const ConvParams p)
         }
     };
 
-    // ---- prologue: slice 0 of A, tap 0 of B ----
-    issue_b(0, 0);
+    // ---- prologue: first slice of A, first tap of B of this block's step range ----
+    const int g0 = p.kpart ? (int)blockIdx.z * p.gsplit : 0;
+    const int g1 = p.kpart ? min(g0 + p.gsplit, G) : G;
+    int cur = 0, tap = g0 % 27, s = g0 / 27;
+    issue_b(g0, 0);
 #pragma unroll
-    for (int it = 0; it < A_ITERS; ++it) store_a(it, load_a(0, it));
+    for (int it = 0; it < A_ITERS; ++it) store_a(it, load_a(s, it));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    int cur = 0, tap = 0, s = 0;
-    for (int g = 0; g < G; ++g) {
-        const bool more = g + 1 < G;
+    for (int g = g0; g < g1; ++g) {
+        const bool more = g + 1 < g1;
         if (more) issue_b(g + 1, cur ^ 1);
         const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
         const int tapoff = (dx * (HY * HZ) + dy * HZ + dz) * ROWB;
@@ -469,12 +476,53 @@ conv3d_k3_kernel(const ConvParams p)
         if (++tap == 27) {
             tap = 0;
             ++s;
-            if (s < nslices) {  // every wave is past its last read of sA: install the next slice
+            if (s < nslices && g + 1 < g1) {  // every wave is past its last read of sA: install the next slice
 #pragma unroll
                 for (int it = 0; it < A_ITERS; ++it) store_a(it, load_a(s, it));
                 __syncthreads();
             }
         }
+    }
+
+    // ---- split-K: raw fp32 partial tile, finalised by conv_ksplit_finalize_kernel ----
+    if (p.kpart) {
+        float* kp = p.kpart + (size_t)blockIdx.z * ((size_t)p.B * p.X * p.Y * p.Z * p.Cout);
+        if constexpr (M16) {
+#pragma unroll
+            for (int gi = 0; gi < NT / 2; ++gi) {
+                const int co = ntile * BN + wn * NT * 32 + gi * 64 + q16 * 16;
+#pragma unroll
+                for (int mi = 0; mi < 2 * MT; ++mi) {
+                    const int mt = wm * MT + (mi >> 1);
+                    const int gx = x0 + (mt >> 1), gy = y0 + (mt & 1) * 4 + 2 * (mi & 1) + (r16 >> 3), gz = z0 + (r16 & 7);
+                    if (gx < p.X && gy < p.Y && gz < p.Z) {
+                        const size_t o = ((((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz) * p.Cout + co;
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (co + ni * 4 + r < p.Cout) kp[o + ni * 4 + r] = acc16[mi][gi * 4 + ni][r];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int co = ntile * BN + (wn * NT + n) * 32 + (lane & 31);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int mt = wm * MT + m;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int q = row_perm((r & 3) + 8 * (r >> 2) + 4 * h);
+                        const int gx = x0 + (mt >> 1), gy = y0 + (mt & 1) * 4 + (q >> 3), gz = z0 + (q & 7);
+                        if (co < p.Cout && gx < p.X && gy < p.Y && gz < p.Z)
+                            kp[((((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz) * p.Cout + co] = acc[m][n][r];
+                    }
+                }
+            }
+        }
+        return;
     }
 
     // ---- epilogue: bias + LeakyReLU, store ----
@@ -694,6 +742,32 @@ __global__ void pack_kernel(const float* __restrict__ w, char* __restrict__ wp, 
     }
 }
 
+// out = act(sum_k kpart[k] + bias), summed in index order (bitwise reproducible), fp32 or bf16 store
+__global__ void __launch_bounds__(256)
+conv_ksplit_finalize_kernel(const float* __restrict__ kpart, int nk, const float* __restrict__ bias, void* __restrict__ out,
+                            int64_t n, int Cout, int leaky, float alpha, int out_bf16)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float v = 0.f;
+        for (int k = 0; k < nk; ++k) v += kpart[(int64_t)k * n + i];
+        if (bias) v += bias[i % Cout];
+        if (leaky && v < 0.f) v *= alpha;
+        if (out_bf16) reinterpret_cast<bf16_t*>(out)[i] = f32_to_bf16(v);
+        else reinterpret_cast<float*>(out)[i] = v;
+    }
+}
+
+// Split the K walk when the launch has fewer workgroups than half the CUs and a scratch buffer is offered.
+inline int conv_ksplit(int64_t nblk, int ntiles_n, int G)
+{
+    const int64_t wgs = nblk * ntiles_n;
+    if (wgs >= 128 || G < 18) return 1;
+    int S = (int)((256 + wgs - 1) / wgs);
+    if (S > G / 9) S = G / 9;  // at least 9 taps per block: the A tile is staged per block
+    if (S > 16) S = 16;
+    return S < 2 ? 1 : S;
+}
+
 template <int DT, int WM, int WN, int MT, int NT, int VAR>
 int launch_conv(const ConvParams& p, int ntiles_n, hipStream_t st, int64_t* nblk_out)
 {
@@ -714,6 +788,19 @@ int launch_conv(const ConvParams& p, int ntiles_n, hipStream_t st, int64_t* nblk
     const int64_t nblk = (int64_t)q.B * q.ntx * q.nty * q.ntz;
     if (nblk > 0x7fffffff) return MMR_EINVAL;
     if (nblk_out) *nblk_out = nblk;
+    const int G = ((p.C0 + p.C1) / Elt<DT>::kc) * 27;
+    const int S = (p.kpart && !p.ymask) ? conv_ksplit(nblk, ntiles_n, G) : 1;
+    if (S > 1) {
+        q.gsplit = (G + S - 1) / S;
+        const int nz = (G + q.gsplit - 1) / q.gsplit;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk, ntiles_n, nz), dim3(CONV_THREADS), LDS, st, q);
+        const int64_t n = (int64_t)p.B * p.X * p.Y * p.Z * p.Cout;
+        const bool obf = (DT == MMR_DT_BF16) && !p.out_f32;
+        hipLaunchKernelGGL(conv_ksplit_finalize_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, st, (const float*)p.kpart, nz,
+                           p.bias, (void*)p.out, n, p.Cout, p.leaky, p.alpha, obf ? 1 : 0);
+        return check_launch();
+    }
+    q.kpart = nullptr;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk, ntiles_n), dim3(CONV_THREADS), LDS, st, q);
     return check_launch();
 }
@@ -1435,9 +1522,34 @@ extern "C" int mmr_conv3d_k3_pack(const float* w_keras, void* w_packed, int Cin,
     return check_launch();
 }
 
+// Scratch for the split-K path of small launches (0 when the launch fills the chip on its own): S partial output
+// tensors in fp32.  Passing ws == NULL to mmr_conv3d_k3_fwd_ws (or calling mmr_conv3d_k3_fwd) disables the split.
+extern "C" int64_t mmr_conv3d_k3_ksplit_ws_bytes(int B, int X, int Y, int Z, int Cin, int Cout, int dtype)
+{
+    if (B < 1 || X < 1 || Y < 1 || Z < 1 || Cin < 1 || Cout < 1 || dtype < 0 || dtype > MMR_DT_F32X1) return MMR_EINVAL;
+    const int BN = conv_bn(Cout), nt = (Cout + BN - 1) / BN;
+    const int txt = (BN == 256) ? 4 : 8;
+    const int64_t nblk = (int64_t)B * ((X + txt - 1) / txt) * ((Y + TY - 1) / TY) * ((Z + TZ - 1) / TZ);
+    const int G = (Cin / ((dtype == MMR_DT_BF16) ? 64 : 32)) * 27;
+    const int S = conv_ksplit(nblk, nt, G);
+    return S > 1 ? (int64_t)S * B * X * Y * Z * Cout * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int mmr_conv3d_k3_fwd_ws(const void* in0, int C0, int up0, const void* in1, int C1, const void* w_packed,
+                                    const float* bias, void* out, void* pool_out, int B, int X, int Y, int Z, int Cout,
+                                    int leaky, float alpha, int dtype, int out_f32, void* ws, void* stream);
+
 extern "C" int mmr_conv3d_k3_fwd(const void* in0, int C0, int up0, const void* in1, int C1, const void* w_packed,
                                  const float* bias, void* out, void* pool_out, int B, int X, int Y, int Z, int Cout,
                                  int leaky, float alpha, int dtype, int out_f32, void* stream)
+{
+    return mmr_conv3d_k3_fwd_ws(in0, C0, up0, in1, C1, w_packed, bias, out, pool_out, B, X, Y, Z, Cout, leaky, alpha, dtype,
+                                out_f32, nullptr, stream);
+}
+
+extern "C" int mmr_conv3d_k3_fwd_ws(const void* in0, int C0, int up0, const void* in1, int C1, const void* w_packed,
+                                    const float* bias, void* out, void* pool_out, int B, int X, int Y, int Z, int Cout,
+                                    int leaky, float alpha, int dtype, int out_f32, void* ws, void* stream)
 {
     if (!in0 || !w_packed || !out || B < 1 || X < 1 || Y < 1 || Z < 1 || Cout < 1 || C0 < 1 || C1 < 0) return MMR_EINVAL;
     if (dtype < 0 || dtype > MMR_DT_F32X1) return MMR_EINVAL;
@@ -1451,6 +1563,7 @@ extern "C" int mmr_conv3d_k3_fwd(const void* in0, int C0, int up0, const void* i
     p.out = (char*)out;
     p.B = B; p.X = X; p.Y = Y; p.Z = Z; p.C0 = C0; p.C1 = C1; p.up0 = up0; p.Cout = Cout;
     p.leaky = leaky; p.alpha = alpha; p.out_f32 = out_f32; p.ymask = nullptr; p.part = nullptr;
+    p.kpart = (float*)ws; p.gsplit = 0;
     p.ntx = (X + TX - 1) / TX; p.nty = (Y + TY - 1) / TY; p.ntz = (Z + TZ - 1) / TZ;
     if (dtype == MMR_DT_BF16) return dispatch_conv<MMR_DT_BF16>(p, as_stream(stream));
     if (dtype == MMR_DT_F32X3) return dispatch_conv<MMR_DT_F32X3>(p, as_stream(stream));
@@ -1480,6 +1593,7 @@ extern "C" int mmr_conv3d_k3_dgrad_masked(const void* in0, int C0, const void* w
     p.out = (char*)out;
     p.B = B; p.X = X; p.Y = Y; p.Z = Z; p.C0 = C0; p.C1 = 0; p.up0 = 0; p.Cout = Cout;
     p.leaky = 0; p.alpha = alpha; p.out_f32 = 1; p.ymask = ymask; p.part = (double*)ws;
+    p.kpart = nullptr; p.gsplit = 0;
     p.ntx = (X + TX - 1) / TX; p.nty = (Y + TY - 1) / TY; p.ntz = (Z + TZ - 1) / TZ;
     int64_t nblk = 0;
     int rc;

@@ -182,12 +182,16 @@ def conv3d_k3(in0, w_packed, bias, cout, in1=None, up0=False, leaky=True, alpha=
     out = torch.empty((B, X, Y, Z, cout), dtype=odt, device=in0.device)
     mode = conv_mode(dtype, x3)
     fam = f"conv3d_k3_mfma_{('f32', 'bf16', 'f32x3', 'f32x1')[mode]}_bn{256 if cout % 256 == 0 else 128 if cout % 128 == 0 else 64 if cout % 64 == 0 else 32}"
+    lib = _lib.load()
+    nws = lib.mmr_conv3d_k3_ksplit_ws_bytes(B, X, Y, Z, C0 + C1, int(cout), mode)  # > 0 only for launches that cannot fill the chip
+    ws = _ws(nws, in0.device) if nws > 0 else None
     with _Timed(fam, (C0 + C1, int(cout), X, Y, Z), 2.0 * 27 * (C0 + C1) * cout * B * X * Y * Z):
-        rc = _lib.load().mmr_conv3d_k3_fwd(
+        rc = lib.mmr_conv3d_k3_fwd_ws(
             in0.data_ptr(), C0, int(up0), in1.data_ptr() if in1 is not None else None, C1,
             w_packed.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), None,
-            B, X, Y, Z, int(cout), int(leaky), float(alpha), mode, int(out_f32), _stream())
-    _lib.check(rc, "mmr_conv3d_k3_fwd")
+            B, X, Y, Z, int(cout), int(leaky), float(alpha), mode, int(out_f32),
+            ws.data_ptr() if ws is not None else None, _stream())
+    _lib.check(rc, "mmr_conv3d_k3_fwd_ws")
     return out
 
 

@@ -121,3 +121,33 @@ def test_flow_head_folded_taps(dev, shape, Cin, mode):
     got = mmr.ops.conv3d_k3_cout3(xt, torch.from_numpy(w).to(dev), torch.from_numpy(bias).to(dev), x3=(mode == "fp32x3"))
     assert got.dtype == torch.float32 and tuple(got.shape) == (2,) + shape + (3,)
     assert _scale_err(got.cpu().numpy(), ref) < (1e-5 if mode == "bf16" else 1e-4)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp32x3", "fp32"])
+def test_split_k_small_launch_matches_unsplit(dev, mode):
+    """Few-workgroup launches split the K walk over several workgroups (ws given) -- same result as the unsplit
+    launch up to the summation order, bitwise reproducible, and the work-space query says when it applies."""
+    import mmr
+    from mmr import _lib
+    ops = mmr.ops
+    rng = np.random.default_rng(31)
+    shape, Cin, Cout = (8, 16, 8), 128, 64
+    dt = torch.bfloat16 if mode == "bf16" else torch.float32
+    x3 = mode == "fp32x3"
+    x = torch.from_numpy(rng.standard_normal((1,) + shape + (Cin,)).astype(np.float32)).to(dev).to(dt)
+    w = torch.from_numpy((rng.standard_normal((3, 3, 3, Cin, Cout)) * 0.05).astype(np.float32)).to(dev)
+    b = torch.from_numpy(rng.standard_normal(Cout).astype(np.float32)).to(dev)
+    wp = ops.pack_conv_weights(w, dt, x3=x3)
+    lib = _lib.load()
+    m = ops.conv_mode(dt, x3)
+    assert lib.mmr_conv3d_k3_ksplit_ws_bytes(1, *shape, Cin, Cout, m) > 0
+    assert lib.mmr_conv3d_k3_ksplit_ws_bytes(1, 160, 160, 160, Cin, Cout, m) == 0
+    y1 = ops.conv3d_k3(x, wp, b, Cout, leaky=True, x3=x3)       # split path (ws allocated by the wrapper)
+    y2 = ops.conv3d_k3(x, wp, b, Cout, leaky=True, x3=x3)
+    assert torch.equal(y1, y2)
+    ref = torch.empty_like(y1)
+    rc = lib.mmr_conv3d_k3_fwd(x.data_ptr(), Cin, 0, None, 0, wp.data_ptr(), b.data_ptr(), ref.data_ptr(), None, 1, *shape, Cout,
+                               1, 0.2, m, 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    tol = 1e-2 if mode == "bf16" else 1e-5  # other summation order over K = 3456 (bf16: output rounding on top)
+    assert float((y1.float() - ref.float()).abs().max()) <= tol * float(ref.float().abs().max())

@@ -356,7 +356,8 @@ def test_dgrad_masked_equals_dgrad_then_leaky_bwd(dev, shape, Cmid, Cin, x3):
     ref = ops.leaky_bwd_bias_(y, ref, db_ref, leaky=True)
     db = torch.full((Cin,), 7.0, device=dev)
     got = ops.conv3d_k3_dgrad_masked(dz, wt, Cin, y, db, x3=x3)
-    assert torch.equal(got, ref)
+    # same MFMA arithmetic; the unfused conv of such a small volume takes the split-K path (other summation order)
+    assert _rel(got, ref) < 2e-6
     assert _rel(db, db_ref) < 1e-5
     db2 = db.clone()
     ops.conv3d_k3_dgrad_masked(dz, wt, Cin, y, db2, accumulate=True, x3=x3)
