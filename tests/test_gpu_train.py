@@ -229,14 +229,21 @@ def test_adam_matches_keras_formula(dev):
     np.testing.assert_allclose(wt.cpu().numpy(), ref, rtol=2e-5, atol=1e-6)
 
 
+_ARCHS = [([32, 32], [32, 32, 32]),               # 32-wide: 32x32 MFMA kernels (BN = 32)
+          ([64, 64], [64, 64, 64]),               # 64-wide: 16x16x32 kernels with the transposed epilogue
+          ([32, 64, 64], [64, 64, 32, 32, 32])]   # three levels, mixed widths
+
+
 @pytest.mark.parametrize("cdt", ["fp32", "fp32x3"])
-def test_full_training_step_gradients(dev, cdt):
-    """One SynthMorph step on a tiny U-Net: every one of the 22 gradient tensors vs autograd."""
+@pytest.mark.parametrize("enc,dec", _ARCHS)
+def test_full_training_step_gradients(dev, cdt, enc, dec):
+    """One SynthMorph step on a tiny U-Net: every gradient tensor vs autograd (several widths / depths, so that the
+    pre-masked gradient bookkeeping sees plain, concat and pooled consumers on both conv kernel families)."""
     import mmr
     from mmr import synth, training
     from oracle import grad_torch as G
     from oracle import net_np
-    shape, enc, dec, L, B = (16, 16, 32), [32, 32], [32, 32, 32], 5, 2
+    shape, L, B = (16, 16, 32), 5, 2
     rng = np.random.default_rng(7)
     coarse = rng.integers(0, L, (B, 4, 4, 8))
     lab_s = np.repeat(np.repeat(np.repeat(coarse, 4, 1), 4, 2), 4, 3).astype(np.uint8)[..., None]
@@ -278,9 +285,13 @@ def test_full_training_step_gradients(dev, cdt):
     names = [p[0] for p in model.plan]
     for i, (g, w) in enumerate(zip(tr.g, wt)):
         err = _rel(g, w.grad)
-        # fp32: exact-fp32 MFMA; fp32x3: every product carries ~5e-6 relative error, which the long
-        # cancelling sums of the earliest layers' weight gradients amplify (forward outputs stay < 1e-4)
-        assert err < (2e-4 if cdt == "fp32" else 1e-3), f"{names[i // 2]} {'bias' if i % 2 else 'kernel'}: {err:.2e}"
+        # fp32: exact-fp32 MFMA, 2e-4 on every tensor of every architecture -> this pins the gradient bookkeeping.
+        # fp32x3: every product carries ~1e-5 relative error (the lo*lo term is dropped); the FORWARD stays < 1e-4, but
+        # a weight gradient is a sum over all voxels of x*dz with heavy cancellation (activations have a DC part, dz
+        # sums to ~0), which amplifies that error: measured <= 1e-3 on most tensors, 3e-3 / 1.6e-2 on the kernels of the
+        # first two layers of the three-level net (their bias gradients, i.e. dz itself, are at 3e-4).
+        tol = 2e-4 if cdt == "fp32" else 3e-2
+        assert err < tol, f"{names[i // 2]} {'bias' if i % 2 else 'kernel'}: {err:.2e}"
 
 
 def test_training_lowers_loss_and_is_reproducible(dev):
