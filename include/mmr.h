@@ -224,6 +224,13 @@ int64_t mmr_maxpool3d2_bwd_masked_ws_bytes(int C);
 int mmr_maxpool3d2_bwd_masked_f32(const float* x, const float* dpool, float* dx, int B, int X, int Y, int Z, int C,
                                   int accumulate, int masked, float alpha, float* dbias, int acc_b, void* ws,
                                   void* stream);
+/* Data gradient of a layer whose input was concat([up2(in0) | in0, in1]), stored split: d0 = the C0 leading channels
+ * (compact, to be pool-summed), d1 = the C1 skip channels times LeakyReLU'(y1) (y1 may be NULL) with dbias1 (+)= their
+ * column sums -- the concatenated gradient is never materialised.  MMR_EUNSUPPORTED outside the 16x16x32 kernels. */
+int64_t mmr_conv3d_k3_dgrad_split_ws_bytes(int B, int X, int Y, int Z, int C1);
+int mmr_conv3d_k3_dgrad_split(const void* dz, int Cz, const void* w_packed, float* d0, float* d1, int B, int X, int Y, int Z,
+                              int C0, int C1, const float* y1, float alpha, float* dbias1, void* ws, int accumulate,
+                              int dtype, void* stream);
 /* Same fusion for the flow head's data gradient (Cin % 64 == 0, else MMR_EUNSUPPORTED -> use the unfused pair). */
 int64_t mmr_conv3d_k3_cout3_dgrad_masked_ws_bytes(int B, int X, int Y, int Z, int Cin);
 int mmr_conv3d_k3_cout3_dgrad_masked_f32(const float* dy, const float* w_keras, float* dx, int B, int X, int Y, int Z,

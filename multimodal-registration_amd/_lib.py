@@ -73,6 +73,8 @@ SIGNATURES = {
     "mmr_ncc_bwd_ws_bytes": (c_int64, [I, I, I, I]),
     "mmr_ncc_bwd_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, F, P]),
     "mmr_bending_bwd_f32": (I, [P, P, P, I, I, I, I, I, P]),
+    "mmr_conv3d_k3_dgrad_split_ws_bytes": (c_int64, [I, I, I, I, I]),
+    "mmr_conv3d_k3_dgrad_split": (I, [P, I, P, P, P, I, I, I, I, I, I, P, F, P, P, I, I, P]),
     "mmr_upcat_bwd_masked_ws_bytes": (c_int64, [I, I]),
     "mmr_upcat_bwd_masked_f32": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P, F, P, I, P, I, P, P]),
     "mmr_maxpool3d2_bwd_masked_ws_bytes": (c_int64, [I]),

@@ -62,6 +62,11 @@ struct ConvParams {
     // partial tile to kpart[kz]; a fixed-order finalize kernel adds them, then bias / LeakyReLU / store (reproducible).
     float* kpart;
     int gsplit;
+    // split store (16x16x32 kernels, training dgrad of a concat layer): output channels [0, csplit) go to `out` with
+    // row stride csplit, channels [csplit, Cout) to `out1` with row stride Cout - csplit; ymask / part then refer to
+    // the second range only (the skip tensor's LeakyReLU backward + bias sums)
+    char* out1;
+    int csplit;
 };
 
 template <int DT> struct Elt;
@@ -535,7 +540,13 @@ conv3d_k3_kernel(const ConvParams p)
         static_assert(NT == 2, "16x16x32 path: 64 columns per wave");
         const int cl = wn * 64 + q16 * 16;
         const int co = ntile * BN + cl;
-        const bool vec = (co + 15 < p.Cout) && !(p.Cout & 7);
+        const int cs = p.csplit;
+        const bool second = cs > 0 && co >= cs;
+        const int ostride = cs ? (second ? p.Cout - cs : cs) : p.Cout;  // row stride and column of this lane's block
+        const int ocol = second ? co - cs : co;
+        char* const optr = second ? p.out1 : p.out;
+        const bool domask = p.ymask && (!cs || second);
+        const bool vec = (co + 15 < p.Cout) && !(ostride & 7) && !(cs & 15);
         float bv[4][4], csum[4][4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
@@ -549,7 +560,7 @@ conv3d_k3_kernel(const ConvParams p)
             const int mt = wm * MT + (mi >> 1);
             const int gx = x0 + (mt >> 1), gy = y0 + (mt & 1) * 4 + 2 * (mi & 1) + (r16 >> 3), gz = z0 + (r16 & 7);
             if (co < p.Cout && gx < p.X && gy < p.Y && gz < p.Z) {
-                const size_t o = ((((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz) * p.Cout + co;
+                const size_t o = ((((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz) * ostride + ocol;
                 float val[4][4];
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
@@ -559,7 +570,7 @@ conv3d_k3_kernel(const ConvParams p)
                         if (p.leaky && val[ni][r] < 0.f) val[ni][r] *= p.alpha;
                     }
                 if (vec) {
-                    if (p.ymask) {
+                    if (domask) {
 #pragma unroll
                         for (int ni = 0; ni < 4; ++ni) {
                             const float4 ym = *reinterpret_cast<const float4*>(p.ymask + o + ni * 4);
@@ -572,12 +583,12 @@ conv3d_k3_kernel(const ConvParams p)
                         }
                     }
                     if (store_f32) {
-                        float* po = reinterpret_cast<float*>(p.out) + o;
+                        float* po = reinterpret_cast<float*>(optr) + o;
 #pragma unroll
                         for (int ni = 0; ni < 4; ++ni)
                             *reinterpret_cast<float4*>(po + ni * 4) = make_float4(val[ni][0], val[ni][1], val[ni][2], val[ni][3]);
                     } else {
-                        bf16_t* po = reinterpret_cast<bf16_t*>(p.out) + o;
+                        bf16_t* po = reinterpret_cast<bf16_t*>(optr) + o;
 #pragma unroll
                         for (int k = 0; k < 2; ++k) {
                             uint4 pk;
@@ -595,12 +606,12 @@ conv3d_k3_kernel(const ConvParams p)
                         for (int r = 0; r < 4; ++r) {
                             const int e = ni * 4 + r;
                             if (co + e < p.Cout) {
-                                if (p.ymask) {
+                                if (domask) {
                                     if (p.ymask[o + e] < 0.f) val[ni][r] *= p.alpha;
                                     csum[ni][r] += val[ni][r];
                                 }
-                                if (store_f32) reinterpret_cast<float*>(p.out)[o + e] = val[ni][r];
-                                else reinterpret_cast<bf16_t*>(p.out)[o + e] = f32_to_bf16(val[ni][r]);
+                                if (store_f32) reinterpret_cast<float*>(optr)[o + e] = val[ni][r];
+                                else reinterpret_cast<bf16_t*>(optr)[o + e] = f32_to_bf16(val[ni][r]);
                             }
                         }
                 }
@@ -621,11 +632,12 @@ conv3d_k3_kernel(const ConvParams p)
         }
         if (p.ymask) {
             __syncthreads();
-            if (tid < BN && ntile * BN + tid < p.Cout) {
+            const int col = ntile * BN + tid;
+            if (tid < BN && col < p.Cout && col >= p.csplit) {
                 double t = 0.0;
 #pragma unroll
                 for (int k = 0; k < WM; ++k) t += (double)s_col[k * BN + tid];
-                p.part[(size_t)blockIdx.x * p.Cout + ntile * BN + tid] = t;
+                p.part[(size_t)blockIdx.x * (p.Cout - p.csplit) + (col - p.csplit)] = t;
             }
         }
         return;
@@ -1563,7 +1575,7 @@ extern "C" int mmr_conv3d_k3_fwd_ws(const void* in0, int C0, int up0, const void
     p.out = (char*)out;
     p.B = B; p.X = X; p.Y = Y; p.Z = Z; p.C0 = C0; p.C1 = C1; p.up0 = up0; p.Cout = Cout;
     p.leaky = leaky; p.alpha = alpha; p.out_f32 = out_f32; p.ymask = nullptr; p.part = nullptr;
-    p.kpart = (float*)ws; p.gsplit = 0;
+    p.kpart = (float*)ws; p.gsplit = 0; p.out1 = nullptr; p.csplit = 0;
     p.ntx = (X + TX - 1) / TX; p.nty = (Y + TY - 1) / TY; p.ntz = (Z + TZ - 1) / TZ;
     if (dtype == MMR_DT_BF16) return dispatch_conv<MMR_DT_BF16>(p, as_stream(stream));
     if (dtype == MMR_DT_F32X3) return dispatch_conv<MMR_DT_F32X3>(p, as_stream(stream));
@@ -1593,7 +1605,7 @@ extern "C" int mmr_conv3d_k3_dgrad_masked(const void* in0, int C0, const void* w
     p.out = (char*)out;
     p.B = B; p.X = X; p.Y = Y; p.Z = Z; p.C0 = C0; p.C1 = 0; p.up0 = 0; p.Cout = Cout;
     p.leaky = 0; p.alpha = alpha; p.out_f32 = 1; p.ymask = ymask; p.part = (double*)ws;
-    p.kpart = nullptr; p.gsplit = 0;
+    p.kpart = nullptr; p.gsplit = 0; p.out1 = nullptr; p.csplit = 0;
     p.ntx = (X + TX - 1) / TX; p.nty = (Y + TY - 1) / TY; p.ntz = (Z + TZ - 1) / TZ;
     int64_t nblk = 0;
     int rc;
@@ -1602,6 +1614,41 @@ extern "C" int mmr_conv3d_k3_dgrad_masked(const void* in0, int C0, const void* w
     else rc = dispatch_conv<MMR_DT_F32>(p, as_stream(stream), &nblk);
     if (rc != MMR_OK) return rc;
     hipLaunchKernelGGL(colsum_final_kernel, dim3(Cout), dim3(64), 0, as_stream(stream), (const double*)ws, dbias, Cout,
+                       (int)nblk, accumulate);
+    return check_launch();
+}
+
+extern "C" int64_t mmr_conv3d_k3_dgrad_split_ws_bytes(int B, int X, int Y, int Z, int C1)
+{
+    return (int64_t)B * ((X + TX - 1) / TX) * ((Y + TY - 1) / TY) * ((Z + TZ - 1) / TZ) * C1 * (int64_t)sizeof(double);
+}
+
+// Data gradient of a conv whose input was concat([up2(in0) | in0, in1]): the first C0 gradient channels are stored
+// compactly to d0 [B,X,Y,Z,C0] (to be pool-summed by mmr_upcat_bwd_masked_f32 with C1 = 0), the last C1 channels
+// directly to d1 [B,X,Y,Z,C1], multiplied by LeakyReLU'(y1) with dbias1 (+)= their column sums when y1 is given.
+// The full concatenated gradient is never materialised.  16x16x32 kernels only (fp32x3 / x1, Cout = C0 + C1 a multiple
+// of 64, C0 and C1 multiples of 16), else MMR_EUNSUPPORTED.
+extern "C" int mmr_conv3d_k3_dgrad_split(const void* dz, int Cz, const void* w_packed, float* d0, float* d1, int B, int X,
+                                         int Y, int Z, int C0, int C1, const float* y1, float alpha, float* dbias1,
+                                         void* ws, int accumulate, int dtype, void* stream)
+{
+    if (!dz || !w_packed || !d0 || !d1 || B < 1 || X < 1 || Y < 1 || Z < 1 || C0 < 1 || C1 < 1 || Cz < 1) return MMR_EINVAL;
+    if (y1 && (!dbias1 || !ws)) return MMR_EINVAL;
+    if (dtype != MMR_DT_F32X3 && dtype != MMR_DT_F32X1) return MMR_EUNSUPPORTED;
+    const int Cout = C0 + C1;
+    if (Cz % 32 || !conv_uses_m16(dtype, conv_bn(Cout)) || (C0 & 15) || (C1 & 15)) return MMR_EUNSUPPORTED;
+    ConvParams p;
+    p.in0 = (const char*)dz; p.in1 = nullptr; p.wp = (const char*)w_packed; p.bias = nullptr;
+    p.out = (char*)d0; p.out1 = (char*)d1; p.csplit = C0;
+    p.B = B; p.X = X; p.Y = Y; p.Z = Z; p.C0 = Cz; p.C1 = 0; p.up0 = 0; p.Cout = Cout;
+    p.leaky = 0; p.alpha = alpha; p.out_f32 = 1; p.ymask = y1; p.part = (double*)ws;
+    p.kpart = nullptr; p.gsplit = 0;
+    p.ntx = (X + TX - 1) / TX; p.nty = (Y + TY - 1) / TY; p.ntz = (Z + TZ - 1) / TZ;
+    int64_t nblk = 0;
+    const int rc = (dtype == MMR_DT_F32X3) ? dispatch_conv<MMR_DT_F32X3>(p, as_stream(stream), &nblk)
+                                           : dispatch_conv<MMR_DT_F32X1>(p, as_stream(stream), &nblk);
+    if (rc != MMR_OK || !y1) return rc;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(C1), dim3(64), 0, as_stream(stream), (const double*)ws, dbias1, C1,
                        (int)nblk, accumulate);
     return check_launch();
 }

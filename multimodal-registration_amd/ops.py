@@ -4,6 +4,8 @@ torch is used for device memory and streams only; every arithmetic operation
 below is a call into libmmr_hip.so.  Shapes are channels-last.  All functions
 raise on CPU tensors: there is no CPU path in the product.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -215,6 +217,37 @@ def conv3d_k3_dgrad_masked(dz, wt_packed, cin, ymask, dbias, alpha=0.2, accumula
                                             int(accumulate), mode, _stream())
     _lib.check(rc, "mmr_conv3d_k3_dgrad_masked")
     return out
+
+
+def dgrad_split_supported(C0, C1, x3):
+    """The split-store dgrad runs on the 16x16x32 kernels only (fp32x3 / x1, 64-column tiles)."""
+    if os.environ.get("MMR_NO_DGRAD_SPLIT"):  # A/B runs
+        return False
+    return bool(x3) and (C0 + C1) % 64 == 0 and C0 % 16 == 0 and C1 % 16 == 0
+
+
+def conv3d_k3_dgrad_split(dz, wt_packed, C0, C1, y1=None, dbias1=None, alpha=0.2, accumulate=False, x3=True):
+    """d(concat input) of a k3 conv stored split: (d0 [B,X,Y,Z,C0] compact, d1 [B,X,Y,Z,C1] times LeakyReLU'(y1) with
+    dbias1 (+)= its column sums).  Returns None when the kernel family does not cover the shape (caller falls back to
+    conv3d_k3 + upcat_bwd)."""
+    _chk(dz, torch.float32, "dz")
+    B, X, Y, Z, Cz = dz.shape
+    mode = conv_mode(torch.float32, x3)
+    lib = _lib.load()
+    d0 = torch.empty((B, X, Y, Z, C0), dtype=torch.float32, device=dz.device)
+    d1 = torch.empty((B, X, Y, Z, C1), dtype=torch.float32, device=dz.device)
+    ws = _ws(lib.mmr_conv3d_k3_dgrad_split_ws_bytes(B, X, Y, Z, C1), dz.device) if y1 is not None else None
+    cin = C0 + C1
+    fam = f"conv3d_k3_mfma_{('f32', 'bf16', 'f32x3', 'f32x1')[mode]}_bn{256 if cin % 256 == 0 else 128 if cin % 128 == 0 else 64 if cin % 64 == 0 else 32}"
+    with _Timed(fam, (Cz, cin, X, Y, Z), 2.0 * 27 * Cz * cin * B * X * Y * Z):
+        rc = lib.mmr_conv3d_k3_dgrad_split(dz.data_ptr(), Cz, wt_packed.data_ptr(), d0.data_ptr(), d1.data_ptr(), B, X, Y, Z,
+                                           int(C0), int(C1), y1.data_ptr() if y1 is not None else None, float(alpha),
+                                           dbias1.data_ptr() if y1 is not None else None,
+                                           ws.data_ptr() if ws is not None else None, int(accumulate), mode, _stream())
+    if rc == -3:  # MMR_EUNSUPPORTED
+        return None
+    _lib.check(rc, "mmr_conv3d_k3_dgrad_split")
+    return d0, d1
 
 
 def conv3d_k3_cin2(src, trg, w_keras, bias, out_dtype, leaky=True, alpha=0.2, x3=False):

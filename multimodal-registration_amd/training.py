@@ -184,6 +184,25 @@ class SynthMorphTrainer:
                         db, acc = bias_of(x)
                         dcat = ops.conv3d_k3_dgrad_masked(dz, wt, C0, x, db, accumulate=acc, x3=self.bwd_x3)
                         premasked.add(id(x))
+                    elif (up0 and in1 is not None and id(in1) not in grads
+                          and ops.dgrad_split_supported(C0, C1, self.bwd_x3)):
+                        # concat layer: the skip half of the gradient leaves the conv epilogue already masked, the
+                        # upsampled half compact; the concatenated gradient is never written
+                        kw1 = {}
+                        if want_mask(in1):
+                            kw1["y1"] = in1
+                            kw1["dbias1"], kw1["accumulate"] = bias_of(in1)
+                            premasked.add(id(in1))
+                        d0c, d1 = ops.conv3d_k3_dgrad_split(dz, wt, C0, C1, x3=self.bwd_x3, **kw1)
+                        grads[id(in1)] = d1
+                        kw0 = {}
+                        if want_mask(x):
+                            kw0["y0"] = x
+                            kw0["dbias0"], kw0["acc_b0"] = bias_of(x)
+                            premasked.add(id(x))
+                        add_grad(x, ops.upcat_bwd(d0c, C0, 0, True, **kw0)[0])
+                        del dz, dy, d0c
+                        continue
                     else:
                         dcat = ops.conv3d_k3(dz, wt, None, C0 + C1, leaky=False, out_f32=True, x3=self.bwd_x3)
                 del dz, dy

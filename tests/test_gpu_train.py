@@ -489,3 +489,30 @@ def test_dense_dice_backward(dev):
     G.dice_loss(torch.from_numpy(t).double(), pt).backward()
     got = mmr.losses.Dice().grad(_t(t, dev), _t(p, dev))
     assert _rel(got, pt.grad) < 1e-5 and float(got[..., L - 1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("shape,C0,C1,Cz", [((8, 8, 8), 64, 64, 64), ((6, 10, 4), 32, 32, 32), ((4, 16, 8), 64, 64, 128)])
+@pytest.mark.parametrize("x3", [True, "hi"])
+def test_dgrad_split_equals_dgrad_then_upcat(dev, shape, C0, C1, Cz, x3):
+    """Split-store dgrad of a concat layer (skip half masked in the epilogue, upsampled half compact) against
+    conv3d_k3 -> upcat_bwd with the same masks."""
+    import mmr
+    ops = mmr.ops
+    rng = np.random.default_rng(13)
+    assert ops.dgrad_split_supported(C0, C1, x3) and not ops.dgrad_split_supported(C0, C1, False)
+    dz = _t(rng.standard_normal((1,) + shape + (Cz,)).astype(np.float32), dev)
+    w = _t((rng.standard_normal((3, 3, 3, C0 + C1, Cz)) * 0.05).astype(np.float32), dev)  # forward kernel (C0+C1) -> Cz
+    half = tuple(s // 2 for s in shape)
+    y0 = _t(rng.standard_normal((1,) + half + (C0,)).astype(np.float32), dev)
+    y1 = _t(rng.standard_normal((1,) + shape + (C1,)).astype(np.float32), dev)
+    wt = ops.pack_conv_weights(w, torch.float32, transpose_flip=True, x3=x3)
+    dcat = ops.conv3d_k3(dz, wt, None, C0 + C1, leaky=False, out_f32=True, x3=x3)
+    b0r, b1r = torch.zeros(C0, device=dev), torch.zeros(C1, device=dev)
+    r0, r1 = ops.upcat_bwd(dcat, C0, C1, True, y0=y0, dbias0=b0r, y1=y1, dbias1=b1r)
+    b0, b1 = torch.full((C0,), 3.0, device=dev), torch.full((C1,), -1.0, device=dev)
+    d0c, d1 = ops.conv3d_k3_dgrad_split(dz, wt, C0, C1, y1=y1, dbias1=b1, x3=x3)
+    g0, _ = ops.upcat_bwd(d0c, C0, 0, True, y0=y0, dbias0=b0)
+    assert _rel(d1, r1) < 2e-6 and _rel(g0, r0) < 2e-6       # the unfused conv of these small volumes is split-K
+    assert _rel(b1, b1r) < 1e-5 and _rel(b0, b0r) < 1e-5
+    d0u, d1u = ops.conv3d_k3_dgrad_split(dz, wt, C0, C1, x3=x3)  # no mask
+    assert _rel(d1u, dcat[..., C0:]) < 2e-6 and _rel(d0u, dcat[..., :C0]) < 2e-6
