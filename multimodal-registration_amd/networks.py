@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .layers import to_device
+from .layers import d2h_volume, h2d_volume, to_device
 
 DEFAULT_FEATURES = [[16, 32, 32, 32], [32, 32, 32, 32, 32, 16, 16]]
 
@@ -393,11 +393,13 @@ class VxmDense:
         out_m, out_f = [], []
         n = np.asarray(src).shape[0] if not isinstance(src, torch.Tensor) else src.shape[0]
         for b in range(n):  # Keras predicts in batches; one pair at a time bounds activation memory
-            s = to_device(src[b:b + 1], device=self.device)
-            t = to_device(trg[b:b + 1], device=self.device)
+            s = h2d_volume(src[b:b + 1], self.device, tag=0)
+            t = h2d_volume(trg[b:b + 1], self.device, tag=1)
             o = self.forward(s, t)
-            out_m.append(o["y_source"].cpu().numpy())
-            out_f.append(o["preint_flow"].cpu().numpy())
+            out_m.append(d2h_volume(o["y_source"], tag=0))
+            out_f.append(d2h_volume(o["preint_flow"], tag=1))
+        if n == 1:
+            return [out_m[0], out_f[0]]
         return [np.concatenate(out_m), np.concatenate(out_f)]
 
 
@@ -418,12 +420,12 @@ class Transform:
 
     def predict(self, inputs, batch_size=None, verbose=0):
         vol, trf = inputs
-        v = to_device(vol, device=self.device)
-        t = to_device(trf, device=self.device)
+        v = h2d_volume(vol, self.device, tag=2)
+        t = h2d_volume(trf, self.device, tag=3)
         if v.dim() == 4:
             v = v[..., None].contiguous()
         if tuple(v.shape[1:4]) != self.inshape or v.shape[-1] != self.nb_feats:
             raise ValueError(f"volume shape {tuple(v.shape)} does not match Transform{self.inshape + (self.nb_feats,)}")
         if self.rescale is not None:
             t = ops.resize_trilinear(t, self.inshape, mul=float(self.rescale), pre_scale=self.rescale >= 1)
-        return ops.warp3d(v, t, self.interp_method, self.fill_value).cpu().numpy()
+        return d2h_volume(ops.warp3d(v, t, self.interp_method, self.fill_value), tag=2)
