@@ -5,7 +5,7 @@ import torch
 from . import ops
 
 
-_ASYNC_H2D_BYTES = 1 << 20
+_ASYNC_H2D_BYTES = 32 << 20  # covers the per-step uint8 label maps of the trainer (4 MB at 160^3)
 
 
 def to_device(a, dtype=torch.float32, device="cuda"):
@@ -14,7 +14,7 @@ def to_device(a, dtype=torch.float32, device="cuda"):
         return a.to(device=device, dtype=dtype).contiguous()
     t = torch.from_numpy(np.ascontiguousarray(a))
     if torch.device(device).type == "cuda" and t.numel() * t.element_size() <= _ASYNC_H2D_BYTES:
-        # small per-step parameters (generator draws, blur kernels, ...): a pageable copy would block the host until the
+        # per-step inputs (label maps, generator draws, blur kernels, ...): a pageable copy would block the host until the
         # stream reaches it, i.e. until the previous step has finished, and the GPU then idles between the generator's
         # small kernels; pinned + non_blocking keeps the host running ahead (the pinned block is recycled by torch's
         # caching host allocator only after the copy's event)
