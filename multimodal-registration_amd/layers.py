@@ -5,20 +5,51 @@ import torch
 from . import ops
 
 
-_ASYNC_H2D_BYTES = 32 << 20  # covers the per-step uint8 label maps of the trainer (4 MB at 160^3)
+_ASYNC_H2D_BYTES = 1 << 20  # small per-step parameters only: CPU writes into pinned (uncached) memory run at ~1 GB/s
+                            # here, so volumes go through data.gen_synthmorph_eb(device=) / h2d_volume instead
+
+
+_RING = {}      # (shape, dtype) -> [next index, [(pinned tensor, event | None)] * _RING_N]
+_RING_N = 4
+_RING_KEYS_MAX = 32
+
+
+def _ring_slot(shape, dtype):
+    """Next pinned staging buffer of a small per-shape ring; waits for the copy that last used it (never in practice:
+    the host is at most one step ahead).  torch's own pin_memory() would call hipHostMalloc whenever its cached blocks
+    are still owned by in-flight copies -- and that call synchronises with the device."""
+    key = (tuple(shape), dtype)
+    ring = _RING.get(key)
+    if ring is None:
+        if len(_RING) >= _RING_KEYS_MAX:
+            _RING.pop(next(iter(_RING)))
+        ring = _RING[key] = [0, [[torch.empty(tuple(shape), dtype=dtype).pin_memory(), None] for _ in range(_RING_N)]]
+    slot = ring[1][ring[0]]
+    ring[0] = (ring[0] + 1) % _RING_N
+    if slot[1] is not None:
+        slot[1].synchronize()
+    return slot
 
 
 def to_device(a, dtype=torch.float32, device="cuda"):
     """NumPy / tensor -> contiguous device tensor (Keras casts float64 inputs to fp32)."""
     if isinstance(a, torch.Tensor):
         return a.to(device=device, dtype=dtype).contiguous()
-    t = torch.from_numpy(np.ascontiguousarray(a))
-    if torch.device(device).type == "cuda" and t.numel() * t.element_size() <= _ASYNC_H2D_BYTES:
+    a = np.asarray(a)
+    if torch.device(device).type == "cuda" and a.size * np.dtype(a.dtype).itemsize <= _ASYNC_H2D_BYTES and a.size > 0:
         # per-step inputs (label maps, generator draws, blur kernels, ...): a pageable copy would block the host until the
         # stream reaches it, i.e. until the previous step has finished, and the GPU then idles between the generator's
-        # small kernels; pinned + non_blocking keeps the host running ahead (the pinned block is recycled by torch's
-        # caching host allocator only after the copy's event)
-        return t.to(dtype).pin_memory().to(device=device, non_blocking=True).contiguous()
+        # small kernels; a pinned staging ring + non_blocking copy keeps the host running ahead
+        slot = _ring_slot(a.shape, dtype)
+        if any(st < 0 for st in a.strides):
+            a = np.ascontiguousarray(a)  # torch cannot wrap negative strides (np.flip views of the batch generator)
+        slot[0].copy_(torch.from_numpy(a))
+        out = slot[0].to(device=device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(out.device))
+        slot[1] = ev
+        return out
+    t = torch.from_numpy(np.ascontiguousarray(a))
     return t.to(device=device, dtype=dtype).contiguous()
 
 

@@ -334,11 +334,12 @@ def run_training(config, label_maps=None, device="cuda", rank=0, world_size=1, p
     gen_tr = data.gen_synthmorph_eb(maps_tr, batch_size=data_cfg["batch_size"], same_subj=data_cfg["same_subj"], flip=True,
                                     random_zero_borders=data_cfg["zero_borders_maps"],
                                     scale_zero_borders=data_cfg["zero_bord_scale"], frac_zero_bord=data_cfg["zero_bord_frac"],
-                                    rng=np.random.default_rng(seed))
+                                    rng=np.random.default_rng(seed), device=device)  # label maps stay in HBM
     gen_val = data.gen_synthmorph_eb(maps_val, batch_size=data_cfg["batch_size_val"], same_subj=data_cfg["same_subj"],
                                      flip=True, random_zero_borders=data_cfg["zero_borders_maps_val"],
                                      scale_zero_borders=data_cfg["zero_bord_scale"],
-                                     frac_zero_bord=data_cfg["zero_bord_frac"], rng=np.random.default_rng(seed + 1)) if maps_val else None
+                                     frac_zero_bord=data_cfg["zero_bord_frac"], rng=np.random.default_rng(seed + 1),
+                                     device=device) if maps_val else None
     in_shape = label_maps[0].shape
     gen_args = dict(in_shape=in_shape, in_label_list=labels_in, out_label_list=labels_in, warp_std=data_cfg["vel_std"],
                     warp_res=data_cfg["vel_res"], blur_std=data_cfg["blur_std"], bias_std=data_cfg["bias_std"],

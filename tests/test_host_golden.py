@@ -63,3 +63,24 @@ def test_batch_generator_golden():
             if kw["same_subj"] and not kw["random_zero_borders"]:
                 assert np.array_equal(src, trg)
         assert voids[0].shape == tuple(G[f"gen{i}_void_shape"]) and str(voids[0].dtype) == str(G[f"gen{i}_void_dtype"])
+
+
+def test_resident_batch_generator_matches_host_generator():
+    """gen_synthmorph_eb(device=...) keeps the label maps on the device and must yield exactly the host batches
+    (same RNG call order); run here on the CPU device."""
+    import torch
+    from mmr import data
+    rng = np.random.default_rng(3)
+    maps = [rng.integers(0, 7, (12, 10, 14)).astype(np.uint8) for _ in range(5)]
+    for same_subj, bs in ((False, 2), (True, 1)):
+        np.random.seed(11)
+        host = data.gen_synthmorph_eb(maps, batch_size=bs, same_subj=same_subj, flip=True, rng=np.random.default_rng(5))
+        hb = [next(host) for _ in range(6)]
+        np.random.seed(11)
+        devg = data.gen_synthmorph_eb(maps, batch_size=bs, same_subj=same_subj, flip=True, rng=np.random.default_rng(5),
+                                      device=torch.device("cpu"))
+        for (hs, ht), _ in hb:
+            (ds, dt_), void = next(devg)
+            assert isinstance(ds, torch.Tensor) and ds.dtype == torch.uint8 and tuple(ds.shape) == hs.shape
+            assert np.array_equal(ds.numpy(), hs) and np.array_equal(dt_.numpy(), ht)
+            assert void[0].shape == (bs, 12, 10, 14, 3)
