@@ -14,8 +14,8 @@ kw = dict(in_shape=S, in_label_list=lab, out_label_list=lab, warp_std=3, warp_re
 g1, g2 = synth.labels_to_image(**kw, id=0, seed=11), synth.labels_to_image(**kw, id=1, seed=12)
 model = mmr.networks.VxmDense(S, nb_unet_features=([64] * 4, [64] * 6), int_steps=5, int_resolution=2, svf_resolution=2,
                               compute_dtype="fp32x3", device=dev, seed=0)
-tr = training.SynthMorphTrainer(model, g1, g2, reg_param=1.0, optimizer=training.Adam(1e-4))
-gen = data.gen_synthmorph_eb(list(maps), batch_size=1, same_subj=False, flip=True, rng=np.random.default_rng(0), device=dev)
+tr = training.SynthMorphTrainer(model, g1, g2, reg_param=1.0, optimizer=training.Adam(float(os.environ.get("MMR_SOAK_LR", "1e-4"))))
+gen = data.gen_synthmorph_eb(list(maps), batch_size=1, same_subj=bool(os.environ.get("MMR_SOAK_SAME")), flip=True, rng=np.random.default_rng(0), device=dev)
 h0 = tr.fit(gen, epochs=1, steps_per_epoch=10, verbose=0)
 torch.cuda.synchronize()
 m0 = torch.cuda.memory_allocated(), torch.cuda.max_memory_allocated()
