@@ -1,6 +1,8 @@
 """BASELINE.json configs as end-to-end cases (parity-test cases, not bench lines):
  C1: config/config.json-style SynthMorph training, 2 synthetic label maps, vol 64^3, 1 step;
  C4: bids_two_steps_registration.py cascade (two VxmDense passes + compose) on a synthetic pair."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -114,3 +116,21 @@ def test_pair_registration_flow_files(dev, tmp_path):
     assert outs["warp"].shape == (32, 16, 24, 3) and np.isfinite(outs["moved"].data).all()
     out2 = registration.register(specs, [m, m], registration.Volume(fx, aff), registration.Volume(mv, aff), compute_dtype="fp32")
     assert out2["warp"].shape == (32, 16, 24, 3) and out2["warp_rai"].shape == (64, 32, 48, 1, 3)
+
+
+def test_training_cli_runs_the_reference_config(dev, tmp_path):
+    """tools/train.py --config-path <44-key JSON> (the reference's command line, train_synthmorph.py:175-185)."""
+    import json
+    import subprocess
+    import sys
+    cfg = dict(CONFIG_C1, model_dir=str(tmp_path / "models"), in_shape=[32, 32, 32], im_scales=[8, 16], def_scales=[8, 16],
+               enc=[32, 32], dec=[32, 32, 32], num_maps=4, epochs=2)
+    path = tmp_path / "config.json"
+    path.write_text(json.dumps(cfg))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "train.py"), "--config-path", str(path)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["epochs"] == 2 and np.isfinite(out["last"]["loss"])
+    assert (tmp_path / "models" / "0002.h5").exists()
