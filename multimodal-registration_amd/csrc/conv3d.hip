@@ -39,6 +39,9 @@ constexpr int ROWB = 128;                             // 128 B of channels, XOR-
 constexpr int A_BYTES = HROWS * ROWB;                 // 86400
 constexpr int CONV_THREADS = 512;
 
+// 16 zero bytes that out-of-volume halo rows are DMA'd from (VAR bit 8)
+__device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
 struct ConvParams {
     const char* in0;
     const char* in1;
@@ -281,13 +284,48 @@ conv3d_k3_kernel(const ConvParams p)
         }
     };
 
+    // VAR bit 8 (bf16 / exact fp32, no conversion on the way): the haloed A tile goes global -> LDS by DMA as well.
+    // Lane i of an instruction lands at base + 16 i, i.e. at (row, chunk position) = (i >> 3, i & 7) of the swizzled
+    // tile, so the swizzle is applied to the SOURCE chunk; out-of-volume rows read a zero page.
+    constexpr bool DMA_A = !X3 && ((VAR >> 8) & 1);
+    const unsigned sA_lds = lds_addr(sA);
+    auto dma_stage_a = [&](int s) {
+        const int ch0 = s * KC;
+        const bool first = ch0 < p.C0;
+        const char* src = first ? p.in0 : p.in1;
+        const int Cs = first ? p.C0 : p.C1;
+        const int chs = first ? ch0 : ch0 - p.C0;
+        const bool up = first && p.up0;
+#pragma unroll
+        for (int it = 0; it < A_ITERS; ++it) {
+            const int i = tid + it * CONV_THREADS;
+            if (i < A_ITEMS) {
+                const int row = i >> 3, cpos = i & 7;
+                const int hx = row / (HY * HZ), hy = (row / HZ) % HY, hz = row % HZ;
+                const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
+                const char* q = reinterpret_cast<const char*>(&g_zero16);
+                if (gx >= 0 && gx < p.X && gy >= 0 && gy < p.Y && gz >= 0 && gz < p.Z) {
+                    size_t vox;
+                    if (up) vox = (((size_t)b * X2 + (gx >> 1)) * Y2 + (gy >> 1)) * Z2 + (gz >> 1);
+                    else vox = (((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz;
+                    q = src + (vox * Cs + chs) * ES + ((cpos ^ swz(hy, hz)) << 4);
+                }
+                glds16(q, __builtin_amdgcn_readfirstlane(sA_lds + (it * CONV_THREADS + wave * 64) * 16));
+            }
+        }
+    };
+
     // ---- prologue: first slice of A, first tap of B of this block's step range ----
     const int g0 = p.kpart ? (int)blockIdx.z * p.gsplit : 0;
     const int g1 = p.kpart ? min(g0 + p.gsplit, G) : G;
     int cur = 0, tap = g0 % 27, s = g0 / 27;
     issue_b(g0, 0);
+    if constexpr (DMA_A) {
+        dma_stage_a(s);
+    } else {
 #pragma unroll
-    for (int it = 0; it < A_ITERS; ++it) store_a(it, load_a(s, it));
+        for (int it = 0; it < A_ITERS; ++it) store_a(it, load_a(s, it));
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -482,8 +520,13 @@ conv3d_k3_kernel(const ConvParams p)
             tap = 0;
             ++s;
             if (s < nslices && g + 1 < g1) {  // every wave is past its last read of sA: install the next slice
+                if constexpr (DMA_A) {
+                    dma_stage_a(s);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else {
 #pragma unroll
-                for (int it = 0; it < A_ITERS; ++it) store_a(it, load_a(s, it));
+                    for (int it = 0; it < A_ITERS; ++it) store_a(it, load_a(s, it));
+                }
                 __syncthreads();
             }
         }
@@ -828,21 +871,23 @@ int dispatch_conv(const ConvParams& p, hipStream_t st, int64_t* nblk_out = nullp
     static int var = -1;
     if (var < 0) {
         const char* e = getenv("MMR_CONV_VARIANT");
-        var = e ? atoi(e) : 160;
+        var = e ? atoi(e) : 416;
     }
     switch (BN) {
         case 256:
             if (var == 96) return launch_conv<DT, 2, 4, 4, 2, 96>(p, nt, st, nblk_out);
-            if (var == 32) return launch_conv<DT, 2, 4, 4, 2, 32>(p, nt, st, nblk_out);   // compiler-scheduled fragments
-            return launch_conv<DT, 2, 4, 4, 2, 160>(p, nt, st, nblk_out);                 // default: explicit pipeline (-2.6 %)
+            if (var == 32) return launch_conv<DT, 2, 4, 4, 2, 32>(p, nt, st, nblk_out);    // compiler-scheduled fragments
+            if (var == 160) return launch_conv<DT, 2, 4, 4, 2, 160>(p, nt, st, nblk_out);  // + explicit fragment pipeline
+            return launch_conv<DT, 2, 4, 4, 2, 416>(p, nt, st, nblk_out);                  // + A tile by LDS-DMA (default)
         case 128:  // 8x8x8-voxel tiles for the narrow N
-            if (var == 32 || DT == MMR_DT_BF16)  // the bf16 pipeline does not fit 256 VGPRs with the 8x8x8 staging
+            if (var == 32) return launch_conv<DT, 4, 2, 4, 2, 32>(p, nt, st, nblk_out);
+            if (DT == MMR_DT_BF16)  // neither the bf16 fragment pipeline nor the DMA staging fit 256 VGPRs at this tile
                 return launch_conv<DT, 4, 2, 4, 2, 32>(p, nt, st, nblk_out);
-            return launch_conv<DT, 4, 2, 4, 2, 160>(p, nt, st, nblk_out);
+            return launch_conv<DT, 4, 2, 4, 2, 416>(p, nt, st, nblk_out);
         case 64:
             if (var == 32) return launch_conv<DT, 8, 1, 2, 2, 32>(p, nt, st, nblk_out);
-            return launch_conv<DT, 8, 1, 2, 2, 160>(p, nt, st, nblk_out);
-        default: return launch_conv<DT, 8, 1, 2, 1, 0>(p, nt, st, nblk_out);
+            return launch_conv<DT, 8, 1, 2, 2, 416>(p, nt, st, nblk_out);
+        default: return launch_conv<DT, 8, 1, 2, 1, 256>(p, nt, st, nblk_out);
     }
 }
 
