@@ -205,7 +205,7 @@ def main():
                 raise SystemExit("training runs fp32 or fp32x3 (fp32 tensors; bf16 hi/lo split inside the convs)")
             L = 26
             enc, dec = [feats] * 4, [feats] * 6
-            maps = synth.generate_label_maps(shape, L, 2, [16, 32, 64], [8, 16, 32], 1, 3, seed=100 + rank, device=dev)
+            maps = synth.generate_label_maps(shape, L, 1, [16, 32, 64], [8, 16, 32], 1, 3, seed=100 + rank, device=dev)
             labels_in = np.arange(L)
             kw = dict(in_shape=shape, in_label_list=labels_in, out_label_list=labels_in, warp_std=3, warp_res=16, blur_std=1,
                       bias_std=0.3, bias_res=40, gamma_std=0.25, device=dev)
@@ -216,10 +216,10 @@ def main():
             tr = training.SynthMorphTrainer(model, g1, g2, reg_param=1.0, optimizer=training.Adam(1e-4),
                                             world_size=world, rank=rank, backward_precision=args.bwd)
             src = torch.from_numpy(maps[0][None, ..., None]).to(dev)
-            trg = torch.from_numpy(maps[1][None, ..., None]).to(dev)
+            trg = src  # config/config.json: same_subj true -- the pair is two generator renderings of one label map
             step = lambda: tr.train_step(src, trg)["loss"]
             workload = (f"train_synthmorph.py step (BASELINE configs[2]): {shape[0]}^3, enc/dec={feats}, {L} labels, Dice + "
-                        f"Grad-l2(reg 1), generators + fwd + bwd + all-reduce + Adam, 1 pair per GPU, label maps resident in HBM"
+                        f"Grad-l2(reg 1), same_subj pairs, generators + fwd + bwd + all-reduce + Adam, 1 pair per GPU, label maps resident in HBM"
                         + (" [OPT-IN bf16-product backward]" if args.bwd else ""))
             par = f"dp{world} (batch sharded by rank, one SUM all-reduce of {model._flat.numel() * 4 / 1e6:.1f} MB over RCCL)"
             cpu_fn = lambda: cpu_baseline_train(enc, dec, shape, L)
