@@ -45,28 +45,60 @@ def synth_pair(shape, device, seed=0):
     return outs
 
 
-def cpu_baseline_infer(enc, dec, full_shape):
-    """Oracle (CPU restatement, 'port') on a bounded sample of the same workload."""
-    from oracle import net_np
-    from oracle import cbind
-    sample = (32, 32, 48)
-    rng = np.random.default_rng(0)
-    mov = rng.random((1,) + sample + (1,)).astype(np.float32)
-    fix = rng.random((1,) + sample + (1,)).astype(np.float32)
-    w = net_np.init_weights(enc, dec, seed=0)
-    real = cbind.conv3d_same
-    net_np.conv3d_same = lambda x, w_, b=None, leaky=False, alpha=0.2: real(x, w_, b, leaky=leaky, alpha=alpha, f32acc=True)
+def cpu_baseline_infer(enc, dec, full_shape, mov, fix, budget_s=45.0):
+    """CPU restatement ('port') of the same forward on the same pair, as BASELINE.md section 3 prescribes: torch-CPU
+    conv3d / max_pool3d (channels-last-3d, oneDNN) + the gather-form tail (oracle/net_torch.py, checked against
+    oracle/net_np.py in tests/test_oracle_kat.py), fp32 like the reference's TF CPU path.  All torch threads, and a
+    1-thread run mirroring --one-cpu-tf (bids_registration.py:460-472).  The sample is the largest leading crop of the
+    pair whose warm-up + 3 timed forwards fit the budget (the full pair when it does); value = crop fraction / median."""
+    from oracle import net_np, net_torch
+    nthreads = torch.get_num_threads()
+    tw = net_torch.prepare_weights(net_np.init_weights(enc, dec, seed=0))
+    mov, fix = mov.detach().float().cpu(), fix.detach().float().cpu()
+    nvox = float(np.prod(full_shape))
+
+    def crop(shape):
+        return mov[:, :shape[0], :shape[1], :shape[2]].contiguous(), fix[:, :shape[0], :shape[1], :shape[2]].contiguous()
+
+    def run(shape, reps, warm=1):
+        a, b = crop(shape)
+        ts = []
+        for i in range(warm + reps):
+            t0 = time.perf_counter()
+            net_torch.vxm_dense_forward(a, b, tw, enc, dec, 5, 2, 2)
+            if i >= warm:
+                ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), ts
+
+    def fits(shape):
+        return tuple(min(int(s), int(f)) // 16 * 16 for s, f in zip(shape, full_shape))
+    probe_shape = fits((32, 32, 48))
+    t_probe, _ = run(probe_shape, 1, warm=1)
+    ladder = [tuple(full_shape), fits([s // 2 for s in full_shape]), fits([s // 4 for s in full_shape]), probe_shape]
+    sample = probe_shape
+    for shp in ladder:   # work is linear in voxels; small crops run less efficiently, so the estimate is an upper bound
+        if t_probe * np.prod(shp) / np.prod(probe_shape) * 4 <= budget_s:
+            sample = shp
+            break
+    med, ts = (t_probe, [t_probe]) if sample == probe_shape else run(sample, 3, warm=1)
+    frac = float(np.prod(sample)) / nvox
+    one_shape = fits((16, 16, 32))
+    torch.set_num_threads(1)
     try:
-        t0 = time.perf_counter()
-        net_np.vxm_dense_forward(mov, fix, w, enc, dec, 5, 2, 2)
-        dt = time.perf_counter() - t0
+        med1, ts1 = run(one_shape, 3, warm=1)
     finally:
-        net_np.conv3d_same = real
-    frac = float(np.prod(sample)) / float(np.prod(full_shape))
-    return {"value": frac / dt, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"one VxmDense forward (enc/dec={enc[0]}) on a {sample[0]}x{sample[1]}x{sample[2]} pair = "
-                      f"{frac:.5f} of the {'x'.join(map(str, full_shape))} voxels, {dt:.1f} s wall; value = that fraction / "
-                      f"wall (pairs/s-equivalent, work is linear in voxels); oracle/conv_c.c f32-accumulate + NumPy tail"}
+        torch.set_num_threads(nthreads)
+    frac1 = float(np.prod(one_shape)) / nvox
+    xs = "x".join
+    return {"value": frac / med, "unit": "pairs/s", "cores": nthreads, "kind": "port",
+            "ms_per_pair_equivalent": med / frac * 1e3, "runs_s": [round(t, 3) for t in ts],
+            "sample": f"VxmDense forward (enc/dec={enc[0]}, fp32) on the leading {xs(map(str, sample))} crop of the same pair = "
+                      f"{frac:.5f} of the {xs(map(str, full_shape))} voxels; median of {len(ts)} after 1 warm-up = {med:.2f} s; "
+                      f"value = crop fraction / median; torch-CPU conv3d/max_pool3d channels-last (oneDNN) + gather-form "
+                      f"resize/VecInt/warp (oracle/net_torch.py), {nthreads} threads; host has {os.cpu_count()} logical CPUs",
+            "one_thread": {"value": frac1 / med1, "unit": "pairs/s", "cores": 1, "runs_s": [round(t, 3) for t in ts1],
+                           "sample": f"same graph, torch.set_num_threads(1) (the reference's --one-cpu-tf mode), "
+                                     f"{xs(map(str, one_shape))} crop = {frac1:.6f} of the voxels, median of 3 = {med1:.2f} s"}}
 
 
 def cpu_baseline_train(enc, dec, full_shape, L):
@@ -87,7 +119,7 @@ def cpu_baseline_train(enc, dec, full_shape, L):
     dt = time.perf_counter() - t0
     frac = float(np.prod(sample)) / float(np.prod(full_shape))
     return {"value": frac / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"one fwd+bwd of the restated SynthMorph step (oracle/grad_torch.py, torch-CPU float64 autograd, "
+            "sample": f"one fwd+bwd of the restated SynthMorph step (oracle/grad_torch.py, torch-CPU float64 autograd, {torch.get_num_threads()} threads, "
                       f"enc/dec={enc[0]}, no generator, no Adam) on a {sample[0]}x{sample[1]}x{sample[2]} pair = {frac:.6f} of "
                       f"the voxels, {dt:.1f} s wall; value = fraction / wall"}
 
@@ -142,18 +174,27 @@ def main():
     local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # MMR_FORCE_DIST=1: create the (RCCL) process group even for one rank so that a 1-GPU box runs the same collective
+    # code path as the driver's N > 1 launches (tests/test_gpu_rccl.py)
+    forced = os.environ.get("MMR_FORCE_DIST", "0") == "1"
+    if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    use_dist = world > 1 or forced
 
     import mmr
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -171,7 +212,7 @@ def main():
             workload = (f"3d_reg.py inference (BASELINE configs[1]): VxmDense forward {shape[0]}x{shape[1]}x{shape[2]}, "
                         f"enc/dec={feats}, int_steps=5, svf/int_res=2, inputs resident in HBM, 1 pair/step")
             par = f"replicas x{world} (single-pair inference does not shard)"
-            cpu_fn = lambda: cpu_baseline_infer(enc, dec, shape)
+            cpu_fn = lambda: cpu_baseline_infer(enc, dec, shape, mov, fix)
             metric, unit, pairs_per_step = "volume-pairs/sec", "pairs/s", 1
         elif wl == "cascade":
             # BASELINE configs[3]: two-step cascade of bids_two_steps_registration.py:311-325,484-499 on one pair --
@@ -253,7 +294,7 @@ def main():
         dt = time.perf_counter() - t0
         prof = mmr.ops.PROFILE
         mmr.ops.PROFILE = None
-        if world > 1:
+        if use_dist:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -264,6 +305,21 @@ def main():
     dtype, extra, workload, par, cpu_fn = w["dtype"], w["extra"], w["workload"], w["par"], w["cpu_fn"]
     metric, unit, pairs_per_step = "volume-pairs/sec", "pairs/s", 1
     dt, prof = timed(w["step"], args.warmup, args.steps)
+
+    fp32_grade = None
+    if args.workload == "infer" and dtype == "bf16" and not args.no_secondary:
+        # the same workload at the drop-in API's default arithmetic (fp32x3: fp32 tensors, bf16 hi/lo-split products,
+        # the 1e-4-grade path of north_star) -- reported beside the bf16 headline, never part of `value`
+        try:
+            w3 = setup("infer", "fp32x3", args.features, args.shape)
+            k3 = max(2, min(args.steps, 3))
+            dt3, _ = timed(w3["step"], 1, k3)
+            fp32_grade = {"dtype": "fp32x3", "ms_per_step": dt3 / k3 * 1e3, "value": world * k3 / dt3, "unit": "pairs/s",
+                          "steps": k3, "warmup": 1}
+            del w3
+            torch.cuda.empty_cache()
+        except Exception as e:
+            fp32_grade = {"error": f"{type(e).__name__}: {e}"}
 
     secondary = None
     if args.workload == "infer" and not args.no_secondary:
@@ -288,6 +344,8 @@ def main():
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
                "config": {"workload": workload, "parallelism": par}}
+        if forced and world == 1:
+            res["config"]["collectives"] = "rccl (forced single-rank group)" if backend == "nccl" else backend + " (forced)"
         roof, fam_ms = roofline_from_profile(prof, args.steps, dtype, f"traffic_{args.workload}.json")
         if args.workload == "ncc":
             gbs = extra["algorithmic_bytes_per_step"] / (dt / args.steps) / 1e9
@@ -297,12 +355,14 @@ def main():
             res["roofline"] = roof
         if fam_ms:
             res["kernel_family_ms_per_step"] = fam_ms
+        if fp32_grade:
+            res["same_workload_fp32x3"] = fp32_grade
         if secondary:
             res["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline and cpu_fn is not None:
             res["cpu_baseline"] = cpu_fn()
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -34,6 +34,16 @@ extern "C" {
 #define MMR_DT_F32X3 2  /* fp32 tensors, bf16 hi/lo split inside the conv (3 bf16 MFMAs per product) */
 #define MMR_DT_F32X1 3  /* fp32 tensors, products of the bf16 hi halves only (opt-in, backward pass) */
 
+/* Upstream semantics that cannot be pinned here (voxelmorph / neurite are absent, SURVEY.md Appendix A "warning"
+ * items A4, A6, A8) are selectable per call; 0 is the behaviour recalled for the commits the reference pins
+ * (README.md:35-37) and the default of the Python layer (mmr.semantics). */
+#define MMR_RESIZE_ALIGN_CORNERS 0 /* A4: sample grid linspace(0, old-1, new)  (neurite, late 2021) */
+#define MMR_RESIZE_ARANGE_OVER_F 1 /* A4: sample grid arange(new) / zoom, clamped at the edge (older neurite) */
+#define MMR_DICE_DIVIDE_NO_NAN 0   /* A6: tf.math.divide_no_nan(top, bottom) */
+#define MMR_DICE_MAX_EPS 1         /* A6: top / max(bottom, 1e-5)            (older voxelmorph) */
+#define MMR_NCC_CLASSIC 0          /* A8: cc = cross^2 / (I_var * J_var + eps) */
+#define MMR_NCC_CLAMPED 1          /* A8: cross, I_var, J_var clamped to >= eps; cc = (cross / I_var) * (cross / J_var) */
+
 int mmr_version(void);
 const char* mmr_error_string(int code);
 /* last HIP error text recorded by a failing call on this thread */
@@ -54,10 +64,13 @@ int mmr_warp3d_nearest_u8(const uint8_t* vol, const float* flow, uint8_t* out,
                           int has_fill, uint8_t fill, void* stream);
 
 /* ne.utils.resize + vxm RescaleTransform (inside VxmDense; 3d_reg.py:394):
- * align-corners trilinear from (X,Y,Z) to (Xo,Yo,Zo), values times `mul`.
- * pre_scale!=0 multiplies before interpolating (factor>1 branch).          */
+ * trilinear from (X,Y,Z) to (Xo,Yo,Zo), values times `mul`.
+ * pre_scale!=0 multiplies before interpolating (factor>1 branch).
+ * grid_mode: MMR_RESIZE_* (A4). zoom: the zoom factor f of MMR_RESIZE_ARANGE_OVER_F (0 = derive new/old
+ * per axis); ignored for MMR_RESIZE_ALIGN_CORNERS.                          */
 int mmr_resize_trilinear_f32(const float* in, float* out, int B, int X, int Y, int Z, int C,
-                             int Xo, int Yo, int Zo, float mul, int pre_scale, void* stream);
+                             int Xo, int Yo, int Zo, float mul, int pre_scale, int grid_mode, float zoom,
+                             void* stream);
 
 /* vxm.utils.compose([A,B]) (bids_two_steps_registration.py:324):
  * out = B + A o (id + B). Also one scaling-and-squaring step when a == b. */
@@ -107,21 +120,25 @@ int mmr_maxpool3d2_fwd(const void* in, void* out, int B, int X, int Y, int Z, in
 
 /* ---- losses ------------------------------------------------------------ *
  * vxm.losses.Dice().loss (train_synthmorph.py:306). ws: >= mmr_dice_ws_bytes.
- * loss_out[0] = -mean_{b,l} divide_no_nan(2 sum(t p), sum(t + p)).         */
+ * loss_out[0] = -mean_{b,l} ratio(2 sum(t p), sum(t + p)); ratio per dice_mode (MMR_DICE_*, A6). */
 int64_t mmr_dice_ws_bytes(int B, int64_t nvox, int L);
 int mmr_dice_fwd_f32(const float* y_true, const float* y_pred, float* loss_out, float* top_bot,
-                     void* ws, int B, int64_t nvox, int L, void* stream);
+                     void* ws, int B, int64_t nvox, int L, int dice_mode, void* stream);
+/* losses.dice_loss_zeropad on dense maps (losses.py:11-69 as its docstring intends; the reference function always
+ * raises): voxels whose channel 0 is >= 1 in either map are zeroed, loss = -mean over labels 1..L-1 of batch item 0. */
+int mmr_dice_zeropad_fwd_f32(const float* y_true, const float* y_pred, float* loss_out, float* top_bot,
+                             void* ws, int B, int64_t nvox, int L, int dice_mode, void* stream);
 /* d loss / d y_pred from the forward's (top, bot) sums [B,L,2]; dpred (+)= scale * gradient. */
 int mmr_dice_bwd_f32(const float* y_true, const float* top_bot, float* dpred, int B, int64_t nvox, int L,
-                     float scale, int accumulate, void* stream);
+                     float scale, int accumulate, int dice_mode, void* stream);
 /* vxm.losses.Grad('l2', loss_mult).loss(None, flow) (train_synthmorph.py:307) -> out[B]. */
 int64_t mmr_grad_l2_ws_bytes(int B, int X, int Y, int Z, int C);
 int mmr_grad_l2_fwd_f32(const float* flow, float* out, void* ws,
                         int B, int X, int Y, int Z, int C, float loss_mult, void* stream);
-/* vxm.losses.NCC(win) (BASELINE.json config 5; no reference call site) -> out[B]. */
+/* vxm.losses.NCC(win) (BASELINE.json config 5; no reference call site) -> out[B]; ncc_form: MMR_NCC_* (A8). */
 int64_t mmr_ncc_ws_bytes(int B, int X, int Y, int Z);
 int mmr_ncc_fwd_f32(const float* I, const float* J, float* out, void* ws,
-                    int B, int X, int Y, int Z, int win, float eps, void* stream);
+                    int B, int X, int Y, int Z, int win, float eps, int ncc_form, void* stream);
 /* bending energy of a displacement field (config 5) -> out[B]. */
 int64_t mmr_bending_ws_bytes(int B, int X, int Y, int Z);
 int mmr_bending_fwd_f32(const float* flow, float* out, void* ws,
@@ -130,7 +147,7 @@ int mmr_bending_fwd_f32(const float* flow, float* out, void* ws,
  * (gout == NULL: 1).  NCC: dI and/or dJ [B,X,Y,Z] (either may be NULL); workspace mmr_ncc_bwd_ws_bytes. */
 int64_t mmr_ncc_bwd_ws_bytes(int B, int X, int Y, int Z);
 int mmr_ncc_bwd_f32(const float* I, const float* J, const float* gout, float* dI, float* dJ, void* ws,
-                    int B, int X, int Y, int Z, int win, float eps, void* stream);
+                    int B, int X, int Y, int Z, int win, float eps, int ncc_form, void* stream);
 int mmr_bending_bwd_f32(const float* flow, const float* gout, float* dflow, int B, int X, int Y, int Z,
                         int accumulate, void* stream);
 
@@ -161,22 +178,24 @@ int mmr_axpy_f32(float* y, const float* x, float a, int64_t n, void* stream);
  * volumes (never materialising the L-channel tensors): loss[0], top_bot[B][L][2] = (2 sum tp, sum t+p). */
 int64_t mmr_dice_labels_ws_bytes(int B, int64_t nvox, int L);
 int mmr_dice_labels_fwd(const uint8_t* lab1, const uint8_t* lab2, const float* flow, float* loss, float* top_bot,
-                        void* ws, int B, int X, int Y, int Z, int L, void* stream);
+                        void* ws, int B, int X, int Y, int Z, int L, int dice_mode, void* stream);
 /* dflow (+)= scale * d loss / d flow */
 int mmr_dice_labels_bwd(const uint8_t* lab1, const uint8_t* lab2, const float* flow, const float* top_bot,
-                        float* dflow, int B, int X, int Y, int Z, int L, float scale, int accumulate, void* stream);
+                        float* dflow, int B, int X, int Y, int Z, int L, float scale, int accumulate, int dice_mode,
+                        void* stream);
 /* losses.dice_loss_zeropad (losses.py:11-69, as its docstring intends; the reference function itself always
  * raises): voxels whose label-0 channel is >= 1 in either map are masked, labels 1..L-1 of batch item 0. */
 int mmr_dice_labels_zeropad_fwd(const uint8_t* lab1, const uint8_t* lab2, const float* flow, float* loss, float* top_bot,
-                                void* ws, int B, int X, int Y, int Z, int L, void* stream);
+                                void* ws, int B, int X, int Y, int Z, int L, int dice_mode, void* stream);
 int mmr_dice_labels_zeropad_bwd(const uint8_t* lab1, const uint8_t* lab2, const float* flow, const float* top_bot,
-                                float* dflow, int B, int X, int Y, int Z, int L, float scale, int accumulate, void* stream);
+                                float* dflow, int B, int X, int Y, int Z, int L, float scale, int accumulate,
+                                int dice_mode, void* stream);
 /* dflow (+)= scale * d/dflow sum_b Grad('l2', loss_mult)(flow)[b] */
 int mmr_grad_l2_bwd_f32(const float* flow, float* dflow, int B, int X, int Y, int Z, int C, float loss_mult,
                         float scale, int accumulate, void* stream);
-/* adjoint of mmr_resize_trilinear_f32 (din is overwritten) */
+/* adjoint of mmr_resize_trilinear_f32 (din is overwritten); same grid_mode / zoom as the forward */
 int mmr_resize_trilinear_bwd_f32(const float* dout, float* din, int B, int X, int Y, int Z, int C,
-                                 int Xo, int Yo, int Zo, float mul, void* stream);
+                                 int Xo, int Yo, int Zo, float mul, int grid_mode, float zoom, void* stream);
 /* adjoint of mmr_compose_f32: da, db overwritten (da == db allowed when a == b) */
 int mmr_compose_bwd_f32(const float* a, const float* b, const float* dout, float* da, float* db,
                         int B, int X, int Y, int Z, void* stream);

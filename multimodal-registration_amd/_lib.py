@@ -22,7 +22,7 @@ SIGNATURES = {
     "mmr_last_hip_error": (ctypes.c_char_p, []),
     "mmr_warp3d_f32": (I, [P, P, P, I, I, I, I, I, I, I, F, I, P]),
     "mmr_warp3d_nearest_u8": (I, [P, P, P, I, I, I, I, I, I, c_uint8, P]),
-    "mmr_resize_trilinear_f32": (I, [P, P, I, I, I, I, I, I, I, I, F, I, P]),
+    "mmr_resize_trilinear_f32": (I, [P, P, I, I, I, I, I, I, I, I, F, I, I, F, P]),
     "mmr_compose_f32": (I, [P, P, P, I, I, I, I, P]),
     "mmr_vecint_f32": (I, [P, P, P, I, I, I, I, I, P]),
     "mmr_conv3d_k3_packed_bytes": (c_int64, [I, I, I]),
@@ -34,11 +34,12 @@ SIGNATURES = {
     "mmr_conv3d_k3_cout3_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "mmr_maxpool3d2_fwd": (I, [P, P, I, I, I, I, I, I, P]),
     "mmr_dice_ws_bytes": (c_int64, [I, c_int64, I]),
-    "mmr_dice_fwd_f32": (I, [P, P, P, P, P, I, c_int64, I, P]),
+    "mmr_dice_fwd_f32": (I, [P, P, P, P, P, I, c_int64, I, I, P]),
+    "mmr_dice_zeropad_fwd_f32": (I, [P, P, P, P, P, I, c_int64, I, I, P]),
     "mmr_grad_l2_ws_bytes": (c_int64, [I, I, I, I, I]),
     "mmr_grad_l2_fwd_f32": (I, [P, P, P, I, I, I, I, I, F, P]),
     "mmr_ncc_ws_bytes": (c_int64, [I, I, I, I]),
-    "mmr_ncc_fwd_f32": (I, [P, P, P, P, I, I, I, I, I, F, P]),
+    "mmr_ncc_fwd_f32": (I, [P, P, P, P, I, I, I, I, I, F, I, P]),
     "mmr_bending_ws_bytes": (c_int64, [I, I, I, I]),
     "mmr_bending_fwd_f32": (I, [P, P, P, I, I, I, I, P]),
     "mmr_philox_normal_f32": (I, [P, c_int64, c_uint64, c_uint32, F, F, P]),
@@ -52,12 +53,12 @@ SIGNATURES = {
     "mmr_argmax_u8": (I, [P, P, c_int64, I, P]),
     "mmr_axpy_f32": (I, [P, P, F, c_int64, P]),
     "mmr_dice_labels_ws_bytes": (c_int64, [I, c_int64, I]),
-    "mmr_dice_labels_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
-    "mmr_dice_labels_bwd": (I, [P, P, P, P, P, I, I, I, I, I, F, I, P]),
-    "mmr_dice_labels_zeropad_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P]),
-    "mmr_dice_labels_zeropad_bwd": (I, [P, P, P, P, P, I, I, I, I, I, F, I, P]),
+    "mmr_dice_labels_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P]),
+    "mmr_dice_labels_bwd": (I, [P, P, P, P, P, I, I, I, I, I, F, I, I, P]),
+    "mmr_dice_labels_zeropad_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P]),
+    "mmr_dice_labels_zeropad_bwd": (I, [P, P, P, P, P, I, I, I, I, I, F, I, I, P]),
     "mmr_grad_l2_bwd_f32": (I, [P, P, I, I, I, I, I, F, F, I, P]),
-    "mmr_resize_trilinear_bwd_f32": (I, [P, P, I, I, I, I, I, I, I, I, F, P]),
+    "mmr_resize_trilinear_bwd_f32": (I, [P, P, I, I, I, I, I, I, I, I, F, I, F, P]),
     "mmr_compose_bwd_f32": (I, [P, P, P, P, P, I, I, I, I, P]),
     "mmr_vecint_save_f32": (I, [P, P, P, I, I, I, I, I, P]),
     "mmr_vecint_bwd_f32": (I, [P, P, P, P, P, I, I, I, I, I, P]),
@@ -69,9 +70,9 @@ SIGNATURES = {
     "mmr_conv3d_k3_dgrad_masked": (I, [P, I, P, P, I, I, I, I, I, P, F, P, P, I, I, P]),
     "mmr_conv3d_k3_cout3_dgrad_masked_ws_bytes": (c_int64, [I, I, I, I, I]),
     "mmr_conv3d_k3_cout3_dgrad_masked_f32": (I, [P, P, P, I, I, I, I, I, P, F, P, P, I, P]),
-    "mmr_dice_bwd_f32": (I, [P, P, P, I, c_int64, I, F, I, P]),
+    "mmr_dice_bwd_f32": (I, [P, P, P, I, c_int64, I, F, I, I, P]),
     "mmr_ncc_bwd_ws_bytes": (c_int64, [I, I, I, I]),
-    "mmr_ncc_bwd_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, F, P]),
+    "mmr_ncc_bwd_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, F, I, P]),
     "mmr_bending_bwd_f32": (I, [P, P, P, I, I, I, I, I, P]),
     "mmr_conv3d_k3_dgrad_split_ws_bytes": (c_int64, [I, I, I, I, I]),
     "mmr_conv3d_k3_dgrad_split": (I, [P, I, P, P, P, I, I, I, I, I, I, P, F, P, P, I, I, P]),
@@ -105,16 +106,22 @@ def lib_path():
 
 
 def load():
-    """Load libmmr_hip.so (building it first if sources are newer and hipcc exists)."""
+    """Load libmmr_hip.so.  A missing library, or one whose recorded source hash no longer matches csrc/ while
+    hipcc is available, is (re)built first -- serialised across the ranks of a node by build.build()'s file lock.
+    A stale library without hipcc is refused rather than silently used."""
     global _LIB
     if _LIB is not None:
         return _LIB
     path = lib_path()
-    if not os.path.exists(path):
-        try:
-            _build.build()
-        except Exception as e:  # no silent fallback
-            raise MmrError(f"libmmr_hip.so is missing and could not be built: {e}") from e
+    if _build.needs_build():
+        have_hipcc = os.path.exists(_build.hipcc_path())
+        if not os.path.exists(path) or have_hipcc:
+            try:
+                _build.build()
+            except Exception as e:  # no silent fallback
+                raise MmrError(f"libmmr_hip.so is missing or stale and could not be built: {e}") from e
+        else:
+            raise MmrError(f"{path} does not match the sources in csrc/ and hipcc is not available to rebuild it")
     lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         try:

@@ -30,6 +30,25 @@ inline int stream_grid(int64_t n, int block, int max_blocks = 256 * 16)
     return (int)g;
 }
 
+// Sampling step per axis of ne.utils.resize: output index i reads input coordinate i * step.
+// MMR_RESIZE_ALIGN_CORNERS: linspace(0, old-1, new) -> step (old-1)/(new-1); MMR_RESIZE_ARANGE_OVER_F: arange(new)/f ->
+// step 1/f with f = zoom (> 0) or, zoom == 0, new/old per axis; positions past old-1 clamp to the edge (interpn).
+inline int resize_steps(int X, int Y, int Z, int Xo, int Yo, int Zo, int grid_mode, float zoom, float& stx, float& sty,
+                        float& stz)
+{
+    if (grid_mode == MMR_RESIZE_ALIGN_CORNERS) {
+        stx = (float)(X - 1) / (float)(Xo > 1 ? Xo - 1 : 1);
+        sty = (float)(Y - 1) / (float)(Yo > 1 ? Yo - 1 : 1);
+        stz = (float)(Z - 1) / (float)(Zo > 1 ? Zo - 1 : 1);
+        return 0;
+    }
+    if (grid_mode != MMR_RESIZE_ARANGE_OVER_F || zoom < 0.f) return 1;
+    stx = zoom > 0.f ? 1.0f / zoom : (float)X / (float)Xo;
+    sty = zoom > 0.f ? 1.0f / zoom : (float)Y / (float)Yo;
+    stz = zoom > 0.f ? 1.0f / zoom : (float)Z / (float)Zo;
+    return 0;
+}
+
 typedef unsigned short bf16_t;  // raw bf16 bits
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
@@ -39,6 +58,31 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f)
 {
     __bf16 h = (__bf16)f;
     return __builtin_bit_cast(unsigned short, h);
+}
+
+// Dice ratio top / bottom under the two upstream variants: MMR_DICE_DIVIDE_NO_NAN =
+// tf.math.divide_no_nan (0 where bottom == 0), MMR_DICE_MAX_EPS = top / max(bottom, 1e-5) (older voxelmorph).
+#define MMR_DICE_EPS 1e-5f
+__device__ __forceinline__ float dice_ratio(float top, float bot, int mode)
+{
+    if (mode == MMR_DICE_MAX_EPS) return top / fmaxf(bot, MMR_DICE_EPS);
+    return (bot != 0.f) ? top / bot : 0.f;
+}
+// d ratio / d p through bottom (ga, same for every voxel) and through top per unit of y_true (gb): the
+// gradient w.r.t. y_pred[v] is gb * y_true[v] + ga   (top = 2 sum t p, bottom = sum t + p)
+__device__ __forceinline__ void dice_ratio_grad(float top, float bot, int mode, float& ga, float& gb)
+{
+    if (mode == MMR_DICE_MAX_EPS) {
+        const bool clamped = !(bot > MMR_DICE_EPS);
+        const float d = clamped ? MMR_DICE_EPS : bot;
+        ga = clamped ? 0.f : -top / (d * d);
+        gb = 2.f / d;
+    } else if (bot != 0.f) {
+        ga = -top / (bot * bot);
+        gb = 2.f / bot;
+    } else {
+        ga = gb = 0.f;
+    }
 }
 
 __device__ __forceinline__ float wave_sum(float v)

@@ -29,7 +29,7 @@ __device__ __forceinline__ double block_sum(double v, double* sh /* >= 4 doubles
 // thread's label is fixed while the block still reads contiguous runs.
 __global__ void __launch_bounds__(RED_BLOCK)
 dice_partial_kernel(const float* __restrict__ yt, const float* __restrict__ yp, double* __restrict__ part,
-                    int64_t nvox, int L, int nblk)
+                    int64_t nvox, int L, int nblk, int zeropad)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_top = reinterpret_cast<float*>(smem);
@@ -45,7 +45,11 @@ dice_partial_kernel(const float* __restrict__ yt, const float* __restrict__ yp, 
         const float* t = yt + (int64_t)b * n_el;
         const float* p = yp + (int64_t)b * n_el;
         for (int64_t e = lo + threadIdx.x; e < hi; e += T) {
-            const float a = t[e], c = p[e];
+            float a = t[e], c = p[e];
+            if (zeropad) {  // losses.py:34-57: voxels whose background channel is >= 1 in either map are zeroed
+                const int64_t v0 = (e / L) * L;
+                if (t[v0] >= 1.f || p[v0] >= 1.f) a = c = 0.f;
+            }
             top += a * c;
             bot += a + c;
         }
@@ -85,22 +89,24 @@ dice_sum_kernel(const double* __restrict__ part, float* __restrict__ top_bot, in
 }
 
 __global__ void __launch_bounds__(RED_BLOCK)
-dice_final_kernel(const float* __restrict__ top_bot, float* __restrict__ loss, int B, int L)
+dice_final_kernel(const float* __restrict__ top_bot, float* __restrict__ loss, int B, int L, int mode, int zeropad)
 {
     __shared__ double sh[4];
     double acc = 0.0;
     for (int i = threadIdx.x; i < B * L; i += blockDim.x) {
         const float ft = top_bot[i * 2], fb = top_bot[i * 2 + 1];
-        acc += (fb != 0.f) ? (double)(ft / fb) : 0.0;  // divide_no_nan
+        const bool counted = !zeropad || (i / L == 0 && i % L >= 1);  // zeropad: labels 1..L-1 of batch item 0
+        if (counted) acc += (double)dice_ratio(ft, fb, mode);
     }
     const double s = block_sum(acc, sh);
-    if (threadIdx.x == 0) loss[0] = (float)(-s / (double)(B * L));
+    if (threadIdx.x == 0) loss[0] = (float)(-s / (double)(zeropad ? (L - 1) : B * L));
 }
 
-// d dice / d y_pred[b,v,l] = -scale/(B L) * (2 t / bot - top / bot^2), 0 where bot == 0 (divide_no_nan)
+// d dice / d y_pred[b,v,l] = -scale/(B L) * (2 t / bot - top / bot^2); MMR_DICE_DIVIDE_NO_NAN: 0 where bot == 0;
+// MMR_DICE_MAX_EPS: bot below the clamp is the constant 1e-5 (only the 2 t / eps term remains)
 __global__ void __launch_bounds__(256)
 dice_bwd_kernel(const float* __restrict__ y_true, const float* __restrict__ top_bot, float* __restrict__ dpred, int B,
-                int64_t nvox, int L, float scale, int accumulate)
+                int64_t nvox, int L, float scale, int accumulate, int mode)
 {
     const int64_t total = (int64_t)B * nvox * L;
     const float c = -scale / (float)(B * L);
@@ -108,7 +114,9 @@ dice_bwd_kernel(const float* __restrict__ y_true, const float* __restrict__ top_
         const int l = (int)(i % L);
         const int b = (int)(i / (nvox * L));
         const float top = top_bot[(b * L + l) * 2], bot = top_bot[(b * L + l) * 2 + 1];
-        const float g = (bot != 0.f) ? c * (2.f * y_true[i] / bot - top / (bot * bot)) : 0.f;
+        float ga, gb;
+        dice_ratio_grad(top, bot, mode, ga, gb);
+        const float g = c * (gb * y_true[i] + ga);
         if (accumulate) dpred[i] += g; else dpred[i] = g;
     }
 }
@@ -168,6 +176,39 @@ grad_l2_final_kernel(const double* __restrict__ part, float* __restrict__ out, i
 //    window a register ring.  Writes the 5 zy-box sums of (I, J, I^2, J^2, IJ).
 //  pass 2 (x box + cc): a thread owns a (y,z) column and slides a 9-plane register ring along x.
 // 'SAME' zero padding falls out of loading zeros outside the volume.
+// Local cross-correlation of one window from its five box sums S = (sum I, sum J, sum I^2, sum J^2, sum IJ), ws = window
+// size.  form: MMR_NCC_CLASSIC cc = cross^2 / (Iv Jv + eps); MMR_NCC_CLAMPED (newer voxelmorph):
+// cross, Iv, Jv clamped to >= eps, cc = (cross / Iv) * (cross / Jv).  Returns cc and d cc / d (cross, Iv, Jv).
+struct NccTerms { float cc, uI, uJ, A, Bc, Cc; };
+__device__ __forceinline__ NccTerms ncc_terms(const float* S, float ws, float eps, int form)
+{
+    NccTerms t;
+    t.uI = S[0] / ws;
+    t.uJ = S[1] / ws;
+    float cross = S[4] - t.uJ * S[0] - t.uI * S[1] + t.uI * t.uJ * ws;
+    float Iv = S[2] - 2.f * t.uI * S[0] + t.uI * t.uI * ws;
+    float Jv = S[3] - 2.f * t.uJ * S[1] + t.uJ * t.uJ * ws;
+    if (form == MMR_NCC_CLAMPED) {
+        const bool kc = cross > eps, ki = Iv > eps, kj = Jv > eps;   // tf.maximum passes the gradient to the larger side
+        cross = kc ? cross : eps;
+        Iv = ki ? Iv : eps;
+        Jv = kj ? Jv : eps;
+        const float ri = cross / Iv, rj = cross / Jv;
+        t.cc = ri * rj;
+        t.A = kc ? 2.f * cross / (Iv * Jv) : 0.f;
+        t.Bc = ki ? -ri * rj / Iv : 0.f;
+        t.Cc = kj ? -ri * rj / Jv : 0.f;
+    } else {
+        const float den = Iv * Jv + eps;
+        const float r = cross / den;
+        t.cc = cross * r;
+        t.A = 2.f * r;
+        t.Bc = -r * r * Jv;
+        t.Cc = -r * r * Iv;
+    }
+    return t;
+}
+
 constexpr int NCC_ZOUT = 56;   // outputs per wave along z (lanes 4..59)
 constexpr int NCC_ROWS = 32;   // output rows per wave strip
 
@@ -240,7 +281,8 @@ ncc_zybox_kernel(const float* __restrict__ I, const float* __restrict__ J, float
 
 // zy: [B][5][X][Y][Z]; thread = (y,z) column of one x segment
 __global__ void __launch_bounds__(256)
-ncc_xbox_kernel(const float* __restrict__ zy, double* __restrict__ part, int X, int Y, int Z, int xseg, int nseg, float eps)
+ncc_xbox_kernel(const float* __restrict__ zy, double* __restrict__ part, int X, int Y, int Z, int xseg, int nseg, float eps,
+                int form)
 {
     __shared__ double sh[4];
     const int b = blockIdx.z / nseg, seg = blockIdx.z % nseg;
@@ -276,11 +318,7 @@ ncc_xbox_kernel(const float* __restrict__ zy, double* __restrict__ part, int X, 
                             for (int j = 0; j < 9; ++j) s += ring[j][q];
                             S[q] = s;
                         }
-                        const float uI = S[0] / ws, uJ = S[1] / ws;
-                        const float cross = S[4] - uJ * S[0] - uI * S[1] + uI * uJ * ws;
-                        const float Iv = S[2] - 2.f * uI * S[0] + uI * uI * ws;
-                        const float Jv = S[3] - 2.f * uJ * S[1] + uJ * uJ * ws;
-                        acc += cross * cross / (Iv * Jv + eps);
+                        acc += ncc_terms(S, ws, eps, form).cc;
                     }
                 }
             }
@@ -365,7 +403,8 @@ bending_partial_kernel(const float* __restrict__ u, double* __restrict__ part, i
 // i.e. seven more 9^3 box filters (zero padded like the forward) of per-window coefficient fields.
 // pass 2': the x box of the forward sums, writing the seven coefficient fields instead of reducing cc
 __global__ void __launch_bounds__(256)
-ncc_xcoef_kernel(const float* __restrict__ zy, float* __restrict__ F, int X, int Y, int Z, int xseg, int nseg, float eps)
+ncc_xcoef_kernel(const float* __restrict__ zy, float* __restrict__ F, int X, int Y, int Z, int xseg, int nseg, float eps,
+                 int form)
 {
     const int b = blockIdx.z / nseg, seg = blockIdx.z % nseg;
     const int col = blockIdx.x * 256 + threadIdx.x;
@@ -400,14 +439,8 @@ ncc_xcoef_kernel(const float* __restrict__ zy, float* __restrict__ F, int X, int
                         for (int j = 0; j < 9; ++j) t += ring[j][q];
                         S[q] = t;
                     }
-                    const float uI = S[0] / ws, uJ = S[1] / ws;
-                    const float cross = S[4] - uJ * S[0] - uI * S[1] + uI * uJ * ws;
-                    const float Iv = S[2] - 2.f * uI * S[0] + uI * uI * ws;
-                    const float Jv = S[3] - 2.f * uJ * S[1] + uJ * uJ * ws;
-                    const float den = Iv * Jv + eps;
-                    const float A = 2.f * cross / den;
-                    const float r = cross / den;
-                    const float Bc = -r * r * Jv, Cc = -r * r * Iv;
+                    const NccTerms t = ncc_terms(S, ws, eps, form);
+                    const float A = t.A, Bc = t.Bc, Cc = t.Cc, uI = t.uI, uJ = t.uJ;
                     float* o = out + (size_t)xo * ncol;
                     o[0] = A; o[nvox] = A * uJ; o[2 * nvox] = A * uI;
                     o[3 * nvox] = Bc; o[4 * nvox] = Bc * uI; o[5 * nvox] = Cc; o[6 * nvox] = Cc * uJ;
@@ -596,20 +629,40 @@ extern "C" int64_t mmr_dice_ws_bytes(int B, int64_t nvox, int L)
     return (int64_t)B * red_blocks(nvox * L) * L * 2 * sizeof(double) + (int64_t)B * L * 2 * sizeof(float);
 }
 
+static int dice_fwd_impl(const float* y_true, const float* y_pred, float* loss_out, float* top_bot, void* ws, int B,
+                         int64_t nvox, int L, int dice_mode, int zeropad, void* stream);
+
 extern "C" int mmr_dice_fwd_f32(const float* y_true, const float* y_pred, float* loss_out, float* top_bot, void* ws,
-                                int B, int64_t nvox, int L, void* stream)
+                                int B, int64_t nvox, int L, int dice_mode, void* stream)
+{
+    return dice_fwd_impl(y_true, y_pred, loss_out, top_bot, ws, B, nvox, L, dice_mode, 0, stream);
+}
+
+// losses.dice_loss_zeropad on dense (one-hot / soft) maps, as its docstring intends (losses.py:13-21,34-69; the
+// reference function itself always raises): background-masked Dice of labels 1..L-1 of batch item 0
+extern "C" int mmr_dice_zeropad_fwd_f32(const float* y_true, const float* y_pred, float* loss_out, float* top_bot,
+                                        void* ws, int B, int64_t nvox, int L, int dice_mode, void* stream)
+{
+    if (L < 2) return MMR_EINVAL;
+    return dice_fwd_impl(y_true, y_pred, loss_out, top_bot, ws, B, nvox, L, dice_mode, 1, stream);
+}
+
+static int dice_fwd_impl(const float* y_true, const float* y_pred, float* loss_out, float* top_bot, void* ws, int B,
+                         int64_t nvox, int L, int dice_mode, int zeropad, void* stream)
 {
     if (!y_true || !y_pred || !loss_out || !ws || B < 1 || nvox < 1 || L < 1 || L > RED_BLOCK) return MMR_EINVAL;
+    if (dice_mode != MMR_DICE_DIVIDE_NO_NAN && dice_mode != MMR_DICE_MAX_EPS) return MMR_EINVAL;
     const int nblk = red_blocks(nvox * L);
     hipLaunchKernelGGL(dice_partial_kernel, dim3(nblk, B), dim3(RED_BLOCK), 2 * RED_BLOCK * sizeof(float),
-                       as_stream(stream), y_true, y_pred, (double*)ws, nvox, L, nblk);
+                       as_stream(stream), y_true, y_pred, (double*)ws, nvox, L, nblk, zeropad);
     int rc = check_launch();
     if (rc) return rc;
     float* tb = top_bot ? top_bot : (float*)((char*)ws + (size_t)B * nblk * L * 2 * sizeof(double));
     hipLaunchKernelGGL(dice_sum_kernel, dim3(B * L), dim3(64), 0, as_stream(stream), (const double*)ws, tb, L, nblk);
     rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(dice_final_kernel, dim3(1), dim3(RED_BLOCK), 0, as_stream(stream), (const float*)tb, loss_out, B, L);
+    hipLaunchKernelGGL(dice_final_kernel, dim3(1), dim3(RED_BLOCK), 0, as_stream(stream), (const float*)tb, loss_out, B, L,
+                       dice_mode, zeropad);
     return check_launch();
 }
 
@@ -652,9 +705,10 @@ extern "C" int64_t mmr_ncc_ws_bytes(int B, int X, int Y, int Z)
 }
 
 extern "C" int mmr_ncc_fwd_f32(const float* I, const float* J, float* out, void* ws, int B, int X, int Y, int Z,
-                               int win, float eps, void* stream)
+                               int win, float eps, int ncc_form, void* stream)
 {
     if (!I || !J || !out || !ws || B < 1 || X < 1 || Y < 1 || Z < 1) return MMR_EINVAL;
+    if (ncc_form != MMR_NCC_CLASSIC && ncc_form != MMR_NCC_CLAMPED) return MMR_EINVAL;
     if (win != 9) return MMR_EUNSUPPORTED;
     int nseg, ncolblk;
     ncc_geom(X, Y, Z, nseg, ncolblk);
@@ -669,7 +723,7 @@ extern "C" int mmr_ncc_fwd_f32(const float* I, const float* J, float* out, void*
     int rc = check_launch();
     if (rc) return rc;
     hipLaunchKernelGGL(ncc_xbox_kernel, dim3(ncolblk, 1, B * nseg), dim3(256), 0, as_stream(stream), (const float*)zy, part,
-                       X, Y, Z, NCC_XSEG, nseg, eps);
+                       X, Y, Z, NCC_XSEG, nseg, eps, ncc_form);
     rc = check_launch();
     if (rc) return rc;
     hipLaunchKernelGGL(mean_final_kernel, dim3(B), dim3(RED_BLOCK), 0, as_stream(stream), (const double*)part, out, B,
@@ -719,9 +773,10 @@ extern "C" int64_t mmr_ncc_bwd_ws_bytes(int B, int X, int Y, int Z)
 }
 
 extern "C" int mmr_ncc_bwd_f32(const float* I, const float* J, const float* gout, float* dI, float* dJ, void* ws, int B,
-                               int X, int Y, int Z, int win, float eps, void* stream)
+                               int X, int Y, int Z, int win, float eps, int ncc_form, void* stream)
 {
     if (!I || !J || !ws || (!dI && !dJ) || B < 1 || X < 1 || Y < 1 || Z < 1) return MMR_EINVAL;
+    if (ncc_form != MMR_NCC_CLASSIC && ncc_form != MMR_NCC_CLAMPED) return MMR_EINVAL;
     if (win != 9) return MMR_EUNSUPPORTED;
     int nseg, ncolblk;
     ncc_geom(X, Y, Z, nseg, ncolblk);
@@ -736,7 +791,7 @@ extern "C" int mmr_ncc_bwd_f32(const float* I, const float* J, const float* gout
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(ncc_zybox_kernel, dim3((unsigned)nb1), dim3(256), 0, st, I, J, zy5, B, X, Y, Z, nzs, nys);
     hipLaunchKernelGGL(ncc_xcoef_kernel, dim3(ncolblk, 1, B * nseg), dim3(256), 0, st, (const float*)zy5, F, X, Y, Z,
-                       NCC_XSEG, nseg, eps);
+                       NCC_XSEG, nseg, eps, ncc_form);
     hipLaunchKernelGGL(box_zy_kernel<7>, dim3((unsigned)nb1), dim3(256), 0, st, (const float*)F, zy7, B, X, Y, Z, nzs, nys);
     hipLaunchKernelGGL(ncc_xgrad_kernel, dim3(ncolblk, 1, B * nseg), dim3(256), 0, st, (const float*)zy7, I, J, gout, dI, dJ,
                        X, Y, Z, NCC_XSEG, nseg);
@@ -754,10 +809,11 @@ extern "C" int mmr_bending_bwd_f32(const float* flow, const float* gout, float* 
 
 // gradient of mmr_dice_fwd_f32's loss w.r.t. y_pred, from the (top, bot) sums the forward returned
 extern "C" int mmr_dice_bwd_f32(const float* y_true, const float* top_bot, float* dpred, int B, int64_t nvox, int L,
-                                float scale, int accumulate, void* stream)
+                                float scale, int accumulate, int dice_mode, void* stream)
 {
     if (!y_true || !top_bot || !dpred || B < 1 || nvox < 1 || L < 1) return MMR_EINVAL;
+    if (dice_mode != MMR_DICE_DIVIDE_NO_NAN && dice_mode != MMR_DICE_MAX_EPS) return MMR_EINVAL;
     hipLaunchKernelGGL(dice_bwd_kernel, dim3(stream_grid((int64_t)B * nvox * L, 256)), dim3(256), 0, as_stream(stream),
-                       y_true, top_bot, dpred, B, nvox, L, scale, accumulate);
+                       y_true, top_bot, dpred, B, nvox, L, scale, accumulate, dice_mode);
     return check_launch();
 }

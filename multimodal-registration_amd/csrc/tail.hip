@@ -203,12 +203,11 @@ extern "C" int mmr_warp3d_nearest_u8(const uint8_t* vol, const float* flow, uint
 }
 
 extern "C" int mmr_resize_trilinear_f32(const float* in, float* out, int B, int X, int Y, int Z, int C, int Xo,
-                                        int Yo, int Zo, float mul, int pre_scale, void* stream)
+                                        int Yo, int Zo, float mul, int pre_scale, int grid_mode, float zoom, void* stream)
 {
     if (!in || !out || B < 1 || X < 1 || Y < 1 || Z < 1 || C < 1 || Xo < 1 || Yo < 1 || Zo < 1) return MMR_EINVAL;
-    const float stx = (float)(X - 1) / (float)(Xo > 1 ? Xo - 1 : 1);
-    const float sty = (float)(Y - 1) / (float)(Yo > 1 ? Yo - 1 : 1);
-    const float stz = (float)(Z - 1) / (float)(Zo > 1 ? Zo - 1 : 1);
+    float stx, sty, stz;
+    if (resize_steps(X, Y, Z, Xo, Yo, Zo, grid_mode, zoom, stx, sty, stz)) return MMR_EINVAL;
     if ((int64_t)X * Y * Z * C > 0x7fffffff || (int64_t)Xo * Yo * Zo > 0x7fffffff) return MMR_EINVAL;
     const int64_t total = (int64_t)B * Xo * Yo * Zo;
     const dim3 grid(stream_grid(total, 256, 256 * 32)), blk(256);

@@ -138,7 +138,8 @@ dice_labels_sum_kernel(const double* __restrict__ part, float* __restrict__ top_
 }
 
 __global__ void __launch_bounds__(TB)
-dice_labels_final_kernel(const float* __restrict__ top_bot, float* __restrict__ loss, int B, int L, int zeropad)
+dice_labels_final_kernel(const float* __restrict__ top_bot, float* __restrict__ loss, int B, int L, int zeropad,
+                         int mode)
 {
     __shared__ double sh[4];
     double acc = 0.0;
@@ -146,7 +147,7 @@ dice_labels_final_kernel(const float* __restrict__ top_bot, float* __restrict__ 
         const int b = i / L, l = i % L;
         const float ft = top_bot[i * 2], fb = top_bot[i * 2 + 1];
         const bool counted = !zeropad || (b == 0 && l >= 1);  // zeropad: labels 1..L-1 of batch item 0 only
-        if (counted) acc += (fb != 0.f) ? (double)(ft / fb) : 0.0;
+        if (counted) acc += (double)dice_ratio(ft, fb, mode);
     }
     const double s = block_sum_d(acc, sh);
     if (threadIdx.x == 0) loss[0] = (float)(-s / (double)(zeropad ? (L - 1) : B * L));
@@ -156,7 +157,7 @@ dice_labels_final_kernel(const float* __restrict__ top_bot, float* __restrict__ 
 __global__ void __launch_bounds__(TB)
 dice_labels_bwd_kernel(const uint8_t* __restrict__ lab1, const uint8_t* __restrict__ lab2,
                        const float* __restrict__ flow, const float* __restrict__ top_bot, float* __restrict__ dflow,
-                       int B, int X, int Y, int Z, int L, float scale, int accumulate, int zeropad)
+                       int B, int X, int Y, int Z, int L, float scale, int accumulate, int zeropad, int mode)
 {
     __shared__ float sA[256], sB[256];  // G[l] = sA[l] + [l == target] * sB[l]
     const int b = blockIdx.y;
@@ -165,10 +166,10 @@ dice_labels_bwd_kernel(const uint8_t* __restrict__ lab1, const uint8_t* __restri
         float a = 0.f, bb = 0.f;
         if (l < L && !(zeropad && l == 0)) {
             const float top = top_bot[(b * L + l) * 2], bot = top_bot[(b * L + l) * 2 + 1];
-            if (bot != 0.f) {
-                a = -c * top / (bot * bot);   // d(top/bot)/dp via bot: -top/bot^2
-                bb = c * 2.f / bot;           // via top: 2 t / bot
-            }
+            float ga, gb;
+            dice_ratio_grad(top, bot, mode, ga, gb);  // via bot: -top/bot^2; via top: 2 t / bot
+            a = c * ga;
+            bb = c * gb;
         }
         sA[l] = a;
         sB[l] = bb;
@@ -1552,10 +1553,12 @@ extern "C" int64_t mmr_dice_labels_ws_bytes(int B, int64_t nvox, int L)
 }
 
 static int dice_labels_fwd_impl(const uint8_t* lab1, const uint8_t* lab2, const float* flow, float* loss,
-                                float* top_bot, void* ws, int B, int X, int Y, int Z, int L, int zeropad, void* stream)
+                                float* top_bot, void* ws, int B, int X, int Y, int Z, int L, int zeropad, int dice_mode,
+                                void* stream)
 {
     if (!lab1 || !lab2 || !flow || !loss || !top_bot || !ws || B < 1 || X < 1 || Y < 1 || Z < 1 || L < 1 || L > 64)
         return MMR_EINVAL;
+    if (dice_mode != MMR_DICE_DIVIDE_NO_NAN && dice_mode != MMR_DICE_MAX_EPS) return MMR_EINVAL;
     const int nblk = rblocks((int64_t)X * Y * Z, TB * 16);
     hipLaunchKernelGGL(dice_labels_partial_kernel, dim3(nblk, B), dim3(TB), 2 * L * TB * sizeof(float),
                        as_stream(stream), lab1, lab2, flow, (double*)ws, X, Y, Z, L, nblk, zeropad);
@@ -1566,46 +1569,50 @@ static int dice_labels_fwd_impl(const uint8_t* lab1, const uint8_t* lab2, const 
     rc = check_launch();
     if (rc) return rc;
     hipLaunchKernelGGL(dice_labels_final_kernel, dim3(1), dim3(TB), 0, as_stream(stream), (const float*)top_bot, loss, B,
-                       L, zeropad);
+                       L, zeropad, dice_mode);
     return check_launch();
 }
 
 extern "C" int mmr_dice_labels_fwd(const uint8_t* lab1, const uint8_t* lab2, const float* flow, float* loss,
-                                   float* top_bot, void* ws, int B, int X, int Y, int Z, int L, void* stream)
+                                   float* top_bot, void* ws, int B, int X, int Y, int Z, int L, int dice_mode,
+                                   void* stream)
 {
-    return dice_labels_fwd_impl(lab1, lab2, flow, loss, top_bot, ws, B, X, Y, Z, L, 0, stream);
+    return dice_labels_fwd_impl(lab1, lab2, flow, loss, top_bot, ws, B, X, Y, Z, L, 0, dice_mode, stream);
 }
 
 extern "C" int mmr_dice_labels_zeropad_fwd(const uint8_t* lab1, const uint8_t* lab2, const float* flow, float* loss,
-                                           float* top_bot, void* ws, int B, int X, int Y, int Z, int L, void* stream)
+                                           float* top_bot, void* ws, int B, int X, int Y, int Z, int L, int dice_mode,
+                                           void* stream)
 {
     if (L < 2) return MMR_EINVAL;
-    return dice_labels_fwd_impl(lab1, lab2, flow, loss, top_bot, ws, B, X, Y, Z, L, 1, stream);
+    return dice_labels_fwd_impl(lab1, lab2, flow, loss, top_bot, ws, B, X, Y, Z, L, 1, dice_mode, stream);
 }
 
 static int dice_labels_bwd_impl(const uint8_t* lab1, const uint8_t* lab2, const float* flow, const float* top_bot,
                                 float* dflow, int B, int X, int Y, int Z, int L, float scale, int accumulate, int zeropad,
-                                void* stream)
+                                int dice_mode, void* stream)
 {
     if (!lab1 || !lab2 || !flow || !top_bot || !dflow || B < 1 || X < 1 || Y < 1 || Z < 1 || L < 1 || L > 64)
         return MMR_EINVAL;
+    if (dice_mode != MMR_DICE_DIVIDE_NO_NAN && dice_mode != MMR_DICE_MAX_EPS) return MMR_EINVAL;
     hipLaunchKernelGGL(dice_labels_bwd_kernel, dim3(rblocks((int64_t)X * Y * Z, TB * 4, 2048), B), dim3(TB), 0,
-                       as_stream(stream), lab1, lab2, flow, top_bot, dflow, B, X, Y, Z, L, scale, accumulate, zeropad);
+                       as_stream(stream), lab1, lab2, flow, top_bot, dflow, B, X, Y, Z, L, scale, accumulate, zeropad,
+                       dice_mode);
     return check_launch();
 }
 
 extern "C" int mmr_dice_labels_bwd(const uint8_t* lab1, const uint8_t* lab2, const float* flow, const float* top_bot,
                                    float* dflow, int B, int X, int Y, int Z, int L, float scale, int accumulate,
-                                   void* stream)
+                                   int dice_mode, void* stream)
 {
-    return dice_labels_bwd_impl(lab1, lab2, flow, top_bot, dflow, B, X, Y, Z, L, scale, accumulate, 0, stream);
+    return dice_labels_bwd_impl(lab1, lab2, flow, top_bot, dflow, B, X, Y, Z, L, scale, accumulate, 0, dice_mode, stream);
 }
 
 extern "C" int mmr_dice_labels_zeropad_bwd(const uint8_t* lab1, const uint8_t* lab2, const float* flow,
                                            const float* top_bot, float* dflow, int B, int X, int Y, int Z, int L,
-                                           float scale, int accumulate, void* stream)
+                                           float scale, int accumulate, int dice_mode, void* stream)
 {
-    return dice_labels_bwd_impl(lab1, lab2, flow, top_bot, dflow, B, X, Y, Z, L, scale, accumulate, 1, stream);
+    return dice_labels_bwd_impl(lab1, lab2, flow, top_bot, dflow, B, X, Y, Z, L, scale, accumulate, 1, dice_mode, stream);
 }
 
 extern "C" int mmr_grad_l2_bwd_f32(const float* flow, float* dflow, int B, int X, int Y, int Z, int C, float loss_mult,
@@ -1622,13 +1629,12 @@ extern "C" int mmr_grad_l2_bwd_f32(const float* flow, float* dflow, int B, int X
 }
 
 extern "C" int mmr_resize_trilinear_bwd_f32(const float* dout, float* din, int B, int X, int Y, int Z, int C, int Xo,
-                                            int Yo, int Zo, float mul, void* stream)
+                                            int Yo, int Zo, float mul, int grid_mode, float zoom, void* stream)
 {
     if (!dout || !din || B < 1 || X < 1 || Y < 1 || Z < 1 || C < 1 || Xo < 1 || Yo < 1 || Zo < 1) return MMR_EINVAL;
     hipStream_t st = as_stream(stream);
-    const float stx = (float)(X - 1) / (float)(Xo > 1 ? Xo - 1 : 1);
-    const float sty = (float)(Y - 1) / (float)(Yo > 1 ? Yo - 1 : 1);
-    const float stz = (float)(Z - 1) / (float)(Zo > 1 ? Zo - 1 : 1);
+    float stx, sty, stz;
+    if (resize_steps(X, Y, Z, Xo, Yo, Zo, grid_mode, zoom, stx, sty, stz)) return MMR_EINVAL;
     hipLaunchKernelGGL(resize_bwd_kernel, dim3(stream_grid((int64_t)B * X * Y * Z * C, TB)), dim3(TB), 0, st, dout,
                        din, B, X, Y, Z, C, Xo, Yo, Zo, stx, sty, stz, mul);
     return check_launch();

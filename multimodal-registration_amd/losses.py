@@ -1,7 +1,5 @@
 """Mirrors of ``vxm.losses`` used by the reference (train_synthmorph.py:303-307)
 plus the NCC / bending-energy terms of BASELINE.json config 5."""
-import torch
-
 from . import ops
 from .layers import to_device
 
@@ -63,13 +61,5 @@ class BendingEnergy:
 def dice_loss_zeropad(y_true, y_pred):
     """Intent of the reference's ``losses.dice_loss_zeropad`` (losses.py:13-21; the reference
     function itself always raises): Dice over labels 1..L-1 of batch item 0 with
-    voxels masked where channel 0 >= 1 in either map.  Composed from device ops."""
-    t = to_device(y_true)[0:1]
-    p = to_device(y_pred)[0:1]
-    keep = ~((t[..., 0:1] >= 1) | (p[..., 0:1] >= 1))
-    t = (t * keep).contiguous()
-    p = (p * keep).contiguous()
-    _, tb = ops.dice_loss(t, p, return_parts=True)
-    top, bot = tb[0, 1:, 0], tb[0, 1:, 1]
-    d = torch.where(bot != 0, top / bot, torch.zeros_like(top))
-    return -d.mean()
+    voxels masked where channel 0 >= 1 in either map.  One HIP reduction (mmr_dice_zeropad_fwd_f32)."""
+    return ops.dice_loss(to_device(y_true), to_device(y_pred), zeropad=True)

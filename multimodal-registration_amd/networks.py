@@ -378,7 +378,8 @@ class VxmDense:
         if self.int_steps > 0:
             pos = ops.vecint(preint, self.int_steps)
             if self.int_resolution > 1:
-                pos = ops.resize_trilinear(pos, self.inshape, mul=float(self.int_resolution), pre_scale=True)
+                pos = ops.resize_trilinear(pos, self.inshape, mul=float(self.int_resolution), pre_scale=True,
+                                           zoom=float(self.int_resolution))
         y = ops.warp3d(source, pos, "linear", self.fill_value)
         r = self.references
         r.source, r.target, r.svf, r.preint_flow, r.postint_flow, r.pos_flow, r.y_source = \
@@ -427,5 +428,6 @@ class Transform:
         if tuple(v.shape[1:4]) != self.inshape or v.shape[-1] != self.nb_feats:
             raise ValueError(f"volume shape {tuple(v.shape)} does not match Transform{self.inshape + (self.nb_feats,)}")
         if self.rescale is not None:
-            t = ops.resize_trilinear(t, self.inshape, mul=float(self.rescale), pre_scale=self.rescale >= 1)
+            t = ops.resize_trilinear(t, self.inshape, mul=float(self.rescale), pre_scale=self.rescale >= 1,
+                                     zoom=float(self.rescale))
         return d2h_volume(ops.warp3d(v, t, self.interp_method, self.fill_value), tag=2)

@@ -8,7 +8,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, semantics
 
 F32, BF16, F32X3, F32X1 = 0, 1, 2, 3
 LINEAR, NEAREST = 0, 1
@@ -101,23 +101,26 @@ def warp3d_nearest_u8(vol, flow, fill_value=None):
     return out
 
 
-def resize_trilinear(x, out_shape, mul=1.0, pre_scale=False):
-    """Align-corners trilinear resize of [B,X,Y,Z,C] to out_shape=(Xo,Yo,Zo), values * mul."""
+def resize_trilinear(x, out_shape, mul=1.0, pre_scale=False, grid=None, zoom=0.0):
+    """Trilinear resize (ne.utils.resize) of [B,X,Y,Z,C] to out_shape=(Xo,Yo,Zo), values * mul.
+    grid: 'align_corners' | 'arange_over_f' (None = mmr.semantics default); zoom: the zoom factor of the
+    'arange_over_f' grid (0 = new/old per axis)."""
     _chk(x, torch.float32, "x")
     B, X, Y, Z, C = x.shape
     Xo, Yo, Zo = (int(s) for s in out_shape)
     out = torch.empty((B, Xo, Yo, Zo, C), dtype=torch.float32, device=x.device)
     rc = _lib.load().mmr_resize_trilinear_f32(x.data_ptr(), out.data_ptr(), B, X, Y, Z, C, Xo, Yo, Zo,
-                                              float(mul), int(pre_scale), _stream())
+                                              float(mul), int(pre_scale), semantics.code("resize_grid", grid),
+                                              float(zoom), _stream())
     _lib.check(rc, "mmr_resize_trilinear_f32")
     return out
 
 
-def rescale_transform(trf, factor):
+def rescale_transform(trf, factor, grid=None):
     """vxm RescaleTransform / rescale_dense_transform on a batched field [B,X,Y,Z,3]."""
     B, X, Y, Z, _ = trf.shape
     new = (int(X * factor), int(Y * factor), int(Z * factor))
-    return resize_trilinear(trf, new, mul=factor, pre_scale=factor >= 1)
+    return resize_trilinear(trf, new, mul=factor, pre_scale=factor >= 1, grid=grid, zoom=factor)
 
 
 def compose(a, b):
@@ -228,8 +231,8 @@ def dgrad_split_supported(C0, C1, x3):
 
 def conv3d_k3_dgrad_split(dz, wt_packed, C0, C1, y1=None, dbias1=None, alpha=0.2, accumulate=False, x3=True):
     """d(concat input) of a k3 conv stored split: (d0 [B,X,Y,Z,C0] compact, d1 [B,X,Y,Z,C1] times LeakyReLU'(y1) with
-    dbias1 (+)= its column sums).  Returns None when the kernel family does not cover the shape (caller falls back to
-    conv3d_k3 + upcat_bwd)."""
+    dbias1 (+)= its column sums).  Callers gate on ``dgrad_split_supported`` (which mirrors the C-side check); a shape
+    the kernel family does not cover raises instead of returning a half-updated state."""
     _chk(dz, torch.float32, "dz")
     B, X, Y, Z, Cz = dz.shape
     mode = conv_mode(torch.float32, x3)
@@ -244,8 +247,9 @@ def conv3d_k3_dgrad_split(dz, wt_packed, C0, C1, y1=None, dbias1=None, alpha=0.2
                                            int(C0), int(C1), y1.data_ptr() if y1 is not None else None, float(alpha),
                                            dbias1.data_ptr() if y1 is not None else None,
                                            ws.data_ptr() if ws is not None else None, int(accumulate), mode, _stream())
-    if rc == -3:  # MMR_EUNSUPPORTED
-        return None
+    if rc == -3:  # MMR_EUNSUPPORTED: dgrad_split_supported() and the C gate disagree -- a bug, not a fallback case
+        raise _lib.MmrError(f"mmr_conv3d_k3_dgrad_split does not cover C0={C0}, C1={C1}, Cz={Cz}, mode={mode}; "
+                            "gate the call with ops.dgrad_split_supported()")
     _lib.check(rc, "mmr_conv3d_k3_dgrad_split")
     return d0, d1
 
@@ -304,8 +308,9 @@ def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 8), dtype=torch.uint8, device=device)
 
 
-def dice_loss(y_true, y_pred, return_parts=False):
-    """-mean_{b,l} divide_no_nan(2 sum(t*p), sum(t+p)); inputs [B,*S,L] f32 -> scalar tensor."""
+def dice_loss(y_true, y_pred, return_parts=False, eps_mode=None, zeropad=False):
+    """-mean_{b,l} ratio(2 sum(t*p), sum(t+p)); inputs [B,*S,L] f32 -> scalar tensor.
+    eps_mode: 'divide_no_nan' | 'max_eps' (None = mmr.semantics default)."""
     _chk(y_true, torch.float32, "y_true")
     _chk(y_pred, torch.float32, "y_pred")
     if y_true.shape != y_pred.shape:
@@ -316,13 +321,14 @@ def dice_loss(y_true, y_pred, return_parts=False):
     ws = _ws(lib.mmr_dice_ws_bytes(B, nvox, L), y_true.device)
     loss = torch.empty(1, dtype=torch.float32, device=y_true.device)
     tb = torch.empty((B, L, 2), dtype=torch.float32, device=y_true.device)
-    rc = lib.mmr_dice_fwd_f32(y_true.data_ptr(), y_pred.data_ptr(), loss.data_ptr(), tb.data_ptr(), ws.data_ptr(),
-                              B, nvox, L, _stream())
+    fn = lib.mmr_dice_zeropad_fwd_f32 if zeropad else lib.mmr_dice_fwd_f32
+    rc = fn(y_true.data_ptr(), y_pred.data_ptr(), loss.data_ptr(), tb.data_ptr(), ws.data_ptr(),
+                              B, nvox, L, semantics.code("dice_eps", eps_mode), _stream())
     _lib.check(rc, "mmr_dice_fwd_f32")
     return (loss[0], tb) if return_parts else loss[0]
 
 
-def dice_loss_bwd(y_true, top_bot, scale=1.0, out=None):
+def dice_loss_bwd(y_true, top_bot, scale=1.0, out=None, eps_mode=None):
     """d dice_loss / d y_pred from the forward's (top, bot) sums; accumulates into ``out`` when given."""
     _chk(y_true, torch.float32, "y_true")
     _chk(top_bot, torch.float32, "top_bot")
@@ -332,7 +338,7 @@ def dice_loss_bwd(y_true, top_bot, scale=1.0, out=None):
     if out is None:
         out = torch.empty_like(y_true)
     rc = _lib.load().mmr_dice_bwd_f32(y_true.data_ptr(), top_bot.data_ptr(), out.data_ptr(), B, nvox, L, float(scale),
-                                      int(acc), _stream())
+                                      int(acc), semantics.code("dice_eps", eps_mode), _stream())
     _lib.check(rc, "mmr_dice_bwd_f32")
     return out
 
@@ -348,7 +354,8 @@ def grad_l2_loss(flow, loss_mult=1.0):
     return out
 
 
-def ncc_loss(I, J, win=9, eps=1e-5):
+def ncc_loss(I, J, win=9, eps=1e-5, form=None):
+    """vxm.losses.NCC(win, eps).loss -> [B]; form: 'classic' | 'clamped' (None = mmr.semantics default)."""
     _chk(I, torch.float32, "I")
     _chk(J, torch.float32, "J")
     if I.shape != J.shape or I.shape[-1] != 1:
@@ -357,7 +364,8 @@ def ncc_loss(I, J, win=9, eps=1e-5):
     lib = _lib.load()
     ws = _ws(lib.mmr_ncc_ws_bytes(B, X, Y, Z), I.device)
     out = torch.empty(B, dtype=torch.float32, device=I.device)
-    rc = lib.mmr_ncc_fwd_f32(I.data_ptr(), J.data_ptr(), out.data_ptr(), ws.data_ptr(), B, X, Y, Z, int(win), float(eps), _stream())
+    rc = lib.mmr_ncc_fwd_f32(I.data_ptr(), J.data_ptr(), out.data_ptr(), ws.data_ptr(), B, X, Y, Z, int(win), float(eps),
+                             semantics.code("ncc_form", form), _stream())
     _lib.check(rc, "mmr_ncc_fwd_f32")
     return out
 
@@ -375,7 +383,7 @@ def bending_energy(flow):
     return out
 
 
-def ncc_loss_bwd(I, J, gout=None, win=9, eps=1e-5, want=("I", "J")):
+def ncc_loss_bwd(I, J, gout=None, win=9, eps=1e-5, want=("I", "J"), form=None):
     """Gradients of ``ncc_loss`` [B] w.r.t. I and / or J, scaled by ``gout`` [B] (None = ones) -> (dI, dJ)."""
     _chk(I, torch.float32, "I")
     _chk(J, torch.float32, "J")
@@ -390,7 +398,8 @@ def ncc_loss_bwd(I, J, gout=None, win=9, eps=1e-5, want=("I", "J")):
         _chk(gout, torch.float32, "gout")
     rc = lib.mmr_ncc_bwd_f32(I.data_ptr(), J.data_ptr(), gout.data_ptr() if gout is not None else None,
                              dI.data_ptr() if dI is not None else None, dJ.data_ptr() if dJ is not None else None,
-                             ws.data_ptr(), B, X, Y, Z, int(win), float(eps), _stream())
+                             ws.data_ptr(), B, X, Y, Z, int(win), float(eps), semantics.code("ncc_form", form),
+                             _stream())
     _lib.check(rc, "mmr_ncc_bwd_f32")
     return dI, dJ
 
@@ -515,7 +524,7 @@ def axpy_(y, x, a=1.0):
 
 
 # ------------------------------- training ------------------------------- #
-def dice_labels_fwd(lab1, lab2, flow, L, zeropad=False):
+def dice_labels_fwd(lab1, lab2, flow, L, zeropad=False, eps_mode=None):
     """Dice(one_hot(lab2), warp_linear(one_hot(lab1), flow)) from uint8 label maps [B,X,Y,Z(,1)]."""
     _chk(lab1, torch.uint8, "lab1")
     _chk(lab2, torch.uint8, "lab2")
@@ -529,19 +538,19 @@ def dice_labels_fwd(lab1, lab2, flow, L, zeropad=False):
     tb = torch.empty((B, L, 2), dtype=torch.float32, device=flow.device)
     fn = lib.mmr_dice_labels_zeropad_fwd if zeropad else lib.mmr_dice_labels_fwd
     rc = fn(lab1.data_ptr(), lab2.data_ptr(), flow.data_ptr(), loss.data_ptr(), tb.data_ptr(),
-            ws.data_ptr(), B, X, Y, Z, int(L), _stream())
+            ws.data_ptr(), B, X, Y, Z, int(L), semantics.code("dice_eps", eps_mode), _stream())
     _lib.check(rc, "mmr_dice_labels_fwd")
     return loss[0], tb
 
 
-def dice_labels_bwd(lab1, lab2, flow, top_bot, L, scale=1.0, out=None, zeropad=False):
+def dice_labels_bwd(lab1, lab2, flow, top_bot, L, scale=1.0, out=None, zeropad=False, eps_mode=None):
     B, X, Y, Z = flow.shape[:4]
     acc = out is not None
     if out is None:
         out = torch.empty_like(flow)
     fn = _lib.load().mmr_dice_labels_zeropad_bwd if zeropad else _lib.load().mmr_dice_labels_bwd
     rc = fn(lab1.data_ptr(), lab2.data_ptr(), flow.data_ptr(), top_bot.data_ptr(),
-            out.data_ptr(), B, X, Y, Z, int(L), float(scale), int(acc), _stream())
+            out.data_ptr(), B, X, Y, Z, int(L), float(scale), int(acc), semantics.code("dice_eps", eps_mode), _stream())
     _lib.check(rc, "mmr_dice_labels_bwd")
     return out
 
@@ -558,13 +567,14 @@ def grad_l2_bwd(flow, loss_mult=1.0, scale=1.0, out=None):
     return out
 
 
-def resize_trilinear_bwd(dout, in_shape, mul=1.0):
-    """Adjoint of resize_trilinear: dout [B,Xo,Yo,Zo,C] -> din [B,*in_shape,C]."""
+def resize_trilinear_bwd(dout, in_shape, mul=1.0, grid=None, zoom=0.0):
+    """Adjoint of resize_trilinear (same grid / zoom): dout [B,Xo,Yo,Zo,C] -> din [B,*in_shape,C]."""
     _chk(dout, torch.float32, "dout")
     B, Xo, Yo, Zo, C = dout.shape
     X, Y, Z = (int(s) for s in in_shape)
     din = torch.empty((B, X, Y, Z, C), dtype=torch.float32, device=dout.device)
-    rc = _lib.load().mmr_resize_trilinear_bwd_f32(dout.data_ptr(), din.data_ptr(), B, X, Y, Z, C, Xo, Yo, Zo, float(mul), _stream())
+    rc = _lib.load().mmr_resize_trilinear_bwd_f32(dout.data_ptr(), din.data_ptr(), B, X, Y, Z, C, Xo, Yo, Zo, float(mul),
+                                                  semantics.code("resize_grid", grid), float(zoom), _stream())
     _lib.check(rc, "mmr_resize_trilinear_bwd_f32")
     return din
 

@@ -180,21 +180,33 @@ def register(specs, models, fixed, moving, warp_interp="linear", resample_interp
         return networks.Transform(arr.shape, interp_method=warp_interp, rescale=sc, nb_feats=1,
                                   device=nets[0].device).predict([arr[None, ..., None], field[None]])[0, ..., 0]
 
-    moved1, warp, scale = predict_field(nets[0], mv_data, fx_data, tiles_mv, tiles_fx)
-    if warp_interp != "linear" or moved1 is None:
-        moved1 = apply(mv_data, warp, scale)
-    moved = moved1
-    if len(nets) == 2:
-        if specs["use_subvol"]:
-            tiles_m1 = tiling.extract_subvolumes(moved1, coords)
-        else:
-            tiles_m1 = []
-        moved2, warp2, _ = predict_field(nets[1], moved1, fx_data, tiles_m1, tiles_fx)
-        warp = utils.compose([np.asarray(warp, np.float32), np.asarray(warp2, np.float32)])  # first, then second
-        if warp_interp == "linear" and moved2 is not None:
-            moved = moved2
-        else:
-            moved = apply(mv_data, warp, scale)
+    if len(nets) == 2 and specs["use_subvol"] and warp_interp == "linear":
+        # bids_two_steps_registration.py:362-404: per tile, model 2 runs on model 1's OWN moved tile and the two
+        # half-res fields are composed per tile; only then are the composed tile fields fused and applied once
+        fields = []
+        for f, m in zip(tiles_fx, tiles_mv):
+            moved_t, w1 = nets[0].predict(_pair(m, f))
+            _, w2 = nets[1].predict(_pair(moved_t[0, ..., 0], f))
+            fields.append(np.asarray(utils.compose([np.asarray(w1[0], np.float32), np.asarray(w2[0], np.float32)])))
+        scale = 2 if fields[0].shape[0] != in_shape[0] else 1
+        warp = tiling.fuse_subvolume_fields(tuple(s // scale for s in in_shape), tuple(s // scale for s in mv_data.shape),
+                                            [tuple(c // scale for c in cd) for cd in coords], fields)
+        moved = apply(mv_data, warp, scale)
+    else:
+        moved1, warp, scale = predict_field(nets[0], mv_data, fx_data, tiles_mv, tiles_fx)
+        if warp_interp != "linear" or moved1 is None:
+            moved1 = apply(mv_data, warp, scale)
+        moved = moved1
+        if len(nets) == 2:
+            # whole volume (:320-358), or sub-volumes with nearest interpolation (:406-470): stage 1 is fused and
+            # applied to the whole volume, stage 2 runs on (tiles of) that moved volume, the fields compose globally
+            tiles_m1 = tiling.extract_subvolumes(moved1, coords) if specs["use_subvol"] else []
+            moved2, warp2, _ = predict_field(nets[1], moved1, fx_data, tiles_m1, tiles_fx)
+            warp = utils.compose([np.asarray(warp, np.float32), np.asarray(warp2, np.float32)])  # first, then second
+            if warp_interp == "linear" and moved2 is not None:
+                moved = moved2
+            else:
+                moved = apply(mv_data, warp, scale)
     moved_vol = Volume(moved, fx.affine)
     moved_orig = resample_img(moved_vol, moving.affine, moving.shape[:3])
     full = utils.rescale_dense_transform(np.asarray(warp, np.float32)[None], scale)[0]

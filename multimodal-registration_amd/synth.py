@@ -81,29 +81,41 @@ def draw_perlin(out_shape, scales, min_std=0, max_std=1, modulate=True, rng=None
 
 
 def generate_label_maps(in_shape, num_labels, num_maps, im_scales, def_scales, im_max_std, def_max_std,
-                        save_label=False, label_dir=None, add_str="", seed=None, device="cuda", shard=None):
+                        save_label=False, label_dir=None, add_str="", seed=None, device="cuda", shard=None,
+                        draws=None):
     """Reference ``generate_label_maps`` (train_synthmorph.py:31-82): per map, Perlin image [*S,L] warped
-    channel-wise by a Perlin field [*S,L,3], argmax over labels -> uint8.  ``shard=(rank, world)`` makes each
-    rank synthesise maps rank, rank+world, ... (independent maps, no communication).
-    Saving uses .npy (the reference writes NIfTI through nibabel, which is host-side glue)."""
+    channel-wise by a Perlin field [*S,L,3], argmax over labels (first maximum, like ``tf.argmax``) -> uint8.
+    ``shard=(rank, world)`` makes each rank synthesise maps rank, rank+world, ... (independent maps, no
+    communication).  ``draws`` = one ``{"im": {...}, "warp": {...}}`` dict of
+    ``draw_perlin`` draws per map injects the randomness (what oracle/synth_np.generate_label_maps consumes);
+    the draws actually used are left in ``generate_label_maps.last_draws``.
+    Saved as ``label_map_{add_str}{i}.nii.gz`` with an identity affine, like train_synthmorph.py:72-76."""
     rng = np.random.default_rng(seed)
     seeds = rng.integers(2 ** 62, size=num_maps)
-    maps = []
+    maps, rec, index = [], [], []
     rank, world = shard if shard else (0, 1)
     for i in range(num_maps):
         if i % world != rank:
             continue
         r = np.random.default_rng(int(seeds[i]))
-        im = draw_perlin((*in_shape, num_labels), im_scales, max_std=im_max_std, rng=r, device=device)
-        warp = draw_perlin((*in_shape, num_labels, len(in_shape)), def_scales, max_std=def_max_std, rng=r, device=device)
+        d = draws[i] if draws is not None else {}
+        im = draw_perlin((*in_shape, num_labels), im_scales, max_std=im_max_std, rng=r, device=device,
+                         draws=d.get("im"))
+        d_im = draw_perlin.last_draws
+        warp = draw_perlin((*in_shape, num_labels, len(in_shape)), def_scales, max_std=def_max_std, rng=r,
+                           device=device, draws=d.get("warp"))
+        rec.append({"im": d_im, "warp": draw_perlin.last_draws})
         moved = ops.warp3d(im[None].contiguous(), warp[None].contiguous(), "linear", None)
         maps.append(ops.argmax_u8(moved[0]).cpu().numpy())
+        index.append(i)
         del im, warp, moved
+    generate_label_maps.last_draws = rec
     if save_label and label_dir:
         import os
+        from . import py_utils
         os.makedirs(label_dir, exist_ok=True)
-        for i, m in enumerate(maps):
-            np.save(os.path.join(label_dir, f"label_map_{add_str}{i * world + rank + 1}.npy"), m)
+        for i, m in zip(index, maps):
+            py_utils.write_nifti(m, os.path.join(label_dir, f"label_map_{add_str}{i + 1}.nii.gz"), np.eye(4))
     return maps
 
 
@@ -206,7 +218,7 @@ class LabelsToImage:
             half = tuple(s // 2 for s in self.in_shape)
             vel = self._perlin_batch(B, half + (3,), [r / 2 for r in self.warp_res], d["vel_stds"], d.get("vel_noise"), seed, "vel")
             deff = ops.vecint(vel.contiguous(), 5)
-            deff = ops.resize_trilinear(deff, self.in_shape, mul=2.0, pre_scale=True)
+            deff = ops.resize_trilinear(deff, self.in_shape, mul=2.0, pre_scale=True, zoom=2.0)
             lab = ops.warp3d_nearest_u8(lab, deff, fill_value=0)
         means = to_device(d["means"], device=self.device)
         stds = to_device(d["stds"], device=self.device)

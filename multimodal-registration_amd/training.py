@@ -63,7 +63,7 @@ class SynthMorphTrainer:
             n = w.numel()
             self.g.append(self.gflat[off:off + n].view(w.shape))
             off += n
-        if self.world > 1:
+        if self.world > 1 or parallel.forced():
             parallel.broadcast_(model._flat, 0, self.pg)
 
     # ------------------------------------------------------------------ forward with tape
@@ -108,21 +108,24 @@ class SynthMorphTrainer:
     def _tail_forward(self, flow):
         m = self.model
         half = tuple(s // m.svf_resolution for s in m.inshape)
-        svf = ops.resize_trilinear(flow, half, mul=1.0 / m.svf_resolution) if m.svf_resolution != 1 else flow
+        svf = ops.resize_trilinear(flow, half, mul=1.0 / m.svf_resolution, zoom=1.0 / m.svf_resolution) \
+            if m.svf_resolution != 1 else flow
         if m.int_resolution != m.svf_resolution:
             raise NotImplementedError("training path assumes int_resolution == svf_resolution (both shipped configs)")
         pos_lo, steps = ops.vecint_save(svf, m.int_steps)
-        pos = ops.resize_trilinear(pos_lo, m.inshape, mul=float(m.int_resolution), pre_scale=True) \
+        pos = ops.resize_trilinear(pos_lo, m.inshape, mul=float(m.int_resolution), pre_scale=True,
+                                   zoom=float(m.int_resolution)) \
             if m.int_resolution != 1 else pos_lo
         return svf, steps, pos_lo, pos
 
     def _tail_backward(self, dpos, svf, steps):
         m = self.model
         half = tuple(svf.shape[1:4])
-        dpos_lo = ops.resize_trilinear_bwd(dpos, half, mul=float(m.int_resolution)) if m.int_resolution != 1 else dpos
+        dpos_lo = ops.resize_trilinear_bwd(dpos, half, mul=float(m.int_resolution), zoom=float(m.int_resolution)) \
+            if m.int_resolution != 1 else dpos
         dsvf = ops.vecint_bwd(svf, steps, dpos_lo, m.int_steps)
         if m.svf_resolution != 1:
-            return ops.resize_trilinear_bwd(dsvf, m.inshape, mul=1.0 / m.svf_resolution)
+            return ops.resize_trilinear_bwd(dsvf, m.inshape, mul=1.0 / m.svf_resolution, zoom=1.0 / m.svf_resolution)
         return dsvf
 
     # ------------------------------------------------------------------ backward over the tape
@@ -263,7 +266,7 @@ class SynthMorphTrainer:
 
     def train_step(self, src_labels, trg_labels, draws_1=None, draws_2=None):
         out = self.forward_backward(src_labels, trg_labels, draws_1, draws_2, train=True)
-        if self.world > 1:
+        if self.world > 1 or parallel.forced():
             parallel.allreduce_sum_(self.gflat, self.pg)  # one 5.8 MB (64f) message
         self.opt.apply(self.model._flat, self.gflat, grad_scale=1.0 / self.world)
         self.model.invalidate_packed()
@@ -274,27 +277,44 @@ class SynthMorphTrainer:
 
     # ------------------------------------------------------------------ fit
     def fit(self, gen, validation_data=None, validation_steps=0, initial_epoch=0, epochs=1, steps_per_epoch=1,
-            save_name=None, save_freq=0, verbose=1, log=None):
-        """Keras-``fit``-like loop over a ``gen_synthmorph_eb`` generator (global batch per item;
-        this rank takes rows rank*b:(rank+1)*b)."""
+            save_name=None, save_freq=0, verbose=1, log=None, local_batches=False, local_val_batches=None):
+        """Keras-``fit``-like loop over a ``gen_synthmorph_eb`` generator.
+
+        local_batches=False: ``gen`` yields the GLOBAL batch and this rank takes rows rank*b:(rank+1)*b (what
+        MirroredStrategy does with the reference's generator, train_synthmorph.py:193-194,335-344).
+        local_batches=True: ``gen`` already yields only this rank's rows (``run_training`` builds it that way, so no
+        rank draws, flips or masks volumes it then throws away).  The same for ``validation_data`` through
+        ``local_val_batches`` (default: like ``local_batches``); a validation batch that is drawn globally but is not
+        a multiple of the world size is evaluated whole on every rank.  The logged losses are means over all ranks."""
+        if local_val_batches is None:
+            local_val_batches = local_batches
+        dev = self.model._flat.device
         history = []
         for epoch in range(initial_epoch, epochs):
             t0 = time.perf_counter()
             losses = []
             for _ in range(steps_per_epoch):
                 (src, trg), _void = next(gen)
-                sl = parallel.shard_rows(src.shape[0], self.rank, self.world)
-                o = self.train_step(src[sl], trg[sl])
+                if not local_batches:
+                    sl = parallel.shard_rows(src.shape[0], self.rank, self.world)
+                    src, trg = src[sl], trg[sl]
+                o = self.train_step(src, trg)
                 losses.append(o["loss"])
-            mean_loss = float(torch.stack(losses).mean())
+            mean_loss = parallel.allreduce_mean_scalar(float(torch.stack(losses).mean()), dev, self.pg)
             rec = {"epoch": epoch + 1, "loss": mean_loss, "s_per_step": (time.perf_counter() - t0) / steps_per_epoch}
             if validation_data is not None and validation_steps:
-                vl = []
+                vl, reduce_val = [], True
                 for _ in range(validation_steps):
                     (src, trg), _void = next(validation_data)
-                    sl = parallel.shard_rows(src.shape[0], self.rank, self.world)
-                    vl.append(self.test_step(src[sl], trg[sl])["loss"])
-                rec["val_loss"] = float(torch.stack(vl).mean())
+                    if not local_val_batches:
+                        if src.shape[0] % self.world == 0:
+                            sl = parallel.shard_rows(src.shape[0], self.rank, self.world)
+                            src, trg = src[sl], trg[sl]
+                        else:
+                            reduce_val = False   # identical whole batch on every rank
+                    vl.append(self.test_step(src, trg)["loss"])
+                v = float(torch.stack(vl).mean())
+                rec["val_loss"] = parallel.allreduce_mean_scalar(v, dev, self.pg) if reduce_val else v
             history.append(rec)
             if verbose and self.rank == 0:
                 print(f"Epoch {epoch + 1}/{epochs} - loss: {rec['loss']:.4f}"
@@ -308,21 +328,34 @@ class SynthMorphTrainer:
 
 
 def run_training(config, label_maps=None, device="cuda", rank=0, world_size=1, process_group=None, seed=0,
-                 compute_dtype="fp32", checkpoint_ext=".h5"):
+                 compute_dtype="fp32x3", checkpoint_ext=".h5"):
     """``train_synthmorph.py __main__`` driven by the reference's 44-key JSON config (config/config.json).
     Checkpoints are ``{epoch:04d}.h5`` in the Keras layout like the reference's ModelCheckpoint (:313-317);
-    ``checkpoint_ext='.safetensors'`` selects the native format."""
-    from . import data, networks, synth
+    ``checkpoint_ext='.safetensors'`` selects the native format.  ``compute_dtype``: 'fp32x3' (default, as
+    tools/train.py and bench.py: fp32-grade products on the bf16 matrix cores) or 'fp32' (exact fp32 MFMA).
+
+    Data-parallel layout (one process per GPU): label maps are synthesised shard-wise (map i on rank
+    i % world) and exchanged once; every rank then feeds ITS rows of the global batch from its own generator
+    (batch_size // world rows, rank-dependent seed); only rank 0 writes files."""
+    from . import data, networks, py_utils, synth
     data_cfg = config
+    if data_cfg["batch_size"] % world_size:
+        raise ValueError(f"batch_size {data_cfg['batch_size']} is not a multiple of the number of GPUs {world_size} "
+                         "(train_synthmorph.py:193-194)")
     if label_maps is None:
         if data_cfg["gen_label"]:
-            label_maps = synth.generate_label_maps(data_cfg["in_shape"], data_cfg["num_labels"], data_cfg["num_maps"],
-                                                   data_cfg["im_scales"], data_cfg["def_scales"], data_cfg["im_max_std"],
-                                                   data_cfg["def_max_std"], data_cfg["save_label"], data_cfg["label_dir"],
-                                                   data_cfg["add_str"], seed=seed, device=device)
-        else:
-            label_maps = [np.load(os.path.join(data_cfg["label_dir"], f)) for f in sorted(os.listdir(data_cfg["label_dir"]))
-                          if f.endswith(".npy")]
+            mine = synth.generate_label_maps(data_cfg["in_shape"], data_cfg["num_labels"], data_cfg["num_maps"],
+                                             data_cfg["im_scales"], data_cfg["def_scales"], data_cfg["im_max_std"],
+                                             data_cfg["def_max_std"], seed=seed, device=device,
+                                             shard=(rank, world_size))
+            label_maps = parallel.gather_maps(mine, data_cfg["num_maps"], rank, world_size, device, process_group)
+            if data_cfg["save_label"] and rank == 0:  # label_map_{add_str}{i}.nii.gz, train_synthmorph.py:71-76
+                os.makedirs(data_cfg["label_dir"], exist_ok=True)
+                for i, m in enumerate(label_maps):
+                    py_utils.write_nifti(m, os.path.join(data_cfg["label_dir"], f"label_map_{data_cfg['add_str']}{i + 1}.nii.gz"),
+                                         np.eye(4))
+        else:  # vxm.py.utils.load_labels (train_synthmorph.py:207): .nii.gz / .nii / .npz / .npy, clear error when empty
+            _, label_maps = py_utils.load_labels(data_cfg["label_dir"])
     labels_in = np.unique(label_maps)
     np.random.seed(42)  # train_synthmorph.py:209
     label_maps = list(label_maps)
@@ -331,14 +364,18 @@ def run_training(config, label_maps=None, device="cuda", rank=0, world_size=1, p
     maps_tr, maps_val = label_maps[:n_tr], label_maps[n_tr:]
     if data_cfg["gen_label_only"]:
         return None
-    gen_tr = data.gen_synthmorph_eb(maps_tr, batch_size=data_cfg["batch_size"], same_subj=data_cfg["same_subj"], flip=True,
+    b_loc = data_cfg["batch_size"] // world_size
+    val_sharded = data_cfg["batch_size_val"] % world_size == 0
+    bv_loc = data_cfg["batch_size_val"] // world_size if val_sharded else data_cfg["batch_size_val"]
+    gen_tr = data.gen_synthmorph_eb(maps_tr, batch_size=b_loc, same_subj=data_cfg["same_subj"], flip=True,
                                     random_zero_borders=data_cfg["zero_borders_maps"],
                                     scale_zero_borders=data_cfg["zero_bord_scale"], frac_zero_bord=data_cfg["zero_bord_frac"],
-                                    rng=np.random.default_rng(seed), device=device)  # label maps stay in HBM
-    gen_val = data.gen_synthmorph_eb(maps_val, batch_size=data_cfg["batch_size_val"], same_subj=data_cfg["same_subj"],
+                                    rng=np.random.default_rng([seed, rank]), device=device)  # label maps stay in HBM
+    gen_val = data.gen_synthmorph_eb(maps_val, batch_size=bv_loc, same_subj=data_cfg["same_subj"],
                                      flip=True, random_zero_borders=data_cfg["zero_borders_maps_val"],
                                      scale_zero_borders=data_cfg["zero_bord_scale"],
-                                     frac_zero_bord=data_cfg["zero_bord_frac"], rng=np.random.default_rng(seed + 1),
+                                     frac_zero_bord=data_cfg["zero_bord_frac"],
+                                     rng=np.random.default_rng([seed + 1, rank if val_sharded else 0]),
                                      device=device) if maps_val else None
     in_shape = label_maps[0].shape
     gen_args = dict(in_shape=in_shape, in_label_list=labels_in, out_label_list=labels_in, warp_std=data_cfg["vel_std"],
@@ -352,7 +389,8 @@ def run_training(config, label_maps=None, device="cuda", rank=0, world_size=1, p
     if data_cfg["bool_init_weights"]:
         model.load_weights(data_cfg["init_weights"])
     model_dir = os.path.join(data_cfg["model_dir"], data_cfg["sub_dir"]) if data_cfg["bool_sub_dir"] else data_cfg["model_dir"]
-    os.makedirs(model_dir, exist_ok=True)
+    if rank == 0:
+        os.makedirs(model_dir, exist_ok=True)
     save_name = os.path.join(model_dir, "{epoch:04d}" + checkpoint_ext)
     trainer = SynthMorphTrainer(model, g1, g2, reg_param=data_cfg["reg_param"], optimizer=Adam(data_cfg["lr"]),
                                 zero_pad_dice=data_cfg["zero_borders_maps"] or data_cfg["zero_borders_maps_val"],
@@ -363,5 +401,6 @@ def run_training(config, label_maps=None, device="cuda", rank=0, world_size=1, p
     hist = trainer.fit(gen_tr, validation_data=gen_val,
                        validation_steps=(len(maps_val) // data_cfg["batch_size_val"]) if maps_val else 0,
                        initial_epoch=data_cfg["init_epoch"], epochs=data_cfg["epochs"], steps_per_epoch=steps,
-                       save_name=save_name, save_freq=data_cfg["save_freq"], verbose=data_cfg["verbose"])
+                       save_name=save_name, save_freq=data_cfg["save_freq"], verbose=data_cfg["verbose"],
+                       local_batches=True, local_val_batches=True)
     return trainer, hist

@@ -40,9 +40,12 @@ def transform(vol, shift):
     return interpn(vol, grid(shift.shape[:3]) + shift)
 
 
-def resize(vol, new_shape):
+def resize(vol, new_shape, grid="align_corners", zoom=None):
     S = vol.shape[:3]
-    lin = [torch.arange(n, dtype=DT) * ((s - 1) / max(n - 1, 1)) for s, n in zip(S, new_shape)]
+    if grid == "arange_over_f":
+        lin = [torch.arange(n, dtype=DT) / (zoom if zoom else n / s) for s, n in zip(S, new_shape)]
+    else:
+        lin = [torch.arange(n, dtype=DT) * ((s - 1) / max(n - 1, 1)) for s, n in zip(S, new_shape)]
     return interpn(vol, torch.stack(torch.meshgrid(*lin, indexing="ij"), -1))
 
 
@@ -53,10 +56,12 @@ def vecint(v, nsteps):
     return v
 
 
-def dice_loss(t, p):
-    """[B,*S,L] -> scalar (-mean divide_no_nan)."""
+def dice_loss(t, p, eps_mode="divide_no_nan"):
+    """[B,*S,L] -> scalar (-mean divide_no_nan, or top / max(bot, 1e-5) for eps_mode='max_eps')."""
     top = 2 * (t * p).sum((1, 2, 3))
     bot = (t + p).sum((1, 2, 3))
+    if eps_mode == "max_eps":
+        return -(top / bot.clamp(min=1e-5)).mean()
     return -torch.where(bot != 0, top / torch.where(bot != 0, bot, torch.ones_like(bot)), torch.zeros_like(bot)).mean()
 
 
@@ -79,23 +84,52 @@ def pool(x):
     return F.max_pool3d(x.permute(0, 4, 1, 2, 3), 2).permute(0, 2, 3, 4, 1)
 
 
+def _windows(x):
+    """[B,X,Y,Z,C] -> [B,X/2,Y/2,Z/2,C,8] (the 2x2x2 MaxPooling3D windows, floor on odd sizes)."""
+    B, X, Y, Z, C = x.shape
+    x = x[:, :X // 2 * 2, :Y // 2 * 2, :Z // 2 * 2]
+    x = x.reshape(B, X // 2, 2, Y // 2, 2, Z // 2, 2, C).permute(0, 1, 3, 5, 7, 2, 4, 6)
+    return x.reshape(B, X // 2, Y // 2, Z // 2, C, 8)
+
+
+def pool_routed(x, k):
+    """MaxPooling3D(2) of x with the window element chosen where ``k`` (another evaluation of the same
+    activation) has its maximum -- the linear piece of max() that evaluation is on."""
+    idx = _windows(k).argmax(-1, keepdim=True)
+    return _windows(x).gather(-1, idx)[..., 0]
+
+
 def up(x):
     return x.repeat_interleave(2, 1).repeat_interleave(2, 2).repeat_interleave(2, 3)
 
 
-def unet(src, trg, ws, enc, dec):
+def unet(src, trg, ws, enc, dec, kinks=None):
+    """``kinks``: optional list with one tensor per LeakyReLU conv layer (execution order) holding ANOTHER
+    evaluation of that layer's activated output (the HIP forward's).  The network is piecewise linear; two fp32-grade
+    evaluations that differ by 5e-6 sit on different linear pieces at the ~1e-5 of the activations that lie that
+    close to a LeakyReLU kink or a max-pool tie, and their exact gradients then differ by O(1) there.  With
+    ``kinks`` the LeakyReLU slope (1 where kinks > 0, else 0.2) and the max-pool routing are taken from that other
+    evaluation, so autograd returns the exact float64 gradient of the SAME linear piece -- which is what a
+    gradient-parity test at 1e-4 has to compare with.  Forward values change by at most 0.8 * 5e-6."""
     nlev = len(enc)
     it = iter(range(0, len(ws), 2))
+    kit = iter(kinks) if kinks is not None else None
+    last_k = [None]
 
     def c(x, leaky=True):
         i = next(it)
-        return conv(x, ws[i], ws[i + 1], leaky)
+        if not leaky or kit is None:
+            return conv(x, ws[i], ws[i + 1], leaky)
+        k = next(kit)
+        last_k[0] = k
+        z = conv(x, ws[i], ws[i + 1], False)
+        return z * torch.where(k > 0, torch.ones_like(k), torch.full_like(k, 0.2))
     last = torch.cat([src, trg], -1)
     skips = []
     for _ in range(nlev):
         last = c(last)
         skips.append(last)
-        last = pool(last)
+        last = pool(last) if kit is None else pool_routed(last, last_k[0])
     for _ in range(nlev):
         last = c(last)
         last = torch.cat([up(last), skips.pop()], -1)
@@ -104,10 +138,10 @@ def unet(src, trg, ws, enc, dec):
     return c(last, leaky=False)
 
 
-def synthmorph_loss(src, trg, onehot1, onehot2, ws, enc, dec, int_steps, reg_param):
+def synthmorph_loss(src, trg, onehot1, onehot2, ws, enc, dec, int_steps, reg_param, kinks=None):
     """Sum over the batch of (Dice + 1) + Grad-l2 (what Keras differentiates, Appendix A11).
-    Returns (total, dice, grad[B], pos_flow, flow)."""
-    flow = unet(src, trg, ws, enc, dec)
+    Returns (total, dice, grad[B], pos_flow, flow).  ``kinks``: see ``unet``."""
+    flow = unet(src, trg, ws, enc, dec, kinks)
     B = flow.shape[0]
     half = tuple(s // 2 for s in flow.shape[1:4])
     pos = []
@@ -123,7 +157,7 @@ def synthmorph_loss(src, trg, onehot1, onehot2, ws, enc, dec, int_steps, reg_par
     return total, dice, gl, pos, flow
 
 
-def ncc_loss(I, J, win=9, eps=1e-5):
+def ncc_loss(I, J, win=9, eps=1e-5, form="classic"):
     """A8 ``vxm.losses.NCC(win).loss`` on [B,*S,1] (float64 tensors): -mean(cross^2 / (Iv*Jv + eps)) per batch item,
     window sums by a ones-kernel conv with zero ('SAME') padding -- the same formula as oracle/ops_np.py::ncc_loss."""
     import torch.nn.functional as F
@@ -136,7 +170,11 @@ def ncc_loss(I, J, win=9, eps=1e-5):
     cross = IJ - uJ * Is - uI * Js + uI * uJ * ws
     Iv = I2 - 2 * uI * Is + uI * uI * ws
     Jv = J2 - 2 * uJ * Js + uJ * uJ * ws
-    cc = cross * cross / (Iv * Jv + eps)
+    if form == "clamped":  # newer upstream: tf.maximum(., eps) on all three, (cross / Iv) * (cross / Jv)
+        cross, Iv, Jv = cross.clamp(min=eps), Iv.clamp(min=eps), Jv.clamp(min=eps)
+        cc = (cross / Iv) * (cross / Jv)
+    else:
+        cc = cross * cross / (Iv * Jv + eps)
     return -cc.flatten(1).mean(1)
 
 

@@ -89,25 +89,32 @@ def spatial_transformer(vol, flow, interp_method="linear", fill_value=None, dtyp
     return np.stack([transform(vol[b], flow[b], interp_method, fill_value, dtype) for b in range(vol.shape[0])])
 
 
-def resize(vol, factor, dtype=np.float32):
-    """A4 ``ne.utils.resize`` on [*S, C]: new = int(old*f), grid linspace(0, old-1, new)."""
+def resize(vol, factor, dtype=np.float32, grid="align_corners"):
+    """A4 ``ne.utils.resize`` on [*S, C]: new = int(old*f).  grid='align_corners' (default, neurite late 2021):
+    sample grid linspace(0, old-1, new); grid='arange_over_f' (older neurite): arange(new) / f, clamp-to-edge
+    through interpn."""
     vol = np.asarray(vol, dtype=dtype)
     S = vol.shape[:-1]
     new = [int(s * factor) for s in S]
     lin = []
     for s, n in zip(S, new):
-        step = dtype(s - 1) / dtype(max(n - 1, 1))
-        lin.append((np.arange(n, dtype=dtype) * step).astype(dtype))
+        if grid == "align_corners":
+            step = dtype(s - 1) / dtype(max(n - 1, 1))
+            lin.append((np.arange(n, dtype=dtype) * step).astype(dtype))
+        elif grid == "arange_over_f":
+            lin.append((np.arange(n, dtype=dtype) / dtype(factor)).astype(dtype))
+        else:
+            raise ValueError(grid)
     loc = np.stack(np.meshgrid(*lin, indexing="ij"), -1)
     return interpn(vol, loc, "linear", None, dtype)
 
 
-def rescale_dense_transform(trf, factor, dtype=np.float32):
+def rescale_dense_transform(trf, factor, dtype=np.float32, grid="align_corners"):
     """A4 ``vxm.utils.rescale_dense_transform`` (3d_reg.py:394), unbatched [*S, D]."""
     trf = np.asarray(trf, dtype=dtype)
     if factor < 1:
-        return (resize(trf, factor, dtype) * dtype(factor)).astype(dtype)
-    return resize((trf * dtype(factor)).astype(dtype), factor, dtype)
+        return (resize(trf, factor, dtype, grid) * dtype(factor)).astype(dtype)
+    return resize((trf * dtype(factor)).astype(dtype), factor, dtype, grid)
 
 
 def vecint(vel, nsteps, dtype=np.float32):
@@ -134,14 +141,22 @@ def _div_no_nan(a, b):
     return out
 
 
-def dice_loss(y_true, y_pred, dtype=np.float64):
+def _dice_ratio(top, bot, eps_mode):
+    if eps_mode == "divide_no_nan":
+        return _div_no_nan(top, bot)
+    if eps_mode == "max_eps":  # older voxelmorph: bottom = tf.maximum(sum(t + p), 1e-5)
+        return top / np.maximum(bot, 1e-5)
+    raise ValueError(eps_mode)
+
+
+def dice_loss(y_true, y_pred, dtype=np.float64, eps_mode="divide_no_nan"):
     """A6 ``vxm.losses.Dice().loss`` (train_synthmorph.py:306): scalar -mean_{b,l} dice."""
     t = np.asarray(y_true, dtype=dtype)
     p = np.asarray(y_pred, dtype=dtype)
     ax = tuple(range(1, t.ndim - 1))
     top = 2 * (t * p).sum(ax)
     bot = (t + p).sum(ax)
-    return -np.mean(_div_no_nan(top, bot))
+    return -np.mean(_dice_ratio(top, bot, eps_mode))
 
 
 def dice_loss_zeropad(y_true, y_pred, dtype=np.float64):
@@ -191,9 +206,10 @@ def _box_sum_same(x, win):
     return out
 
 
-def ncc_loss(I, J, win=9, eps=1e-5, dtype=np.float64):
-    """A8 ``vxm.losses.NCC(win).loss`` on [B,*S,1]; older upstream form
-    cc = cross^2 / (I_var*J_var + eps); returns -mean(cc) per batch item [B]."""
+def ncc_loss(I, J, win=9, eps=1e-5, dtype=np.float64, form="classic"):
+    """A8 ``vxm.losses.NCC(win).loss`` on [B,*S,1]; form='classic' (older upstream, default):
+    cc = cross^2 / (I_var*J_var + eps); form='clamped' (newer upstream): cross, I_var, J_var = max(., eps),
+    cc = (cross / I_var) * (cross / J_var); returns -mean(cc) per batch item [B]."""
     I = np.asarray(I, dtype=dtype)[..., 0]
     J = np.asarray(J, dtype=dtype)[..., 0]
     ws = float(win ** 3)
@@ -203,7 +219,13 @@ def ncc_loss(I, J, win=9, eps=1e-5, dtype=np.float64):
     cross = IJ - uJ * Is - uI * Js + uI * uJ * ws
     Iv = I2 - 2 * uI * Is + uI * uI * ws
     Jv = J2 - 2 * uJ * Js + uJ * uJ * ws
-    cc = cross * cross / (Iv * Jv + eps)
+    if form == "classic":
+        cc = cross * cross / (Iv * Jv + eps)
+    elif form == "clamped":
+        cross, Iv, Jv = np.maximum(cross, eps), np.maximum(Iv, eps), np.maximum(Jv, eps)
+        cc = (cross / Iv) * (cross / Jv)
+    else:
+        raise ValueError(form)
     return -cc.reshape(cc.shape[0], -1).mean(1)
 
 

@@ -31,6 +31,20 @@ def perlin(out_shape, scales, stds, noise):
     return out.reshape(out_shape)
 
 
+def generate_label_maps(in_shape, num_labels, draws, im_scales, def_scales):
+    """train_synthmorph.py:55-69 with injected draws: per map ``im = perlin((*S, L))``, ``warp = perlin((*S, L, 3))``,
+    ``im = vxm.utils.transform(im, warp)`` (channel-wise linear warp, A2), ``lab = tf.argmax(im, -1)`` (index of the
+    FIRST maximum), cast to uint8.  Also returns the warped images so a test can tell near-ties from errors."""
+    maps, ims = [], []
+    for d in draws:
+        im = perlin((*in_shape, num_labels), im_scales, d["im"]["stds"], d["im"]["noise"])
+        warp = perlin((*in_shape, num_labels, len(in_shape)), def_scales, d["warp"]["stds"], d["warp"]["noise"])
+        im = O.transform(im, warp, "linear", None)
+        ims.append(im)
+        maps.append(np.argmax(im, axis=-1).astype(np.uint8))  # np.argmax: first occurrence, as tf.argmax
+    return maps, ims
+
+
 def gaussian_kernel(sigma, blur_std):
     R = int(np.round(blur_std * 3))
     x = np.arange(-R, R + 1, dtype=np.float64)

@@ -29,6 +29,34 @@ def test_binding_table_matches_header():
     assert b"invalid" in lib.mmr_error_string(-1)
 
 
+def test_binding_arity_matches_header():
+    """Every ctypes signature has exactly as many arguments as the prototype in include/mmr.h (a flag added to the
+    header but not to the binding would shift every later argument silently)."""
+    import mmr
+    src = open(os.path.join(ROOT, "include", "mmr.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = dict(re.findall(r"\b(mmr_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S))
+    assert sorted(protos) == sorted(mmr._lib.SIGNATURES)
+    for name, args in protos.items():
+        args = args.strip()
+        n = 0 if args in ("", "void") else len(args.split(","))
+        assert n == len(mmr._lib.SIGNATURES[name][1]), f"{name}: header has {n} arguments, binding {len(mmr._lib.SIGNATURES[name][1])}"
+
+
+def test_semantics_switch_is_validated():
+    import pytest
+    import mmr
+    assert mmr.semantics.get("resize_grid") == "align_corners" and mmr.semantics.code("ncc_form") == 0
+    assert mmr.semantics.code("dice_eps", "max_eps") == 1
+    with mmr.semantics.using(ncc_form="clamped"):
+        assert mmr.semantics.code("ncc_form") == 1
+    assert mmr.semantics.code("ncc_form") == 0
+    with pytest.raises(ValueError):
+        mmr.semantics.set(resize_grid="bilinear")
+    with pytest.raises(KeyError):
+        mmr.semantics.set(nonsense="x")
+
+
 def test_product_path_refuses_cpu_tensors():
     import numpy as np
     import pytest

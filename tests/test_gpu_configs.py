@@ -134,3 +134,44 @@ def test_training_cli_runs_the_reference_config(dev, tmp_path):
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["epochs"] == 2 and np.isfinite(out["last"]["loss"])
     assert (tmp_path / "models" / "0002.h5").exists()
+
+
+def test_two_step_subvol_linear_composes_per_tile(dev):
+    """bids_two_steps_registration.py:362-404 (use_subvol + linear): per tile, model 2 sees model 1's own moved tile and
+    the two fields are composed per tile BEFORE fusion.  The expected field is assembled here tile by tile from the
+    operators; it must differ from the nearest branch's order (fuse stage 1, re-tile, compose globally)."""
+    import scipy.ndimage as ndi
+    import mmr
+    from mmr import registration, tiling, utils
+    rng = np.random.default_rng(6)
+    fx = ndi.gaussian_filter(rng.random((64, 32, 48)), 2.0)
+    mv = ndi.shift(fx, (1.5, -1.0, 0.5), order=1) + 0.02 * rng.random(fx.shape)
+    aff = np.eye(4)
+    specs = dict(use_subvol=True, subvol_size=[32, 32, 32], min_perc_overlap=0.1, int_steps=5, int_res=2, svf_res=2,
+                 enc=[32, 32], dec=[32, 32, 32])
+    nets = []
+    for seed in (1, 2):
+        m = mmr.networks.VxmDense((32, 32, 32), nb_unet_features=(specs["enc"], specs["dec"]), int_steps=5, int_resolution=2,
+                                  svf_resolution=2, compute_dtype="fp32", seed=seed)
+        w = m.get_weights()
+        w[-2] = (rng.standard_normal(w[-2].shape) * 3e-2).astype(np.float32)
+        m.set_weights(w)
+        nets.append(m)
+    out = registration.register(specs, nets, registration.Volume(fx, aff), registration.Volume(mv, aff),
+                                warp_interp="linear", compute_dtype="fp32")
+    fxp, mvp, tiles_fx, tiles_mv, coords = registration.preprocess(specs, registration.Volume(fx, aff), registration.Volume(mv, aff))
+    assert len(coords) >= 2
+    fields = []
+    for f, m in zip(tiles_fx, tiles_mv):
+        moved_t, w1 = nets[0].predict([m[None, ..., None], f[None, ..., None]])
+        _, w2 = nets[1].predict([moved_t, f[None, ..., None]])
+        fields.append(np.asarray(utils.compose([w1[0], w2[0]])))
+    exp = tiling.fuse_subvolume_fields((16, 16, 16), tuple(s // 2 for s in fxp.shape), [tuple(c // 2 for c in cd) for cd in coords], fields)
+    np.testing.assert_array_equal(out["warp"], exp)
+    assert np.abs(exp).max() > 0.05
+    moved = mmr.networks.Transform(fxp.shape, interp_method="linear", rescale=2, nb_feats=1).predict(
+        [mvp.get_fdata()[None, ..., None], exp[None]])[0, ..., 0]
+    np.testing.assert_array_equal(out["moved"].data, moved)
+    outn = registration.register(specs, nets, registration.Volume(fx, aff), registration.Volume(mv, aff),
+                                 warp_interp="nearest", compute_dtype="fp32")
+    assert np.abs(outn["warp"] - out["warp"]).max() > 1e-4   # the two branches are different computations

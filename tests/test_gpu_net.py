@@ -98,3 +98,34 @@ def test_default_voxelmorph_features_via_channel_padding(dev, dtype, tol):
     for got, exp in ((preint, ref["preint_flow"]), (moved, ref["moved"])):
         assert np.abs(got - exp).max() / np.abs(exp).max() < tol
     assert model.count_params() == sum(w.size for w in weights)
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32x3", 1e-4), ("bf16", 2e-2)])
+def test_vxmdense_256_features_matches_oracle(dev, dtype, tol):
+    """The benchmarked width (BASELINE configs[1]: enc/dec = 256, the BN=256 MFMA tiles, split-K coarse levels)
+    as a WHOLE forward against the oracle, not per layer: 3d_reg.py:297-314 builds exactly this network.
+    fp32x3 (the API default) must hold north_star's 1e-4; bf16 is compared with the oracle rounding its conv
+    inputs / weights to bf16 at the same points, bound 2e-2 of each output's scale over the 10-conv-deep net."""
+    import mmr
+    from oracle import net_np
+    shape, enc, dec = (32, 32, 48), [256] * 4, [256] * 6
+    rng = np.random.default_rng(11)
+    mov, fix = _pair(rng, shape)
+    weights = net_np.init_weights(enc, dec, seed=5, flow_std=1e-2)
+    for i in range(1, len(weights), 2):
+        weights[i] = (rng.standard_normal(weights[i].shape) * 0.05).astype(np.float32)
+    model = mmr.networks.VxmDense(shape, nb_unet_features=(enc, dec), int_steps=5, int_resolution=2,
+                                  svf_resolution=2, compute_dtype=dtype)
+    model.set_weights(weights)
+    moved, preint = model.predict([mov, fix])
+    pos = model.references.pos_flow.cpu().numpy()
+    quant = net_np.bf16_round if dtype == "bf16" else None
+    ref = net_np.vxm_dense_forward(mov, fix, weights, enc, dec, 5, 2, 2, quant=quant)
+    assert np.abs(ref["pos_flow"]).max() > 0.5, "test flow too small to be meaningful"
+    errs = {}
+    for name, got, exp in (("preint_flow", preint, ref["preint_flow"]), ("pos_flow", pos, ref["pos_flow"]),
+                           ("moved", moved, ref["moved"])):
+        errs[name] = np.abs(got - exp).max() / np.abs(exp).max()
+    print(f"256-feature whole-net parity [{dtype}]: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    for name, err in errs.items():
+        assert err < tol, f"{name}: rel-to-scale err {err:.3e} >= {tol}"

@@ -99,3 +99,46 @@ def test_generate_label_maps(dev):
     assert np.array_equal(maps[0], again[0])
     shard1 = synth.generate_label_maps((32, 32, 32), 6, 2, [8, 16], [4, 8], 1, 3, seed=0, shard=(1, 2))
     assert len(shard1) == 1 and np.array_equal(shard1[0], maps[1])
+
+
+def test_generate_label_maps_matches_oracle(dev):
+    """train_synthmorph.py:55-69 against oracle/synth_np.generate_label_maps on the same injected draws:
+    uint8 label maps bit-exact, except voxels where the oracle's two largest warped Perlin channels lie within
+    fp32 rounding of each other (1e-5 of the image scale; there the argmax of two fp32 evaluations of the
+    trilinear warp may legitimately differ) -- those must be rare and the GPU label must be one of the two."""
+    from mmr import synth
+    from oracle import synth_np
+    shape, L, n = (32, 24, 40), 6, 2
+    im_scales, def_scales = [8, 16], [4, 8]
+    maps = synth.generate_label_maps(shape, L, n, im_scales, def_scales, 1, 3, seed=4)
+    rec = synth.generate_label_maps.last_draws
+    draws = [{k: {"stds": d[k]["stds"], "noise": [_cpu(g) for g in d[k]["noise"]]} for k in ("im", "warp")} for d in rec]
+    ref_maps, ref_ims = synth_np.generate_label_maps(shape, L, draws, im_scales, def_scales)
+    # injected draws reproduce the seeded run
+    again = synth.generate_label_maps(shape, L, n, im_scales, def_scales, 1, 3, seed=999, draws=draws)
+    for got, rep, ref, im in zip(maps, again, ref_maps, ref_ims):
+        assert got.dtype == np.uint8 and got.shape == shape and np.array_equal(got, rep)
+        assert len(np.unique(ref)) >= 4
+        srt = np.sort(im, axis=-1)
+        near_tie = (srt[..., -1] - srt[..., -2]) < 1e-5 * np.abs(im).max()
+        diff = got != ref
+        assert not (diff & ~near_tie).any(), f"{(diff & ~near_tie).sum()} label mismatches away from ties"
+        assert diff.mean() < 1e-3
+        if diff.any():  # at a near-tie the GPU label must be the runner-up
+            order = np.argsort(-im, axis=-1, kind="stable")
+            assert np.array_equal(got[diff], order[..., 1][diff].astype(np.uint8))
+
+
+def test_argmax_u8_bitexact_with_ties(dev):
+    """mmr_argmax_u8 == tf.argmax / np.argmax (index of the FIRST maximum) bit for bit, on data full of exact ties
+    (small integers), on all-equal rows, with the maximum in the first / last channel, for several channel counts."""
+    import mmr
+    rng = np.random.default_rng(0)
+    for C in (1, 2, 3, 6, 26, 33):
+        x = rng.integers(-2, 3, (5, 7, 11, C)).astype(np.float32)
+        x[0, 0, :, :] = 1.0                      # whole row tied -> 0
+        x[1, 1, :, -1] = 9.0                     # unique max in the last channel
+        x[2, 2, :, 0] = 9.0                      # unique max in the first channel
+        x[3, 3, :, :] = -np.float32(0.0)         # -0.0 == +0.0 ties
+        got = mmr.ops.argmax_u8(torch.from_numpy(x).cuda()).cpu().numpy()
+        assert got.dtype == np.uint8 and np.array_equal(got, np.argmax(x, -1).astype(np.uint8)), C

@@ -154,3 +154,103 @@ def test_layer_plan_matches_keras_order():
     assert n == 1_454_211 or abs(n - 1.45e6) < 1e4  # SURVEY: 1.45 M params at 64 features
     p256 = net_np.layer_plan([256] * 4, [256] * 6)
     assert abs(sum(27 * ci * co + co for _, ci, co in p256) - 23.04e6) < 5e4
+
+
+def test_gradient_oracle_kinks_self_consistent():
+    """oracle/grad_torch.py::unet(kinks=...) with the kinks taken from its OWN activations is the same function and
+    has the same gradients as the plain graph (LeakyReLU slopes and max-pool routing of the same linear piece);
+    with kinks from a perturbed evaluation the forward moves by no more than the perturbation."""
+    from oracle import grad_torch as G
+    enc, dec = [4, 4], [4, 4, 4]
+    r = np.random.default_rng(3)
+    ws = [torch.from_numpy(w).double().requires_grad_(True) for w in net_np.init_weights(enc, dec, seed=1, flow_std=0.1)]
+    src = torch.from_numpy(r.random((1, 8, 8, 8, 1)))
+    trg = torch.from_numpy(r.random((1, 8, 8, 8, 1)))
+    acts = []
+    real = G.conv
+
+    def rec(x, w, b, leaky=True):
+        y = real(x, w, b, leaky)
+        if leaky:
+            acts.append(y.detach())
+        return y
+    G.conv = rec
+    try:
+        f0 = G.unet(src, trg, ws, enc, dec)
+    finally:
+        G.conv = real
+    assert len(acts) == len(enc) + len(dec)
+    g0 = torch.autograd.grad(f0.square().sum(), ws)
+    f1 = G.unet(src, trg, ws, enc, dec, kinks=acts)
+    g1 = torch.autograd.grad(f1.square().sum(), ws)
+    assert torch.allclose(f0, f1, rtol=0, atol=1e-14)
+    for a, b in zip(g0, g1):
+        assert torch.allclose(a, b, rtol=1e-12, atol=1e-14)
+    f2 = G.unet(src, trg, ws, enc, dec, kinks=[a + 1e-6 * torch.randn_like(a) for a in acts])
+    assert (f2 - f0).abs().max() < 1e-4 * f0.abs().max()
+
+
+def test_generate_label_maps_oracle_kat():
+    """oracle/synth_np.generate_label_maps (train_synthmorph.py:55-69): zero warp noise -> the label map is the
+    argmax of the Perlin image itself; a constant image -> label 0 everywhere (tf.argmax returns the first maximum)."""
+    from oracle import synth_np
+    shape, L = (8, 8, 8), 4
+    r = np.random.default_rng(0)
+    d = {"im": {"stds": [1.0], "noise": [r.standard_normal((4, 4, 4, L)).astype(np.float32)]},
+         "warp": {"stds": [0.0], "noise": [np.zeros((4, 4, 4, 2, 3), np.float32)]}}
+    maps, ims = synth_np.generate_label_maps(shape, L, [d], [2], [2])
+    ref = synth_np.perlin((*shape, L), [2], [1.0], d["im"]["noise"])
+    assert maps[0].dtype == np.uint8 and np.array_equal(maps[0], np.argmax(ref, -1))
+    d["im"]["stds"] = [0.0]
+    maps, _ = synth_np.generate_label_maps(shape, L, [d], [2], [2])
+    assert not maps[0].any()
+
+
+def test_switchable_semantics_oracle_branches():
+    """KATs for the oracle's own branches of the unpinnable upstream variants."""
+    # A4: arange(new)/f -- factor 2: even outputs copy, odd are midpoints, the last clamps; factor .5: every 2nd sample
+    v = (np.arange(5, dtype=np.float32) ** 2)[:, None, None, None] * np.ones((1, 2, 2, 1), np.float32)
+    up = O.resize(v, 2, grid="arange_over_f")
+    assert np.allclose(up[:, 0, 0, 0], [0, .5, 1, 2.5, 4, 6.5, 9, 12.5, 16, 16])
+    assert np.array_equal(O.resize(v, 0.5, grid="arange_over_f")[:, 0, 0, 0], [0, 4])
+    ac = O.resize(v, 2, grid="align_corners")
+    assert np.isclose(ac[0, 0, 0, 0], 0) and np.isclose(ac[-1, 0, 0, 0], 16) and not np.allclose(ac, up)
+    # torch interpolate(align_corners=False) is NOT the arange/f grid (it is half-pixel centred): document by test
+    t = F.interpolate(torch.from_numpy(v).permute(3, 0, 1, 2)[None], scale_factor=2, mode="trilinear", align_corners=False)
+    assert not np.allclose(t[0, 0, :, 0, 0].numpy(), up[:, 0, 0, 0])
+    # A6: bottom == 0 -> 0 in both; tiny bottom separates them
+    t1 = np.zeros((1, 2, 2, 2, 2), np.float32); p1 = np.zeros_like(t1)
+    assert O.dice_loss(t1, p1) == 0 and O.dice_loss(t1, p1, eps_mode="max_eps") == 0
+    p1[0, 0, 0, 0, 0] = 2e-6; t1[0, 0, 0, 0, 0] = 1e-6
+    a, b = O.dice_loss(t1, p1), O.dice_loss(t1, p1, eps_mode="max_eps")
+    assert np.isclose(a, -0.5 * (2 * 2e-12 / 3e-6)) and np.isclose(b, -0.5 * (2 * 2e-12 / 1e-5))
+    # A8: identical images -> both forms give -1 away from eps; constant image: the 4^3 windows that lie wholly inside the
+    # 12^3 volume have zero variance and zero cross (classic cc = 0/(0+eps) = 0, clamped cc = (eps/eps)^2 = 1); every
+    # window that touches the zero padding has cc = 1 under both
+    r = np.random.default_rng(0)
+    I = r.random((1, 12, 12, 12, 1))
+    assert np.allclose(O.ncc_loss(I, I, 9, form="clamped"), O.ncc_loss(I, I, 9, form="classic"), rtol=1e-3)
+    c = np.full((1, 12, 12, 12, 1), 0.5)
+    assert np.isclose(O.ncc_loss(c, c, 9, form="classic")[0], -(1.0 - 64 / 1728), atol=1e-6)
+    assert np.isclose(O.ncc_loss(c, c, 9, form="clamped")[0], -1.0, atol=1e-6)
+    from oracle import grad_torch as G
+    for form in ("classic", "clamped"):
+        assert np.allclose(G.ncc_loss(torch.from_numpy(I), torch.from_numpy(I * 0.5 + 0.1), form=form).numpy(),
+                           O.ncc_loss(I, I * 0.5 + 0.1, 9, form=form), rtol=1e-9)
+
+
+def test_torch_cpu_baseline_graph_equals_numpy_oracle():
+    """oracle/net_torch.py (what bench.py times as cpu_baseline) computes the same VxmDense forward as oracle/net_np.py."""
+    from oracle import net_torch
+    enc, dec = [8, 8, 8], [8, 8, 8, 8]
+    r = np.random.default_rng(1)
+    w = net_np.init_weights(enc, dec, seed=2, flow_std=0.05)
+    for i in range(1, len(w), 2):
+        w[i] = (r.standard_normal(w[i].shape) * 0.05).astype(np.float32)
+    mov = r.random((1, 16, 16, 24, 1)).astype(np.float32)
+    fix = r.random((1, 16, 16, 24, 1)).astype(np.float32)
+    ref = net_np.vxm_dense_forward(mov, fix, w, enc, dec, 5, 2, 2)
+    got = net_torch.vxm_dense_forward(torch.from_numpy(mov), torch.from_numpy(fix), net_torch.prepare_weights(w), enc, dec, 5, 2, 2)
+    assert np.abs(ref["pos_flow"]).max() > 0.3
+    for k in ("moved", "preint_flow", "pos_flow"):
+        assert np.abs(got[k].numpy() - ref[k]).max() < 2e-5 * max(np.abs(ref[k]).max(), 1), k
