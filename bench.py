@@ -135,6 +135,15 @@ def roofline_from_profile(prof, steps, dtype, traffic_file):
         return None, {}
     dom = max(fam, key=lambda k: fam[k][0])
     ms, fl, n = fam[dom]
+    fam_ms = {k: round(v[0] / steps, 4) for k, v in fam.items()}
+    if dom.startswith("hbm:"):   # HBM-bound family: the recorded work is ALGORITHMIC BYTES per launch
+        gbs = fl / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                "traffic": None, "kernel": dom[4:], "launches_per_step": n // max(steps, 1), "avg_launch_ms": ms / max(n, 1),
+                "algorithmic_bytes_per_launch": fl / max(n, 1),
+                "other_kernels_GBps": {k[4:]: round(v[1] / (v[0] * 1e-3) / 1e9, 1) for k, v in fam.items()
+                                       if k != dom and k.startswith("hbm:") and v[0] > 0}}
+        return roof, fam_ms
     peak = PEAKS["bf16" if "bf16" in dom else ("f32x3" if "f32x3" in dom else "fp32")]
     achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     traffic = None
@@ -347,10 +356,15 @@ def main():
         if forced and world == 1:
             res["config"]["collectives"] = "rccl (forced single-rank group)" if backend == "nccl" else backend + " (forced)"
         roof, fam_ms = roofline_from_profile(prof, args.steps, dtype, f"traffic_{args.workload}.json")
-        if args.workload == "ncc":
+        if args.workload == "ncc" and roof:
             gbs = extra["algorithmic_bytes_per_step"] / (dt / args.steps) / 1e9
-            roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                    "traffic": None, "kernel": "ncc_partial_kernel + bending_partial_kernel (2+3 volumes read once)"}
+            roof["whole_step_GBps"] = gbs   # NCC + bending + finalize launches + the torch add, wall clock
+            tf = os.path.join(ROOT, "profiles", "traffic_ncc.json")
+            if os.path.exists(tf):
+                try:
+                    roof["traffic"] = json.load(open(tf)).get(roof["kernel"], {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    pass
         if roof:
             res["roofline"] = roof
         if fam_ms:

@@ -2,6 +2,8 @@
 // All reductions are two-stage and ordered (per-thread fp32 -> per-block
 // double partials in a caller workspace -> one finalize block), so results
 // are bitwise reproducible run to run -- no float atomics.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace mmr {
@@ -180,11 +182,15 @@ grad_l2_final_kernel(const double* __restrict__ part, float* __restrict__ out, i
 // size.  form: MMR_NCC_CLASSIC cc = cross^2 / (Iv Jv + eps); MMR_NCC_CLAMPED (newer voxelmorph):
 // cross, Iv, Jv clamped to >= eps, cc = (cross / Iv) * (cross / Jv).  Returns cc and d cc / d (cross, Iv, Jv).
 struct NccTerms { float cc, uI, uJ, A, Bc, Cc; };
+// FAST: quotients through v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division sequence
+template <bool FAST = false>
+__device__ __forceinline__ float ncc_div(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+template <bool FAST = false>
 __device__ __forceinline__ NccTerms ncc_terms(const float* S, float ws, float eps, int form)
 {
     NccTerms t;
-    t.uI = S[0] / ws;
-    t.uJ = S[1] / ws;
+    t.uI = FAST ? S[0] * (1.0f / ws) : S[0] / ws;
+    t.uJ = FAST ? S[1] * (1.0f / ws) : S[1] / ws;
     float cross = S[4] - t.uJ * S[0] - t.uI * S[1] + t.uI * t.uJ * ws;
     float Iv = S[2] - 2.f * t.uI * S[0] + t.uI * t.uI * ws;
     float Jv = S[3] - 2.f * t.uJ * S[1] + t.uJ * t.uJ * ws;
@@ -193,14 +199,14 @@ __device__ __forceinline__ NccTerms ncc_terms(const float* S, float ws, float ep
         cross = kc ? cross : eps;
         Iv = ki ? Iv : eps;
         Jv = kj ? Jv : eps;
-        const float ri = cross / Iv, rj = cross / Jv;
+        const float ri = ncc_div<FAST>(cross, Iv), rj = ncc_div<FAST>(cross, Jv);
         t.cc = ri * rj;
         t.A = kc ? 2.f * cross / (Iv * Jv) : 0.f;
         t.Bc = ki ? -ri * rj / Iv : 0.f;
         t.Cc = kj ? -ri * rj / Jv : 0.f;
     } else {
         const float den = Iv * Jv + eps;
-        const float r = cross / den;
+        const float r = ncc_div<FAST>(cross, den);
         t.cc = cross * r;
         t.A = 2.f * r;
         t.Bc = -r * r * Jv;
@@ -328,6 +334,180 @@ ncc_xbox_kernel(const float* __restrict__ zy, double* __restrict__ part, int X, 
     if (threadIdx.x == 0) part[((size_t)b * nseg + seg) * gridDim.x + blockIdx.x] = r;
 }
 
+// ------------------------------ local NCC, single pass ------------------------------ //
+// Forward only (the backward below keeps the two-pass form because it needs the window sums as fields).
+// One 512-thread workgroup owns a (32 y) x (56 z) output tile and marches along an x segment; nothing but the two
+// input volumes is read and nothing but one partial sum per workgroup is written (the two-pass form moved 0.8 GB at
+// 256^3 for 134 MB of input).  The three box filters use three different mechanisms, so no window-sum volume exists:
+//   x: every lane keeps the RAW (I, J) of the last 9 planes of its 5 haloed rows in registers (90 VGPRs); the five
+//      window sums (I, J, I^2, J^2, IJ) slide (+ new plane - leaving plane) and are re-summed exactly from the ring
+//      every 9th plane, so a sum never carries more than 8 add/subtract pairs of rounding (no drift along x);
+//   y: the 40 haloed rows x 5 x-sums are exchanged through LDS (double buffered, one barrier per plane) and each wave
+//      sums the 9-row windows of its 4 output rows;
+//   z: lanes are z; the 9-wide window of those 4 x 5 values is 8 dependent `v_add_f32_dpp ... wave_shr:1` (whole-wave
+//      shift by one lane, zero shifted in at lane 0): VALU only, 7 clk per wave-instruction measured
+//      (tools/ubench/dpp_rate.hip) against 40 for the ds_bpermute + add the two-pass kernels use.
+// 'SAME' zero padding: out-of-volume samples are loaded from a clamped (in-bounds) address and multiplied by a 0/1
+// mask -- a `cond ? load : 0` makes hipcc branch around every load and wait for each one in turn.  Tile geometry:
+// lanes 0..63 hold input z = 56 zt - 4 + lane; after the right-shifting box, lane l >= 8 holds the window centred
+// at z - 4 = 56 zt + (l - 8) (56 outputs).
+constexpr int NF_WAVES = 8;                       // waves per workgroup
+constexpr int NF_RPW = 5;                         // haloed rows per wave
+constexpr int NF_ROWS = NF_WAVES * NF_RPW;        // 40 haloed rows
+constexpr int NF_YOUT = NF_ROWS - 8;              // 32 output rows per tile
+constexpr int NF_OPW = NF_YOUT / NF_WAVES;        // 4 output rows per wave
+constexpr int NF_ZOUT = 56;
+constexpr int NF_LDS_BYTES = 2 * NF_ROWS * 5 * 64 * (int)sizeof(float);   // 102,400 B
+
+__device__ __forceinline__ float wave_shr1(float v)   // lane l <- lane l-1, lane 0 <- 0
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float box9_shr(float v)    // lane l: v[l-8] + ... + v[l]
+{
+    float s = v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s = v + wave_shr1(s);
+    return s;
+}
+
+__global__ void __launch_bounds__(NF_WAVES * 64)
+ncc_fused_kernel(const float* __restrict__ I, const float* __restrict__ J, double* __restrict__ part, int X, int Y, int Z,
+                 int xseg, int nxs, int nyt, int nzt, float eps, int form)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* zb = reinterpret_cast<float*>(smem);            // [2][NF_ROWS][5][64]
+    __shared__ double sh[NF_WAVES];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int t = blockIdx.x;
+    const int zt = t % nzt; t /= nzt;
+    const int yt = t % nyt; t /= nyt;
+    const int xs = t % nxs;
+    const int b = t / nxs;
+    const int x0 = xs * xseg;
+    const int x1 = (x0 + xseg < X) ? x0 + xseg : X;
+    const int z = zt * NF_ZOUT - 4 + lane;                  // input z of this lane
+    const bool zin = z >= 0 && z < Z;
+    const size_t nvox = (size_t)X * Y * Z;
+    const float* Ib = I + (size_t)b * nvox;
+    const float* Jb = J + (size_t)b * nvox;
+    const int yrow0 = yt * NF_YOUT - 4 + w * NF_RPW;        // first haloed row of this wave
+    int roff[NF_RPW];
+    float rmask[NF_RPW];
+#pragma unroll
+    for (int r = 0; r < NF_RPW; ++r) {
+        const int y = yrow0 + r;
+        const bool in = zin && y >= 0 && y < Y;
+        rmask[r] = in ? 1.f : 0.f;
+        roff[r] = in ? y * Z + z : 0;
+    }
+    float ra[9][NF_RPW], rc[9][NF_RPW];                     // raw ring, slot 8 = newest plane
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int r = 0; r < NF_RPW; ++r) ra[k][r] = rc[k][r] = 0.f;
+    // outputs of this wave: tile rows NF_OPW*w .. +3 (haloed rows NF_OPW*w .. NF_OPW*w + 11)
+    const int yo0 = yt * NF_YOUT + w * NF_OPW;
+    const int zc = z - 4;
+    const bool zout = lane >= 8 && zc < Z;                  // zc >= 0 follows from lane >= 8 (zt >= 0)
+    const float ws = 729.f;
+    float acc = 0.f;
+    float pa[NF_RPW], pc[NF_RPW];                           // prefetched plane
+    const int xi0 = x0 - 4, nstep = (x1 - x0) + 8;
+    {
+        const float xm = xi0 >= 0 ? 1.f : 0.f;              // xi0 < X always
+        const size_t po = (size_t)(xi0 >= 0 ? xi0 : 0) * Y * Z;
+#pragma unroll
+        for (int r = 0; r < NF_RPW; ++r) {
+            pa[r] = Ib[po + roff[r]] * (xm * rmask[r]);
+            pc[r] = Jb[po + roff[r]] * (xm * rmask[r]);
+        }
+    }
+    float W[NF_RPW][5];                                     // x-window sums of this lane's rows
+#pragma unroll
+    for (int r = 0; r < NF_RPW; ++r)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) W[r][q] = 0.f;
+    for (int s = 0; s < nstep; ++s) {
+        // slide the window sums (the leaving plane is ring slot 0), rotate the ring, take the prefetched plane
+        const bool refresh = (s - 8) % 9 == 0;              // s = 8, 17, 26, ...: exact re-sum instead (uniform)
+        if (s > 8 && !refresh) {
+#pragma unroll
+            for (int r = 0; r < NF_RPW; ++r) {
+                const float a = pa[r], c = pc[r], ao = ra[0][r], co = rc[0][r];
+                W[r][0] += a - ao;
+                W[r][1] += c - co;
+                W[r][2] += a * a - ao * ao;
+                W[r][3] += c * c - co * co;
+                W[r][4] += a * c - ao * co;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int r = 0; r < NF_RPW; ++r) { ra[k][r] = ra[k + 1][r]; rc[k][r] = rc[k + 1][r]; }
+#pragma unroll
+        for (int r = 0; r < NF_RPW; ++r) { ra[8][r] = pa[r]; rc[8][r] = pc[r]; }
+        {
+            const int xn = xi0 + s + 1;
+            const bool xin = xn >= 0 && xn < X;             // the plane after the last step is loaded but never used
+            const float xm = xin ? 1.f : 0.f;
+            const size_t po = (size_t)(xin ? xn : 0) * Y * Z;
+#pragma unroll
+            for (int r = 0; r < NF_RPW; ++r) {
+                pa[r] = Ib[po + roff[r]] * (xm * rmask[r]);
+                pc[r] = Jb[po + roff[r]] * (xm * rmask[r]);
+            }
+        }
+        if (s < 8) continue;                                // window not yet full (uniform branch)
+        if (refresh) {
+#pragma unroll
+            for (int r = 0; r < NF_RPW; ++r) {
+                float sI = 0.f, sJ = 0.f, sII = 0.f, sJJ = 0.f, sIJ = 0.f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const float a = ra[k][r], c = rc[k][r];
+                    sI += a; sJ += c; sII += a * a; sJJ += c * c; sIJ += a * c;
+                }
+                W[r][0] = sI; W[r][1] = sJ; W[r][2] = sII; W[r][3] = sJJ; W[r][4] = sIJ;
+            }
+        }
+        float* buf = zb + (size_t)(s & 1) * (NF_ROWS * 5 * 64);
+#pragma unroll
+        for (int r = 0; r < NF_RPW; ++r) {
+            float* o = buf + ((w * NF_RPW + r) * 5) * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) o[q * 64] = W[r][q];
+        }
+        __syncthreads();
+        // y windows of this wave's 4 output rows (rows j .. j+8 of the 12 it reads; common part rows 3..8), then the z box
+        float S[NF_OPW][5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            float v[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) v[j] = buf[((w * NF_OPW + j) * 5 + q) * 64 + lane];
+            const float A = ((v[3] + v[4]) + (v[5] + v[6])) + (v[7] + v[8]);
+            S[0][q] = box9_shr(A + ((v[0] + v[1]) + v[2]));
+            S[1][q] = box9_shr(A + ((v[1] + v[2]) + v[9]));
+            S[2][q] = box9_shr(A + ((v[2] + v[9]) + v[10]));
+            S[3][q] = box9_shr(A + ((v[9] + v[10]) + v[11]));
+        }
+#pragma unroll
+        for (int j = 0; j < NF_OPW; ++j)
+            if (zout && yo0 + j < Y) acc += ncc_terms<true>(S[j], ws, eps, form).cc;
+    }
+    double v = wave_sum((double)acc);
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0.0;
+#pragma unroll
+        for (int i = 0; i < NF_WAVES; ++i) r += sh[i];
+        part[blockIdx.x] = r;
+    }
+}
+
 __global__ void mean_final_kernel(const double* __restrict__ part, float* __restrict__ out, int B, int64_t nb,
                                   double denom, float sign)
 {
@@ -340,59 +520,94 @@ __global__ void mean_final_kernel(const double* __restrict__ part, float* __rest
 }
 
 // ------------------------------ bending --------------------------------- //
-// A thread owns an interior (y,z) column and marches along an x segment keeping the three x-planes of its
-// stencil in registers: per voxel it loads only the 5 points of the incoming plane (centre, y+-1, z+-1) x 3
-// channels instead of 19 x 3; z runs across lanes so every load is a contiguous 12 B/lane stream.
-struct P5 { float c[3], ym[3], yp[3], zm[3], zp[3]; };
+// Bending energy, forward.  A lane owns one voxel column position z (its three channels are one 12-byte load per
+// row), a wave owns BF_R output rows (BF_R + 2 haloed) of a 64-wide z strip and marches along an x segment with the
+// three planes of the stencil in registers: every input row is loaded ONCE per plane as a contiguous 768-byte wave
+// load; the z +- 1 neighbours are whole-wave DPP shifts (wave_shr:1 / wave_shl:1), not loads.  The first version
+// issued 27 scalar loads per voxel (1.65 TB/s at 256^3); this one issues (BF_R + 2) / BF_R.
+constexpr int BF_ZOUT = 62;      // output voxels per wave along z (lanes 1..62)
 
-__device__ __forceinline__ P5 load_p5(const float* q, int sy)
+__device__ __forceinline__ float wave_shl1(float v)   // lane l <- lane l+1, lane 63 <- 0
 {
-    P5 r;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        r.c[k] = q[k]; r.ym[k] = q[k - sy]; r.yp[k] = q[k + sy]; r.zm[k] = q[k - 3]; r.zp[k] = q[k + 3];
-    }
-    return r;
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
-__global__ void __launch_bounds__(RED_BLOCK)
-bending_partial_kernel(const float* __restrict__ u, double* __restrict__ part, int X, int Y, int Z, int xseg, int nseg)
+struct F3 { float v[3]; };
+
+template <int BF_R>              // output rows per wave (BF_R + 2 rows loaded per plane)
+__global__ void __launch_bounds__(RED_BLOCK, 2)
+bending_fused_kernel(const float* __restrict__ u, double* __restrict__ part, int X, int Y, int Z, int xseg, int nxs, int nyg,
+                     int nzs, int64_t nwaves)
 {
     __shared__ double sh[4];
-    const int b = blockIdx.z / nseg, seg = blockIdx.z % nseg;
-    const int Yi = Y - 2, Zi = Z - 2;
-    const int col = blockIdx.x * RED_BLOCK + threadIdx.x;
-    const int sy = Z * 3;
-    const size_t sx = (size_t)Y * Z * 3;
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     float acc = 0.f;
-    if (col < Yi * Zi) {
-        const int y = col / Zi + 1, z = col % Zi + 1;
-        const int x0 = 1 + seg * xseg;
-        const int x1 = (x0 + xseg < X - 1) ? x0 + xseg : X - 1;
-        const float* q = u + (size_t)b * X * sx + (size_t)y * sy + (size_t)z * 3;
-        // need centre, y+-1, z+-1 at x-1 and x+1; plus the four yz diagonals at x
-        P5 pm = load_p5(q + (size_t)(x0 - 1) * sx, sy);
-        P5 pc = load_p5(q + (size_t)x0 * sx, sy);
-        for (int x = x0; x < x1; ++x) {
-            const float* qc = q + (size_t)x * sx;
-            const P5 pp = load_p5(qc + sx, sy);
+    if (wid < nwaves) {
+        int64_t t = wid;
+        const int zs = (int)(t % nzs); t /= nzs;
+        const int yg = (int)(t % nyg); t /= nyg;
+        const int xs = (int)(t % nxs);
+        const int b = (int)(t / nxs);
+        const int z = zs * BF_ZOUT + lane;                  // outputs at lanes 1..62 -> z = zs*62 + 1 .. zs*62 + 62
+        const bool zin = z < Z;
+        const int yh0 = yg * BF_R;                          // first haloed row; output rows yh0 + 1 .. yh0 + BF_R
+        const int xa = 1 + xs * xseg;
+        const int xb = (xa + xseg < X - 1) ? xa + xseg : X - 1;
+        const size_t sx = (size_t)Y * Z * 3;
+        const float* base = u + (size_t)b * X * sx;           // wave-uniform; per-lane parts are 32-bit offsets
+        const unsigned zoff = (unsigned)(zin ? z : 0) * 3u;   // clamped: masked lanes load in bounds
+        unsigned roff[BF_R + 2];
+        float rmask[BF_R + 2];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float c0 = pc.c[k];
-                const float dxx = pp.c[k] - 2.f * c0 + pm.c[k];
-                const float dyy = pc.yp[k] - 2.f * c0 + pc.ym[k];
-                const float dzz = pc.zp[k] - 2.f * c0 + pc.zm[k];
-                const float dxy = (pp.yp[k] - pp.ym[k] - pm.yp[k] + pm.ym[k]) * 0.25f;
-                const float dxz = (pp.zp[k] - pp.zm[k] - pm.zp[k] + pm.zm[k]) * 0.25f;
-                const float dyz = (qc[k + sy + 3] - qc[k + sy - 3] - qc[k - sy + 3] + qc[k - sy - 3]) * 0.25f;
-                acc += dxx * dxx + dyy * dyy + dzz * dzz + 2.f * (dxy * dxy + dxz * dxz + dyz * dyz);
+        for (int r = 0; r < BF_R + 2; ++r) {
+            const bool in = zin && (yh0 + r) < Y;
+            rmask[r] = in ? 1.f : 0.f;
+            roff[r] = (in ? (unsigned)(yh0 + r) * (unsigned)Z * 3u : 0u) + zoff;
+        }
+        F3 p0[BF_R + 2], p1[BF_R + 2], p2[BF_R + 2], pn[BF_R + 2];
+        auto load_plane = [&](F3* p, int x) {
+            const float* q = base + (size_t)x * sx;
+#pragma unroll
+            for (int r = 0; r < BF_R + 2; ++r) {
+                // one 12-byte load from an always-in-bounds address, zeroed by a multiplicative mask: a `cond ? load : 0`
+                // makes hipcc branch around every load and wait for each in turn (8 dependent round trips per plane)
+                const F3 t = *reinterpret_cast<const F3*>(q + roff[r]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) p[r].v[k] = t.v[k] * rmask[r];
             }
-            pm = pc;
-            pc = pp;
+        };
+        load_plane(p0, xa - 1);
+        load_plane(p1, xa);
+        load_plane(p2, xa + 1);
+        const bool zout = lane >= 1 && lane <= BF_ZOUT && z <= Z - 2;
+        for (int x = xa; x < xb; ++x) {
+            load_plane(pn, (x + 2 < X) ? x + 2 : X - 1);     // one plane ahead of the stencil: its latency hides under this step
+#pragma unroll
+            for (int j = 0; j < BF_R; ++j) {
+                float e = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float c0 = p1[j + 1].v[k];
+                    const float dxx = p2[j + 1].v[k] - 2.f * c0 + p0[j + 1].v[k];
+                    const float dyy = p1[j + 2].v[k] - 2.f * c0 + p1[j].v[k];
+                    const float dzz = wave_shl1(c0) - 2.f * c0 + wave_shr1(c0);
+                    const float dxy = (p2[j + 2].v[k] - p2[j].v[k] - p0[j + 2].v[k] + p0[j].v[k]) * 0.25f;
+                    // mixed z differences: difference across x (or y) first, then ONE pair of lane shifts of it
+                    const float dx = p2[j + 1].v[k] - p0[j + 1].v[k];
+                    const float dy = p1[j + 2].v[k] - p1[j].v[k];
+                    const float dxz = (wave_shl1(dx) - wave_shr1(dx)) * 0.25f;
+                    const float dyz = (wave_shl1(dy) - wave_shr1(dy)) * 0.25f;
+                    e += dxx * dxx + dyy * dyy + dzz * dzz + 2.f * (dxy * dxy + dxz * dxz + dyz * dyz);
+                }
+                if (zout && (yh0 + 1 + j) <= Y - 2) acc += e;
+            }
+#pragma unroll
+            for (int r = 0; r < BF_R + 2; ++r) { p0[r] = p1[r]; p1[r] = p2[r]; p2[r] = pn[r]; }
         }
     }
     const double r = block_sum((double)acc, sh);
-    if (threadIdx.x == 0) part[((size_t)b * nseg + seg) * gridDim.x + blockIdx.x] = r;
+    if (threadIdx.x == 0) part[blockIdx.x] = r;
 }
 
 // ------------------------------ NCC backward ---------------------------- //
@@ -693,15 +908,29 @@ inline void ncc_geom(int X, int Y, int Z, int& nseg, int& ncolblk)
     nseg = (X + NCC_XSEG - 1) / NCC_XSEG;
     ncolblk = (int)(((int64_t)Y * Z + 255) / 256);
 }
+// single-pass forward: (y,z) tiles x x-segments; the segment count fills the 256 CUs once (one workgroup per CU by
+// LDS) without making segments so short that their 8-plane halo dominates
+inline void ncc_fused_geom(int B, int X, int Y, int Z, int& nzt, int& nyt, int& nxs, int& xseg)
+{
+    nzt = (Z + NF_ZOUT - 1) / NF_ZOUT;
+    nyt = (Y + NF_YOUT - 1) / NF_YOUT;
+    const int64_t tiles = (int64_t)B * nzt * nyt;
+    int want = (int)((256 + tiles - 1) / tiles);            // segments so that tiles * segs >= ~256
+    if (tiles * want > 256 && want > 1) --want;             // ... but not more than one round of workgroups
+    const int max_by_len = X / 16 > 0 ? X / 16 : 1;         // keep segments >= 16 planes (halo <= 1.5x)
+    nxs = want < 1 ? 1 : (want > max_by_len ? max_by_len : want);
+    xseg = (X + nxs - 1) / nxs;
+    nxs = (X + xseg - 1) / xseg;
+}
 }  // namespace
 
-// workspace = the five zy-box volumes (fp32) followed by the per-block partial sums
+// workspace = one double per workgroup of the single-pass kernel
 extern "C" int64_t mmr_ncc_ws_bytes(int B, int X, int Y, int Z)
 {
     if (B < 1 || X < 1 || Y < 1 || Z < 1) return MMR_EINVAL;
-    int nseg, ncolblk;
-    ncc_geom(X, Y, Z, nseg, ncolblk);
-    return (int64_t)B * 5 * X * Y * Z * sizeof(float) + (int64_t)B * nseg * ncolblk * sizeof(double);
+    int nzt, nyt, nxs, xseg;
+    ncc_fused_geom(B, X, Y, Z, nzt, nyt, nxs, xseg);
+    return (int64_t)B * nzt * nyt * nxs * sizeof(double);
 }
 
 extern "C" int mmr_ncc_fwd_f32(const float* I, const float* J, float* out, void* ws, int B, int X, int Y, int Z,
@@ -710,58 +939,74 @@ extern "C" int mmr_ncc_fwd_f32(const float* I, const float* J, float* out, void*
     if (!I || !J || !out || !ws || B < 1 || X < 1 || Y < 1 || Z < 1) return MMR_EINVAL;
     if (ncc_form != MMR_NCC_CLASSIC && ncc_form != MMR_NCC_CLAMPED) return MMR_EINVAL;
     if (win != 9) return MMR_EUNSUPPORTED;
-    int nseg, ncolblk;
-    ncc_geom(X, Y, Z, nseg, ncolblk);
-    if ((int64_t)B * nseg > 65535) return MMR_EINVAL;
-    float* zy = (float*)ws;
-    double* part = (double*)((char*)ws + (size_t)B * 5 * X * Y * Z * sizeof(float));
-    const int nzs = (Z + NCC_ZOUT - 1) / NCC_ZOUT, nys = (Y + NCC_ROWS - 1) / NCC_ROWS;
-    const int64_t nw = (int64_t)B * X * nys * nzs;
-    const int64_t nb1 = (nw + 3) / 4;
-    if (nb1 > 0x7fffffff) return MMR_EINVAL;
-    hipLaunchKernelGGL(ncc_zybox_kernel, dim3((unsigned)nb1), dim3(256), 0, as_stream(stream), I, J, zy, B, X, Y, Z, nzs, nys);
+    if ((int64_t)Y * Z > 0x7fffffff) return MMR_EINVAL;
+    int nzt, nyt, nxs, xseg;
+    ncc_fused_geom(B, X, Y, Z, nzt, nyt, nxs, xseg);
+    const int64_t nblk = (int64_t)nzt * nyt * nxs;          // per batch item
+    if ((int64_t)B * nblk > 0x7fffffff) return MMR_EINVAL;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ncc_fused_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, NF_LDS_BYTES);
+        if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
+        attr_set = true;
+    }
+    double* part = (double*)ws;
+    hipLaunchKernelGGL(ncc_fused_kernel, dim3((unsigned)(B * nblk)), dim3(NF_WAVES * 64), NF_LDS_BYTES, as_stream(stream), I, J,
+                       part, X, Y, Z, xseg, nxs, nyt, nzt, eps, ncc_form);
     int rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(ncc_xbox_kernel, dim3(ncolblk, 1, B * nseg), dim3(256), 0, as_stream(stream), (const float*)zy, part,
-                       X, Y, Z, NCC_XSEG, nseg, eps, ncc_form);
-    rc = check_launch();
-    if (rc) return rc;
-    hipLaunchKernelGGL(mean_final_kernel, dim3(B), dim3(RED_BLOCK), 0, as_stream(stream), (const double*)part, out, B,
-                       (int64_t)nseg * ncolblk, (double)X * Y * Z, -1.0f);
+    hipLaunchKernelGGL(mean_final_kernel, dim3(B), dim3(RED_BLOCK), 0, as_stream(stream), (const double*)part, out, B, nblk,
+                       (double)X * Y * Z, -1.0f);
     return check_launch();
 }
 
 namespace {
-constexpr int BEND_XSEG = 32;
-inline void bend_geom(int X, int Y, int Z, int& nseg, int& ncolblk)
+// waves over (z strips, y row groups, x segments, batch); x segments of 16 planes (2-plane halo) give >= 2048 waves at 256^3
+constexpr int BF_ROWS = 4;    // 82 us at 256^3 against 135 us with 6 rows (190 VGPRs)
+inline void bend_geom(int B, int X, int Y, int Z, int& nzs, int& nyg, int& nxs, int& xseg, int64_t& nwaves, int R = BF_ROWS)
 {
-    nseg = (X - 2 + BEND_XSEG - 1) / BEND_XSEG;
-    ncolblk = (int)(((int64_t)(Y - 2) * (Z - 2) + RED_BLOCK - 1) / RED_BLOCK);
+    nzs = (Z - 2 + BF_ZOUT - 1) / BF_ZOUT;
+    nyg = (Y - 2 + R - 1) / R;
+    xseg = 16;
+    nxs = (X - 2 + xseg - 1) / xseg;
+    nwaves = (int64_t)B * nzs * nyg * nxs;
 }
 }  // namespace
 
 extern "C" int64_t mmr_bending_ws_bytes(int B, int X, int Y, int Z)
 {
     if (B < 1 || X < 3 || Y < 3 || Z < 3) return MMR_EINVAL;
-    int nseg, ncolblk;
-    bend_geom(X, Y, Z, nseg, ncolblk);
-    return (int64_t)B * nseg * ncolblk * sizeof(double);
+    int nzs, nyg, nxs, xseg;
+    int64_t nwaves;
+    bend_geom(B, X, Y, Z, nzs, nyg, nxs, xseg, nwaves, 4);     // the smallest row group = the most blocks
+    return ((nwaves + 3) / 4 + B) * (int64_t)sizeof(double);
 }
 
 extern "C" int mmr_bending_fwd_f32(const float* flow, float* out, void* ws, int B, int X, int Y, int Z, void* stream)
 {
     if (!flow || !out || !ws || B < 1 || X < 3 || Y < 3 || Z < 3) return MMR_EINVAL;
     if ((int64_t)Y * Z * 3 > 0x7fffffff) return MMR_EINVAL;
-    int nseg, ncolblk;
-    bend_geom(X, Y, Z, nseg, ncolblk);
-    if ((int64_t)B * nseg > 65535) return MMR_EINVAL;
-    hipLaunchKernelGGL(bending_partial_kernel, dim3(ncolblk, 1, B * nseg), dim3(RED_BLOCK), 0, as_stream(stream), flow,
-                       (double*)ws, X, Y, Z, BEND_XSEG, nseg);
-    int rc = check_launch();
-    if (rc) return rc;
+    int nzs, nyg, nxs, xseg;
+    int64_t nwaves;
+    static const int rows = [] { const char* e = getenv("MMR_BEND_ROWS"); return (e && atoi(e) == 6) ? 6 : BF_ROWS; }();  // A/B knob
+    bend_geom(1, X, Y, Z, nzs, nyg, nxs, xseg, nwaves, rows);  // per batch item, so that a block never straddles items
+    const int64_t nblk = (nwaves + 3) / 4;
+    if (nblk * B > 0x7fffffff) return MMR_EINVAL;
     const int64_t n = (int64_t)(X - 2) * (Y - 2) * (Z - 2) * 3;
-    hipLaunchKernelGGL(mean_final_kernel, dim3(B), dim3(RED_BLOCK), 0, as_stream(stream), (const double*)ws, out, B,
-                       (int64_t)nseg * ncolblk, (double)n, 1.0f);
+    for (int b = 0; b < B; ++b) {
+        double* part = (double*)ws + (int64_t)b * nblk;
+        if (rows == 6)
+            hipLaunchKernelGGL(bending_fused_kernel<6>, dim3((unsigned)nblk), dim3(RED_BLOCK), 0, as_stream(stream),
+                               flow + (size_t)b * X * Y * Z * 3, part, X, Y, Z, xseg, nxs, nyg, nzs, nwaves);
+        else
+            hipLaunchKernelGGL(bending_fused_kernel<BF_ROWS>, dim3((unsigned)nblk), dim3(RED_BLOCK), 0, as_stream(stream),
+                               flow + (size_t)b * X * Y * Z * 3, part, X, Y, Z, xseg, nxs, nyg, nzs, nwaves);
+        int rc = check_launch();
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(mean_final_kernel, dim3(B), dim3(RED_BLOCK), 0, as_stream(stream), (const double*)ws, out, B, nblk,
+                       (double)n, 1.0f);
     return check_launch();
 }
 

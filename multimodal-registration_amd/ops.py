@@ -364,8 +364,9 @@ def ncc_loss(I, J, win=9, eps=1e-5, form=None):
     lib = _lib.load()
     ws = _ws(lib.mmr_ncc_ws_bytes(B, X, Y, Z), I.device)
     out = torch.empty(B, dtype=torch.float32, device=I.device)
-    rc = lib.mmr_ncc_fwd_f32(I.data_ptr(), J.data_ptr(), out.data_ptr(), ws.data_ptr(), B, X, Y, Z, int(win), float(eps),
-                             semantics.code("ncc_form", form), _stream())
+    with _Timed("hbm:ncc_fused_kernel", (X, Y, Z), 2.0 * 4 * B * X * Y * Z):   # algorithmic bytes: I and J read once
+        rc = lib.mmr_ncc_fwd_f32(I.data_ptr(), J.data_ptr(), out.data_ptr(), ws.data_ptr(), B, X, Y, Z, int(win), float(eps),
+                                 semantics.code("ncc_form", form), _stream())
     _lib.check(rc, "mmr_ncc_fwd_f32")
     return out
 
@@ -378,7 +379,8 @@ def bending_energy(flow):
     lib = _lib.load()
     ws = _ws(lib.mmr_bending_ws_bytes(B, X, Y, Z), flow.device)
     out = torch.empty(B, dtype=torch.float32, device=flow.device)
-    rc = lib.mmr_bending_fwd_f32(flow.data_ptr(), out.data_ptr(), ws.data_ptr(), B, X, Y, Z, _stream())
+    with _Timed("hbm:bending_fused_kernel", (X, Y, Z), 3.0 * 4 * B * X * Y * Z):   # the field read once
+        rc = lib.mmr_bending_fwd_f32(flow.data_ptr(), out.data_ptr(), ws.data_ptr(), B, X, Y, Z, _stream())
     _lib.check(rc, "mmr_bending_fwd_f32")
     return out
 

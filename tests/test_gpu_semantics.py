@@ -29,11 +29,13 @@ def test_resize_grid_variants(dev, shape, factor):
     for g, ref in refs.items():
         got = mmr.ops.rescale_transform(_t(trf[None], dev), factor, grid=g)[0].cpu().numpy()
         assert got.shape == ref.shape
-        np.testing.assert_allclose(got, ref, rtol=0, atol=3e-6, err_msg=g)
+        # 3e-6 where the sample coordinates are exact in fp32 (factor 2, 1/2); for factor 1.5 the kernel forms
+        # i * (1/f), the oracle i / f: one ulp of a coordinate ~ 10 moves a value by a few 1e-6
+        np.testing.assert_allclose(got, ref, rtol=0, atol=3e-6 if factor in (0.5, 2) else 2e-5, err_msg=g)
     # process-wide default
     assert mmr.semantics.get("resize_grid") == "align_corners"
     with mmr.semantics.using(resize_grid="arange_over_f"):
-        np.testing.assert_allclose(mmr.utils.rescale_dense_transform(trf, factor), refs["arange_over_f"], rtol=0, atol=3e-6)
+        np.testing.assert_allclose(mmr.utils.rescale_dense_transform(trf, factor), refs["arange_over_f"], rtol=0, atol=2e-5)
     np.testing.assert_allclose(mmr.utils.rescale_dense_transform(trf, factor), refs["align_corners"], rtol=0, atol=3e-6)
 
 
@@ -74,8 +76,10 @@ def test_ncc_form_variants(dev, form):
     shape = (14, 19, 37)
     I = rng.random((2,) + shape + (1,)).astype(np.float32)
     J = (0.5 * I + 0.5 * rng.random((2,) + shape + (1,))).astype(np.float32)
-    # a constant block: zero variance and zero cross there -> the eps handling of the two forms differs
-    I[:, 2:12, 3:14, 5:20] = 0.25
+    # a block where BOTH images are constant: zero variances and zero cross -> classic 0 / (0 + eps) = 0, clamped
+    # (eps / eps) * (eps / eps) = 1 for every window inside it
+    I[:, 1:13, 3:16, 5:22] = 0.25
+    J[:, 1:13, 3:16, 5:22] = 0.75
     ref = O.ncc_loss(I, J, 9, form=form)
     other = O.ncc_loss(I, J, 9, form="clamped" if form == "classic" else "classic")
     assert np.abs(ref - other).max() > 1e-4
