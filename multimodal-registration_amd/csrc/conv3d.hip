@@ -72,6 +72,22 @@ struct ConvParams {
     int csplit;
 };
 
+template <int N> struct IntTag { static constexpr int value = N; };
+
+// Diagnostic build only (VAR bit 10, MMR_CONV_VARIANT=1440): where a tap's cycles go.  Per wave slot w (0..7) the sums over
+// all workgroups of: [0] tap top -> weight DMA issued, [1] -> last MFMA issued (fragment reads + MFMAs), [2] -> own DMA
+// landed (vmcnt 0), [3] -> barrier passed, [4] A restage (per slice), [5] number of taps.  s_memtime ticks.  Read the
+// SHARES, never the run time of this build (cdna_hip_programming.md section 7, in-kernel stamps).
+__device__ unsigned long long g_conv_stamp[8][8];
+__device__ __forceinline__ unsigned long long stamp_now()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
 template <int DT> struct Elt;
 template <> struct Elt<MMR_DT_BF16> { static constexpr int size = 2; static constexpr int kc = 64; };
 template <> struct Elt<MMR_DT_F32> { static constexpr int size = 4; static constexpr int kc = 32; };
@@ -93,6 +109,24 @@ __device__ __forceinline__ void glds16(const char* g, unsigned lds_off)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(g), "s"(lds_off)
+                 : "memory");
+}
+
+// Same, with the source as a wave-uniform base (SGPR pair) + a 32-bit per-lane byte offset: no 64-bit address VGPRs,
+// so the DMA can be issued from the middle of the MFMA stream where every fragment register is live.
+__device__ __forceinline__ void glds16_s(const char* sbase_in, unsigned voff, unsigned lds_off)
+{
+    // the "s" constraint does not make a value uniform: hand the compiler one that provably is.  The base then comes from
+    // v_readfirstlane (a VALU write of an SGPR) and hipcc pads nothing inside an asm: a VMEM instruction that reads such an
+    // SGPR needs 5 wait states, hence the `s_nop 4`
+    const unsigned long long a = (unsigned long long)sbase_in;
+    // (readfirstlane returns int: go through unsigned, or the low half is SIGN-extended over the high one)
+    const unsigned long long sbase = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a) |
+                                     ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_off)
                  : "memory");
 }
 
@@ -137,6 +171,21 @@ conv3d_k3_kernel(const ConvParams p)
     constexpr bool LO = (DT == MMR_DT_F32X3);  // lo halves staged and multiplied
     constexpr bool PIPE = M16 && (DT == MMR_DT_BF16) && MT == 4 && ((VAR >> 7) & 1);  // VAR bit 7: explicit fragment pipeline
     constexpr bool PIPE3 = M16 && (DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) && ((VAR >> 7) & 1);
+    // VAR bit 9: the weight DMA of the next tap is issued from INSIDE the MFMA stream instead of at the top of the tap,
+    // and at different points for the two waves of a SIMD (waves w and w + 4 share one): while one wave spends its
+    // issue slots on the four global_load_lds, its partner keeps the matrix pipe fed.  Issued at the top of the tap by
+    // both, the DMA (and the fragment round trip behind it) left the pipe idle right after every barrier.
+    constexpr bool MIDDMA = PIPE && ((VAR >> 9) & 1);
+    constexpr bool STAMP = ((VAR >> 10) & 1) != 0;
+    // VAR bit 11: split placement of the next tap's weight DMA.  The cycle stamps (tools/conv_stamps.py) show that the
+    // older half of the workgroup (waves 0-3; wave w shares a SIMD with wave w + 4 and wins the issue arbitration by age)
+    // finishes its 64 MFMAs ~700 clk before the younger half and then idles at the barrier, while at the top of the tap
+    // BOTH halves spend 220-340 clk issuing their four global_load_lds with the matrix pipe empty.  So waves 0-3 issue
+    // their share AFTER their MFMAs (inside the time they would wait at the barrier anyway) and start the tap's
+    // fragment reads at once; waves 4-7 keep issuing at the top, now under the older waves' MFMAs.
+    constexpr bool SPLITDMA = (PIPE || PIPE3) && !MIDDMA && ((VAR >> 11) & 1);
+    constexpr bool BATCHA = (DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) && ((VAR >> 12) & 1);
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = 0;
     static_assert(WM * WN == 8, "8 waves");
     static_assert(TXT == 4 || TXT == 8, "M tile");
     constexpr int BN = WN * NT * 32;
@@ -247,6 +296,38 @@ conv3d_k3_kernel(const ConvParams p)
         }
         return val;
     };
+    // VAR bit 12 (fp32x3 / x1): the same items, but every lane loads from a clamped, always-valid address and returns the
+    // in-bounds flag separately, so that all loads of a slice can be issued back to back and masked when they are stored.
+    // `if (in bounds) load` compiles to a branch + wait per item: the 8 items of a slice were 8 dependent round trips
+    // (6.7 k cycles per slice on the stamps of tools/conv_stamps.py train).
+    struct AItemM { uint4 a, b; unsigned ok; };
+    auto load_a_nb = [&](int s, int it) -> AItemM {
+        const int i0 = tid + it * CONV_THREADS;
+        const int i = i0 < A_ITEMS ? i0 : A_ITEMS - 1;
+        const int ch0 = s * KC;
+        const bool first = ch0 < p.C0;
+        const char* src = first ? p.in0 : p.in1;
+        const int Cs = first ? p.C0 : p.C1;
+        const int chs = first ? ch0 : ch0 - p.C0;
+        const bool up = first && p.up0;
+        const int row = i >> 2, chunk = i & 3;
+        const int hx = row / (HY * HZ), hy = (row / HZ) % HY, hz = row % HZ;
+        const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
+        const unsigned ok = (i0 < A_ITEMS && gx >= 0 && gx < p.X && gy >= 0 && gy < p.Y && gz >= 0 && gz < p.Z) ? 0xffffffffu : 0u;
+        const int pX = p.X, pY = p.Y, pZ = p.Z;
+        const int cx = gx < 0 ? 0 : (gx >= pX ? pX - 1 : gx), cy = gy < 0 ? 0 : (gy >= pY ? pY - 1 : gy),
+                  cz = gz < 0 ? 0 : (gz >= pZ ? pZ - 1 : gz);
+        size_t vox;
+        if (up) vox = (((size_t)b * X2 + (cx >> 1)) * Y2 + (cy >> 1)) * Z2 + (cz >> 1);
+        else vox = (((size_t)b * pX + cx) * pY + cy) * pZ + cz;
+        const char* q = src + (vox * Cs + chs) * ES + chunk * 32;
+        AItemM val;
+        val.a = *reinterpret_cast<const uint4*>(q);
+        val.b = *reinterpret_cast<const uint4*>(q + 16);
+        val.ok = ok;
+        return val;
+    };
+    auto and4 = [](uint4 v, unsigned m) { return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m); };
     auto store_a = [&](int it, const AItem& val) {
         const int i = tid + it * CONV_THREADS;
         if (i < A_ITEMS) {
@@ -273,12 +354,15 @@ conv3d_k3_kernel(const ConvParams p)
         }
     };
     const unsigned sB_lds = lds_addr(sB);
+    const unsigned tid16 = (unsigned)tid * 16u;
     auto issue_b = [&](int g, int buf) {
         const char* wt = wtile + (size_t)g * B_BYTES;
         const unsigned dst = __builtin_amdgcn_readfirstlane(sB_lds + buf * B_BYTES + wave * 1024);
 #pragma unroll
-        for (int it = 0; it < B_ITERS; ++it)
-            glds16(wt + (it * CONV_THREADS + tid) * 16, dst + it * CONV_THREADS * 16);
+        for (int it = 0; it < B_ITERS; ++it) {
+            if constexpr (MIDDMA || SPLITDMA) glds16_s(wt + it * CONV_THREADS * 16, tid16, dst + it * CONV_THREADS * 16);
+            else glds16(wt + (it * CONV_THREADS + tid) * 16, dst + it * CONV_THREADS * 16);
+        }
         if (B_BYTES < CONV_THREADS * 16) {
             if (wave * 1024 < B_BYTES) glds16(wt + tid * 16, dst);
         }
@@ -320,18 +404,64 @@ conv3d_k3_kernel(const ConvParams p)
     const int g1 = p.kpart ? min(g0 + p.gsplit, G) : G;
     int cur = 0, tap = g0 % 27, s = g0 / 27;
     issue_b(g0, 0);
+    // a macro, not a lambda: wrapped in one more closure, hipcc no longer scalarises the by-value kernel argument
+    // struct and every instantiation reads ConvParams from scratch (288 B/lane; the bn64 convs ran 1.8x slower)
+    // named scalars, not an array: an indexed array of structs stays in scratch here even when unrolled
+#define MMR_STAGE_A_REGS(sl) \
+    do { \
+        if constexpr (BATCHA) { \
+            static_assert(A_ITERS <= 10, "staging items"); \
+            AItemM i0; \
+            AItemM i1; \
+            AItemM i2; \
+            AItemM i3; \
+            AItemM i4; \
+            AItemM i5; \
+            AItemM i6; \
+            AItemM i7; \
+            AItemM i8; \
+            AItemM i9; \
+            if constexpr (A_ITERS > 0) i0 = load_a_nb(sl, 0); \
+            if constexpr (A_ITERS > 1) i1 = load_a_nb(sl, 1); \
+            if constexpr (A_ITERS > 2) i2 = load_a_nb(sl, 2); \
+            if constexpr (A_ITERS > 3) i3 = load_a_nb(sl, 3); \
+            if constexpr (A_ITERS > 4) i4 = load_a_nb(sl, 4); \
+            if constexpr (A_ITERS > 5) i5 = load_a_nb(sl, 5); \
+            if constexpr (A_ITERS > 6) i6 = load_a_nb(sl, 6); \
+            if constexpr (A_ITERS > 7) i7 = load_a_nb(sl, 7); \
+            if constexpr (A_ITERS > 8) i8 = load_a_nb(sl, 8); \
+            if constexpr (A_ITERS > 9) i9 = load_a_nb(sl, 9); \
+            if constexpr (A_ITERS > 0) { AItem v; v.a = and4(i0.a, i0.ok); v.b = and4(i0.b, i0.ok); store_a(0, v); } \
+            if constexpr (A_ITERS > 1) { AItem v; v.a = and4(i1.a, i1.ok); v.b = and4(i1.b, i1.ok); store_a(1, v); } \
+            if constexpr (A_ITERS > 2) { AItem v; v.a = and4(i2.a, i2.ok); v.b = and4(i2.b, i2.ok); store_a(2, v); } \
+            if constexpr (A_ITERS > 3) { AItem v; v.a = and4(i3.a, i3.ok); v.b = and4(i3.b, i3.ok); store_a(3, v); } \
+            if constexpr (A_ITERS > 4) { AItem v; v.a = and4(i4.a, i4.ok); v.b = and4(i4.b, i4.ok); store_a(4, v); } \
+            if constexpr (A_ITERS > 5) { AItem v; v.a = and4(i5.a, i5.ok); v.b = and4(i5.b, i5.ok); store_a(5, v); } \
+            if constexpr (A_ITERS > 6) { AItem v; v.a = and4(i6.a, i6.ok); v.b = and4(i6.b, i6.ok); store_a(6, v); } \
+            if constexpr (A_ITERS > 7) { AItem v; v.a = and4(i7.a, i7.ok); v.b = and4(i7.b, i7.ok); store_a(7, v); } \
+            if constexpr (A_ITERS > 8) { AItem v; v.a = and4(i8.a, i8.ok); v.b = and4(i8.b, i8.ok); store_a(8, v); } \
+            if constexpr (A_ITERS > 9) { AItem v; v.a = and4(i9.a, i9.ok); v.b = and4(i9.b, i9.ok); store_a(9, v); } \
+        } else { \
+            _Pragma("unroll") for (int it = 0; it < A_ITERS; ++it) store_a(it, load_a(sl, it)); \
+        } \
+    } while (0)
     if constexpr (DMA_A) {
         dma_stage_a(s);
     } else {
-#pragma unroll
-        for (int it = 0; it < A_ITERS; ++it) store_a(it, load_a(s, it));
+        MMR_STAGE_A_REGS(s);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int g = g0; g < g1; ++g) {
         const bool more = g + 1 < g1;
-        if (more) issue_b(g + 1, cur ^ 1);
+        if constexpr (STAMP) st_t = stamp_now();
+        if constexpr (SPLITDMA) {
+            if (more && wave >= 4) issue_b(g + 1, cur ^ 1);
+        } else if constexpr (!MIDDMA) {
+            if (more) issue_b(g + 1, cur ^ 1);
+        }
+        if constexpr (STAMP) { const unsigned long long t = stamp_now(); st_acc[0] += t - st_t; st_t = t; }
         const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
         const int tapoff = (dx * (HY * HZ) + dy * HZ + dz) * ROWB;
         const int sw = (swz(vyl + dy, vz + dz) ^ h) << 4;
@@ -404,6 +534,58 @@ conv3d_k3_kernel(const ConvParams p)
                         acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             __builtin_bit_cast(bf16x8, bh16[ni]), __builtin_bit_cast(bf16x8, ah16[mi]), acc16[mi][ni], 0, 0, 0);
                     }
+            } else if constexpr (MIDDMA) {
+                static_assert(MT == 4 && NT == 2, "pipelined schedule is written for the 128x64 wave tile");
+                uint4 fa[2][8], fb[2][4];
+                const char* pa0 = bA + a16_off[0] + ((q16 ^ sw16) << 4);
+                const char* pa1 = bA + a16_off[0] + (((4 + q16) ^ sw16) << 4);
+                const char* pb = bB + b16_off[0];
+                // fragment i in consumption order: B of k-step 0 (4), A of k-step 0 (8), B of k-step 1 (4), A of k-step 1 (8)
+                auto rd = [&](int i) {
+                    if (i < 4) fb[0][i] = *reinterpret_cast<const uint4*>(pb + i * 256);
+                    else if (i < 12) { const int mi = i - 4; fa[0][mi] = *reinterpret_cast<const uint4*>(pa0 + (((mi >> 2) * HY + ((mi >> 1) & 1) * 4 + 2 * (mi & 1)) * HZ) * ROWB); }
+                    else if (i < 16) { const int ni = i - 12; fb[1][ni] = *reinterpret_cast<const uint4*>(pb + ni * 256 + 4 * BN * 16); }
+                    else { const int mi = i - 16; fa[1][mi] = *reinterpret_cast<const uint4*>(pa1 + (((mi >> 2) * HY + ((mi >> 1) & 1) * 4 + 2 * (mi & 1)) * HZ) * ROWB); }
+                };
+                auto mm = [&](int j) {   // MFMA j: k-step j / 32, A tile (j / 4) % 8, B fragment j % 4
+                    const int ks = j >> 5, mi = (j >> 2) & 7, ni = j & 3;
+                    acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, fb[ks][ni]), __builtin_bit_cast(bf16x8, fa[ks][mi]), acc16[mi][ni], 0, 0, 0);
+                };
+                // One code path, three scheduling regions cut by the two DMA issue points (the asm is a scheduling barrier):
+                // MFMA groups 0..2 | waves 0-3 issue | groups 3..8 | waves 4-7 issue | groups 9..15.  Reads keep
+                // the PIPE order (7 up front, then the per-group counts below), split where the regions are cut.
+#pragma unroll
+                for (int i = 0; i < 10; ++i) rd(i);
+#pragma unroll
+                for (int j = 0; j < 12; ++j) mm(j);
+                __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (more && wave < 4) issue_b(g + 1, cur ^ 1);
+#pragma unroll
+                for (int i = 10; i < 20; ++i) rd(i);
+#pragma unroll
+                for (int j = 12; j < 36; ++j) mm(j);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (more && wave >= 4) issue_b(g + 1, cur ^ 1);
+#pragma unroll
+                for (int i = 20; i < 24; ++i) rd(i);
+#pragma unroll
+                for (int j = 36; j < 64; ++j) mm(j);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             } else if constexpr (PIPE) {
                 // Explicit fragment pipeline over the whole tap (24 reads, 64 MFMAs in one scheduling region): the B
                 // fragments of the second k-step and A fragments two groups ahead are in flight while the matrix
@@ -513,8 +695,14 @@ conv3d_k3_kernel(const ConvParams p)
             }
         }
         }
+        if constexpr (SPLITDMA) {
+            if (more && wave < 4) issue_b(g + 1, cur ^ 1);
+        }
+        if constexpr (STAMP) { const unsigned long long t = stamp_now(); st_acc[1] += t - st_t; st_t = t; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA of tap g+1 has landed (this wave's share)
+        if constexpr (STAMP) { const unsigned long long t = stamp_now(); st_acc[2] += t - st_t; st_t = t; }
         __syncthreads();                                  // ... everyone's has; buffer `cur` is free
+        if constexpr (STAMP) { const unsigned long long t = stamp_now(); st_acc[3] += t - st_t; st_t = t; st_acc[5] += 1; }
         cur ^= 1;
         if (++tap == 27) {
             tap = 0;
@@ -524,11 +712,17 @@ conv3d_k3_kernel(const ConvParams p)
                     dma_stage_a(s);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 } else {
-#pragma unroll
-                    for (int it = 0; it < A_ITERS; ++it) store_a(it, load_a(s, it));
+                    MMR_STAGE_A_REGS(s);
                 }
                 __syncthreads();
+                if constexpr (STAMP) { const unsigned long long t = stamp_now(); st_acc[4] += t - st_t; }
             }
+        }
+    }
+    if constexpr (STAMP) {
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) atomicAdd(&g_conv_stamp[wave][k], st_acc[k]);
         }
     }
 
@@ -871,24 +1065,46 @@ int dispatch_conv(const ConvParams& p, hipStream_t st, int64_t* nblk_out = nullp
     static int var = -1;
     if (var < 0) {
         const char* e = getenv("MMR_CONV_VARIANT");
-        var = e ? atoi(e) : 416;
+        var = e ? atoi(e) : 0;   // 0 = the per-tile defaults below
     }
     switch (BN) {
         case 256:
             if (var == 96) return launch_conv<DT, 2, 4, 4, 2, 96>(p, nt, st, nblk_out);
             if (var == 32) return launch_conv<DT, 2, 4, 4, 2, 32>(p, nt, st, nblk_out);    // compiler-scheduled fragments
             if (var == 160) return launch_conv<DT, 2, 4, 4, 2, 160>(p, nt, st, nblk_out);  // + explicit fragment pipeline
-            return launch_conv<DT, 2, 4, 4, 2, 416>(p, nt, st, nblk_out);                  // + A tile by LDS-DMA (default)
+            if (var == 416) return launch_conv<DT, 2, 4, 4, 2, 416>(p, nt, st, nblk_out);  // + A tile by LDS-DMA (round-1 default)
+            if (var == 928) return launch_conv<DT, 2, 4, 4, 2, 928>(p, nt, st, nblk_out);  // + staggered mid-tap weight DMA
+            if (var == 1440) return launch_conv<DT, 2, 4, 4, 2, 1440>(p, nt, st, nblk_out); // 416 + cycle stamps (diagnostic)
+            if (var == 3488) return launch_conv<DT, 2, 4, 4, 2, 3488>(p, nt, st, nblk_out); // 2464 + cycle stamps (diagnostic)
+            return launch_conv<DT, 2, 4, 4, 2, 2464>(p, nt, st, nblk_out);                  // + split weight-DMA placement (default)
         case 128:  // 8x8x8-voxel tiles for the narrow N
             if (var == 32) return launch_conv<DT, 4, 2, 4, 2, 32>(p, nt, st, nblk_out);
             if (DT == MMR_DT_BF16)  // neither the bf16 fragment pipeline nor the DMA staging fit 256 VGPRs at this tile
                 return launch_conv<DT, 4, 2, 4, 2, 32>(p, nt, st, nblk_out);
+            if (var == 2464) return launch_conv<DT, 4, 2, 4, 2, 2464>(p, nt, st, nblk_out);
+            if (var == 4512) return launch_conv<DT, 4, 2, 4, 2, 4512>(p, nt, st, nblk_out);  // 416 + batched branch-free A staging
             return launch_conv<DT, 4, 2, 4, 2, 416>(p, nt, st, nblk_out);
         case 64:
             if (var == 32) return launch_conv<DT, 8, 1, 2, 2, 32>(p, nt, st, nblk_out);
-            return launch_conv<DT, 8, 1, 2, 2, 416>(p, nt, st, nblk_out);
+            if (var == 2464) return launch_conv<DT, 8, 1, 2, 2, 2464>(p, nt, st, nblk_out);
+            if (var == 1440) return launch_conv<DT, 8, 1, 2, 2, 1440>(p, nt, st, nblk_out);
+            if (var == 3488) return launch_conv<DT, 8, 1, 2, 2, 3488>(p, nt, st, nblk_out);
+            if (var == 4512) return launch_conv<DT, 8, 1, 2, 2, 4512>(p, nt, st, nblk_out);  // 416 + batched branch-free A staging
+            if (var == 5536) return launch_conv<DT, 8, 1, 2, 2, 5536>(p, nt, st, nblk_out);  // 4512 + cycle stamps (diagnostic)
+            if (var == 416) return launch_conv<DT, 8, 1, 2, 2, 416>(p, nt, st, nblk_out);    // round-1 default
+            // fp32x3 / x1: batched branch-free A staging (-5 % on the C3 training convs); bf16 / exact fp32 stage A by DMA
+            return launch_conv<DT, 8, 1, 2, 2, 4512>(p, nt, st, nblk_out);
         default: return launch_conv<DT, 8, 1, 2, 1, 256>(p, nt, st, nblk_out);
     }
+}
+
+// Diagnostic: copy out and clear the cycle stamps of the MMR_CONV_VARIANT=1440 build (tools/conv_stamps.py); not in mmr.h.
+extern "C" int mmr_debug_conv_stamps(unsigned long long* out64)
+{
+    unsigned long long z[64] = {0};
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_conv_stamp), sizeof(z)) != hipSuccess) return MMR_EHIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamp), z, sizeof(z)) != hipSuccess) return MMR_EHIP;
+    return MMR_OK;
 }
 
 // ---- first layer: concat(moving, fixed) (2 ch) -> Cout, VALU ------------- //

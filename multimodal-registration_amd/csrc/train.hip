@@ -14,6 +14,8 @@
 //    their volume is small (<= 100 M adds) next to the 1.3 TB/s atomic rate.
 //  * wgrad is an MFMA GEMM over voxels (v_mfma_f32_32x32x2_f32) with
 //    per-workgroup partial slabs reduced in a fixed order (reproducible).
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace mmr {
@@ -878,10 +880,31 @@ __device__ __forceinline__ void split_bf16(float f, unsigned short& hi, unsigned
 constexpr int WX_A_BYTES = W_HROWS * 128;  // 76800
 constexpr int WX_B_BYTES = 256 * 256;      // 65536
 
-template <int COT, bool LO>
+// Diagnostic (MMR_WGRAD_STAMP=1): per wave slot the s_memtime sums over all workgroups of [0] wait at the top-of-tile
+// barrier, [1] hi/lo split + LDS stores + barrier, [2] issue of the next tile's loads, [3] the 16 k-blocks, [4] tiles.
+__device__ unsigned long long g_wgrad_stamp[8][8];
+__device__ __forceinline__ unsigned long long wstamp_now()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
+// PF: which operand tiles of the NEXT voxel tile are prefetched into registers under the k-loop (bit 0: X, 40 VGPRs;
+// bit 1: dZ, 32 VGPRs).  With both (72 VGPRs next to 112 accumulator registers) the kernel spills, and every spill
+// reload between the prefetch loads is a `s_waitcnt vmcnt(0)`: the 13 loads of a tile ran as 13 dependent round trips
+// (16 k of the 45 k cycles per tile, tools/wgrad_stamps.py).
+// FULLCO: Cout is a multiple of 64, every float4 of dZ exists -> one branch-free load path.  (With the tail path compiled
+// into the same kernel behind a wave-uniform branch, hipcc put `s_waitcnt vmcnt(0)` in front of every dZ load at the
+// join of the two paths: 8 more dependent round trips per tile.)
+template <int COT, bool LO, bool STAMP = false, int PF = 3, bool FULLCO = false>
 __global__ void __launch_bounds__(W_THREADS, 2)
 wgrad_x3_kernel(const WgradParams p)
 {
+    constexpr bool PFX = (PF & 1) != 0, PFZ = (PF & 2) != 0;
+    unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st_t = 0;
     constexpr int NU = (COT == 2) ? 7 : 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sX = smem;
@@ -934,32 +957,52 @@ wgrad_x3_kernel(const WgradParams p)
         x0 = txi * W_TX; y0 = tyi * W_TY; z0 = tzi * W_TZ;
     };
     struct XItem { float4 a, b; };
-    auto load_x = [&](int b, int x0, int y0, int z0, int it) -> XItem {
-        const int i = tid + it * W_THREADS;
-        XItem val;
-        val.a = make_float4(0.f, 0.f, 0.f, 0.f);
-        val.b = val.a;
-        if (i < W_HROWS * 4) {
-            const int row = i >> 2, c = i & 3;
-            const int hx = row / (W_HY * W_HZ), hy = (row / W_HZ) % W_HY, hz = row % W_HZ;
-            const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
-            if (gx >= 0 && gx < p.X && gy >= 0 && gy < p.Y && gz >= 0 && gz < p.Z) {
-                size_t vox;
-                if (up) vox = (((size_t)b * X2 + (gx >> 1)) * Y2 + (gy >> 1)) * Z2 + (gz >> 1);
-                else vox = (((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz;
-                const float* qsrc = src + vox * Cs + chs + c * 8;
-                val.a = *reinterpret_cast<const float4*>(qsrc);
-                val.b = *reinterpret_cast<const float4*>(qsrc + 4);
-            }
-        }
+    // Branch-free prefetch: every lane loads from a clamped (always in-bounds) address and the value is zeroed with a
+    // bit mask afterwards.  With `if (in bounds) load` hipcc branches around every load and waits for it before the
+    // next one: the 13 loads of a tile became 13 dependent round trips, 16 k of the 45 k cycles a tile took
+    // (tools/wgrad_stamps.py), all of them with the matrix cores idle.
+    auto mask4 = [](float4 v, unsigned m) -> float4 {
+        return make_float4(__uint_as_float(__float_as_uint(v.x) & m), __uint_as_float(__float_as_uint(v.y) & m),
+                           __uint_as_float(__float_as_uint(v.z) & m), __uint_as_float(__float_as_uint(v.w) & m));
+    };
+    unsigned okbits = 0;   // bit it: item `it` of the prefetched X tile is in bounds; bit 16 + it: the same for dZ
+    // halo coordinates of this thread's X items, packed once: hx | hy << 4 | hz << 8 | valid << 12 (the row -> (hx, hy, hz)
+    // decomposition needs two integer divisions per item; everything derived from it is recomputed per tile, see opaque())
+    int xpk[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int i0 = tid + it * W_THREADS;
+        const int row = (i0 < W_HROWS * 4 ? i0 : W_HROWS * 4 - 1) >> 2;
+        xpk[it] = (row / (W_HY * W_HZ)) | (((row / W_HZ) % W_HY) << 4) | ((row % W_HZ) << 8) | ((i0 < W_HROWS * 4 ? 1 : 0) << 12);
+    }
+    auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
+    auto load_x = [&](int tv, int b, int x0, int y0, int z0, int it) -> XItem {
+        const int pk = opaque(xpk[it]);
+        const int c = tv & 3;
+        const int hx = pk & 15, hy = (pk >> 4) & 15, hz = (pk >> 8) & 15;
+        const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
+        const bool ok = ((pk >> 12) & 1) && gx >= 0 && gx < p.X && gy >= 0 && gy < p.Y && gz >= 0 && gz < p.Z;
+        const int cx = min(max(gx, 0), p.X - 1), cy = min(max(gy, 0), p.Y - 1), cz = min(max(gz, 0), p.Z - 1);
+        size_t vox;
+        if (up) vox = (((size_t)b * X2 + (cx >> 1)) * Y2 + (cy >> 1)) * Z2 + (cz >> 1);
+        else vox = (((size_t)b * p.X + cx) * p.Y + cy) * p.Z + cz;
+        const float* qsrc = src + vox * Cs + chs + c * 8;
+        okbits = ok ? (okbits | (1u << it)) : (okbits & ~(1u << it));
+        XItem val;   // raw: the mask is applied in store_x, AFTER the k-loop -- a use here would make the wave wait for the load
+        val.a = *reinterpret_cast<const float4*>(qsrc);
+        val.b = *reinterpret_cast<const float4*>(qsrc + 4);
         return val;
     };
-    auto store_x = [&](int it, const XItem& v) {
-        const int i = tid + it * W_THREADS;
+    auto store_x = [&](int tv, int it, const XItem& vraw) {
+        const int i = tv + it * W_THREADS;
         if (i < W_HROWS * 4) {
             const int row = i >> 2, c = i & 3;
-            const int hz = row % W_HZ;
+            const int hz = (opaque(xpk[it]) >> 8) & 15;
             const int sw = (hz >> 1) & 1;
+            const unsigned m = ((okbits >> it) & 1u) ? 0xffffffffu : 0u;
+            XItem v;
+            v.a = mask4(vraw.a, m);
+            v.b = mask4(vraw.b, m);
             const float f[8] = {v.a.x, v.a.y, v.a.z, v.a.w, v.b.x, v.b.y, v.b.z, v.b.w};
             unsigned hi[4], lo[4];
 #pragma unroll
@@ -975,14 +1018,22 @@ wgrad_x3_kernel(const WgradParams p)
                 *reinterpret_cast<uint4*>(sX + row * 128 + ((1 ^ sw) << 6) + c * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
         }
     };
-    auto load_z = [&](int b, int x0, int y0, int z0, int it) -> float4 {
-        const int i = tid + it * W_THREADS;
+    auto load_z = [&](int tv, int b, int x0, int y0, int z0, int it) -> float4 {
+        const int i = tv + it * W_THREADS;
         const int v = i >> 4, c4 = i & 15;
         const int gx = x0 + (v >> 6), gy = y0 + ((v >> 3) & 7), gz = z0 + (v & 7);
+        const int co = cob * 64 + c4 * 4;
+        if constexpr (FULLCO) {   // branch-free (see load_x): clamped address, bit mask applied at store time
+            const bool ok = gx < p.X && gy < p.Y && gz < p.Z;
+            const int cx = min(gx, p.X - 1), cy = min(gy, p.Y - 1), cz = min(gz, p.Z - 1);
+            const float* qq = p.dz + ((((size_t)b * p.X + cx) * p.Y + cy) * p.Z + cz) * p.Cout;
+            okbits = ok ? (okbits | (0x10000u << it)) : (okbits & ~(0x10000u << it));
+            return *reinterpret_cast<const float4*>(qq + co);   // raw; masked in store_z
+        } else {
+        okbits |= 0x10000u << it;
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gx < p.X && gy < p.Y && gz < p.Z) {
             const float* qq = p.dz + ((((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz) * p.Cout;
-            const int co = cob * 64 + c4 * 4;
             if (co + 3 < p.Cout) val = *reinterpret_cast<const float4*>(qq + co);
             else {
                 if (co < p.Cout) val.x = qq[co];
@@ -991,9 +1042,11 @@ wgrad_x3_kernel(const WgradParams p)
             }
         }
         return val;
+        }
     };
-    auto store_z = [&](int it, float4 val) {
-        const int i = tid + it * W_THREADS;
+    auto store_z = [&](int tv, int it, float4 vraw) {
+        const float4 val = mask4(vraw, ((okbits >> (16 + it)) & 1u) ? 0xffffffffu : 0u);
+        const int i = tv + it * W_THREADS;
         const int v = i >> 4, c4 = i & 15;
         const int vz = v & 7;
         unsigned short h0, l0, h1, l1, h2, l2, h3, l3;
@@ -1008,31 +1061,63 @@ wgrad_x3_kernel(const WgradParams p)
 
     XItem px[A_IT];
     float4 pz[B_IT];
+    // `opaque_tid()`: the staging index arithmetic (row -> halo coordinates -> clamped address, 13 items per thread) is
+    // invariant across voxel tiles, so hipcc hoists all of it out of the tile loop and keeps it live across the k-loop,
+    // next to 112 accumulator registers: it is what spilled.  An empty asm makes the thread index opaque per use, so
+    // the arithmetic (a few hundred VALU per 45 k-cycle tile) is redone where it is needed and nothing stays live.
+    auto opaque_tid = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t; };
     int tile = blockIdx.x;
     if (tile < p.ntiles) {
+        const int tv = opaque_tid();
         int b, x0, y0, z0;
         tile_origin(tile, b, x0, y0, z0);
+        if constexpr (PFX) {
 #pragma unroll
-        for (int it = 0; it < A_IT; ++it) px[it] = load_x(b, x0, y0, z0, it);
+            for (int it = 0; it < A_IT; ++it) px[it] = load_x(tv, b, x0, y0, z0, it);
+        }
+        if constexpr (PFZ) {
 #pragma unroll
-        for (int it = 0; it < B_IT; ++it) pz[it] = load_z(b, x0, y0, z0, it);
+            for (int it = 0; it < B_IT; ++it) pz[it] = load_z(tv, b, x0, y0, z0, it);
+        }
     }
     for (; tile < p.ntiles; tile += gridDim.x) {
+        if constexpr (STAMP) st_t = wstamp_now();
         __syncthreads();
+        if constexpr (STAMP) { const unsigned long long t = wstamp_now(); st_acc[0] += t - st_t; st_t = t; }
+        const int tv = opaque_tid();
+        if constexpr (!PFX || !PFZ) {   // the operand tile that is not prefetched: all its loads in one batch, then the stores
+            int b, x0, y0, z0;
+            tile_origin(tile, b, x0, y0, z0);
+            if constexpr (!PFX) {
 #pragma unroll
-        for (int it = 0; it < A_IT; ++it) store_x(it, px[it]);
+                for (int it = 0; it < A_IT; ++it) px[it] = load_x(tv, b, x0, y0, z0, it);
+            }
+            if constexpr (!PFZ) {
 #pragma unroll
-        for (int it = 0; it < B_IT; ++it) store_z(it, pz[it]);
+                for (int it = 0; it < B_IT; ++it) pz[it] = load_z(tv, b, x0, y0, z0, it);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) store_x(tv, it, px[it]);
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) store_z(tv, it, pz[it]);
         __syncthreads();
+        if constexpr (STAMP) { const unsigned long long t = wstamp_now(); st_acc[1] += t - st_t; st_t = t; }
         const int nxt = tile + gridDim.x;
         if (nxt < p.ntiles) {
+            const int tv = opaque_tid();
             int b, x0, y0, z0;
             tile_origin(nxt, b, x0, y0, z0);
+            if constexpr (PFX) {
 #pragma unroll
-            for (int it = 0; it < A_IT; ++it) px[it] = load_x(b, x0, y0, z0, it);
+                for (int it = 0; it < A_IT; ++it) px[it] = load_x(tv, b, x0, y0, z0, it);
+            }
+            if constexpr (PFZ) {
 #pragma unroll
-            for (int it = 0; it < B_IT; ++it) pz[it] = load_z(b, x0, y0, z0, it);
+                for (int it = 0; it < B_IT; ++it) pz[it] = load_z(tv, b, x0, y0, z0, it);
+            }
         }
+        if constexpr (STAMP) { const unsigned long long t = wstamp_now(); st_acc[2] += t - st_t; st_t = t; }
         for (int kb = 0; kb < 16; ++kb) {  // 16 voxels per k-block: (vx = kb>>2, vy = (kb&3)*2 + {0,1}, vz = 0..7)
             const char* xa = sX + ((kb >> 2) * (W_HY * W_HZ) + (kb & 3) * 2 * W_HZ) * 128;
             const char* zb = sZ + kb * 16 * 256;
@@ -1057,6 +1142,13 @@ wgrad_x3_kernel(const WgradParams p)
                 MMR_WG(1); MMR_WG(1); MMR_WG(1); MMR_WG(1); MMR_WG(1); MMR_WG(0); MMR_WG(0);
 #undef MMR_WG
             }
+        }
+        if constexpr (STAMP) { const unsigned long long t = wstamp_now(); st_acc[3] += t - st_t; st_acc[4] += 1; }
+    }
+    if constexpr (STAMP) {
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) atomicAdd(&g_wgrad_stamp[wave][k], st_acc[k]);
         }
     }
     float* out = p.slab + (((size_t)blockIdx.x * gridDim.y + slice) * gridDim.z + cob) * (27 * 32 * 64);
@@ -1891,11 +1983,23 @@ static int wgrad_impl(const float* in0, int C0, int up0, const float* in1, int C
         constexpr int LDSX = WX_A_BYTES + WX_B_BYTES;
         static bool attr_x3 = false;
         if (!attr_x3) {
-            const void* ks[4] = {reinterpret_cast<const void*>(wgrad_x3_kernel<2, true>),
-                                 reinterpret_cast<const void*>(wgrad_x3_kernel<1, true>),
-                                 reinterpret_cast<const void*>(wgrad_x3_kernel<2, false>),
-                                 reinterpret_cast<const void*>(wgrad_x3_kernel<1, false>)};
-            for (int i = 0; i < 4; ++i) {
+            const void* ks[] = {reinterpret_cast<const void*>(wgrad_x3_kernel<2, true>),
+                                reinterpret_cast<const void*>(wgrad_x3_kernel<1, true>),
+                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, false>),
+                                reinterpret_cast<const void*>(wgrad_x3_kernel<1, false>),
+                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, true, 3>),
+                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, true, 2>),
+                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, true, 1>),
+                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, true, 0>),
+                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, false, 2>),
+                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, false, 1>),
+                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, false, 0>),
+                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, false, 3, true>),
+                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, false, 2, true>),
+                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, false, 0, true>),
+                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, true, 3, true>),
+                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, false, false, 3, true>)};
+            for (size_t i = 0; i < sizeof(ks) / sizeof(ks[0]); ++i) {
                 hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDSX);
                 if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
             }
@@ -1903,10 +2007,25 @@ static int wgrad_impl(const float* in0, int C0, int up0, const float* in1, int C
         }
         const dim3 g3(gx, nslices, ncob), b3(W_THREADS);
         if (x3 == 1) {
+            static const bool stamp = getenv("MMR_WGRAD_STAMP") != nullptr;   // diagnostic build, tools/wgrad_stamps.py
+            static const int pf = getenv("MMR_WGRAD_PF") ? atoi(getenv("MMR_WGRAD_PF")) : 3;   // A/B knob
+            const bool fullco = (Cout % 64) == 0;
             if (Cout <= 32) hipLaunchKernelGGL((wgrad_x3_kernel<1, true>), g3, b3, LDSX, as_stream(stream), p);
+            else if (fullco && stamp) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, true, 3, true>), g3, b3, LDSX, as_stream(stream), p);
+            else if (fullco && pf == 2) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 2, true>), g3, b3, LDSX, as_stream(stream), p);
+            else if (fullco && pf == 0) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 0, true>), g3, b3, LDSX, as_stream(stream), p);
+            else if (fullco) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 3, true>), g3, b3, LDSX, as_stream(stream), p);
+            else if (stamp && pf == 3) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, true, 3>), g3, b3, LDSX, as_stream(stream), p);
+            else if (stamp && pf == 2) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, true, 2>), g3, b3, LDSX, as_stream(stream), p);
+            else if (stamp && pf == 1) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, true, 1>), g3, b3, LDSX, as_stream(stream), p);
+            else if (stamp) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, true, 0>), g3, b3, LDSX, as_stream(stream), p);
+            else if (pf == 2) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 2>), g3, b3, LDSX, as_stream(stream), p);
+            else if (pf == 1) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 1>), g3, b3, LDSX, as_stream(stream), p);
+            else if (pf == 0) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 0>), g3, b3, LDSX, as_stream(stream), p);
             else hipLaunchKernelGGL((wgrad_x3_kernel<2, true>), g3, b3, LDSX, as_stream(stream), p);
         } else {
             if (Cout <= 32) hipLaunchKernelGGL((wgrad_x3_kernel<1, false>), g3, b3, LDSX, as_stream(stream), p);
+            else if ((Cout % 64) == 0) hipLaunchKernelGGL((wgrad_x3_kernel<2, false, false, 3, true>), g3, b3, LDSX, as_stream(stream), p);
             else hipLaunchKernelGGL((wgrad_x3_kernel<2, false>), g3, b3, LDSX, as_stream(stream), p);
         }
     } else if (Cout <= 32)
@@ -1918,6 +2037,15 @@ static int wgrad_impl(const float* in0, int C0, int up0, const float* in1, int C
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(stream_grid((int64_t)27 * (C0 + C1) * Cout, TB)), dim3(TB), 0,
                        as_stream(stream), (const float*)ws, dw, gx, nslices, ncob, C0 + C1, Cout, accumulate);
     return check_launch();
+}
+
+// Diagnostic: copy out and clear the wgrad cycle stamps (tools/wgrad_stamps.py); not part of mmr.h.
+extern "C" int mmr_debug_wgrad_stamps(unsigned long long* out64)
+{
+    unsigned long long z[64] = {0};
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_wgrad_stamp), sizeof(z)) != hipSuccess) return MMR_EHIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wgrad_stamp), z, sizeof(z)) != hipSuccess) return MMR_EHIP;
+    return MMR_OK;
 }
 
 extern "C" int mmr_conv3d_k3_wgrad_f32(const float* in0, int C0, int up0, const float* in1, int C1, const float* dz,
