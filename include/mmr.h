@@ -95,7 +95,9 @@ int mmr_conv3d_k3_pack(const float* w_keras, void* w_packed, int Cin, int Cout, 
  * in0's channels (= concatenate([upsampled, skip])).  dtype selects element
  * type of in0/in1/w_packed/out (bf16 in, fp32 accumulate, or exact fp32).
  * out_f32 != 0 stores fp32 output even for the bf16 path.
- * pool_out: optional MaxPooling3D(2) of the activated output, fused.       */
+ * pool_out: must be NULL here (MMR_EUNSUPPORTED otherwise).  The pooling pass that costs time is the one after the
+ * FIRST layer, and that one is fused: mmr_conv3d_k3_cin2_fwd.  After the deeper encoder layers the tensors are
+ * 8x .. 512x smaller (0.1 ms in total at 160x160x192 x 256); use mmr_maxpool3d2_fwd.                          */
 int mmr_conv3d_k3_fwd(const void* in0, int C0, int up0, const void* in1, int C1,
                       const void* w_packed, const float* bias, void* out, void* pool_out,
                       int B, int X, int Y, int Z, int Cout,
@@ -108,7 +110,9 @@ int mmr_conv3d_k3_fwd_ws(const void* in0, int C0, int up0, const void* in1, int 
                          const void* w_packed, const float* bias, void* out, void* pool_out,
                          int B, int X, int Y, int Z, int Cout,
                          int leaky, float alpha, int dtype, int out_f32, void* ws, void* stream);
-/* First layer: concatenate([moving, fixed]) (2 x 1 channel, fp32) -> Cout. */
+/* First layer: concatenate([moving, fixed]) (2 x 1 channel, fp32) -> Cout.  pool_out (optional, same element type as
+ * out, [B,X/2,Y/2,Z/2,Cout]): MaxPooling3D(2) of the activated output from the same kernel (bf16 and fp32x3 kernels;
+ * MMR_EUNSUPPORTED with the exact-fp32 kernel).  Saves the 2.5 GB read of a separate pooling pass at C2.        */
 int mmr_conv3d_k3_cin2_fwd(const float* src, const float* trg, const float* w_keras, const float* bias,
                            void* out, void* pool_out, int B, int X, int Y, int Z, int Cout,
                            int leaky, float alpha, int out_dtype, void* stream);

@@ -1185,15 +1185,20 @@ constexpr int M2_THREADS = 256;
 template <bool X3, bool OUT_BF16>
 __global__ void __launch_bounds__(M2_THREADS)
 conv3d_cin2_mfma_kernel(const float* __restrict__ src, const float* __restrict__ trg, const float* __restrict__ w,
-                        const float* __restrict__ bias, void* __restrict__ out, int B, int X, int Y, int Z, int Cout,
-                        int leaky, float alpha, int ntx, int nty, int ntz, int ntiles)
+                        const float* __restrict__ bias, void* __restrict__ out, void* __restrict__ pool, int B, int X, int Y,
+                        int Z, int Cout, int leaky, float alpha, int ntx, int nty, int ntz, int ntiles)
 {
+    // Voxel order of the im2col rows: row v = wave*64 + vt*32 + l  <->  x = 2*(wave >> 1) + vt, y = 4*(wave & 1) + (l >> 3),
+    // z = l & 7.  A wave then owns both x planes of a 2x2x2 pooling window (its two accumulator tiles), the y pair is
+    // lanes l / l ^ 8 and the z pair lanes l / l ^ 1, so the fused MaxPooling3D(2) is two DPP moves per value and no LDS.
+    auto vox_x = [](int v) { return 2 * (v >> 7) + ((v >> 5) & 1); };
+    auto vox_y = [](int v) { return 4 * ((v >> 6) & 1) + ((v >> 3) & 3); };
+    auto vox_z = [](int v) { return v & 7; };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NPL = X3 ? 2 : 1;
     float* s_img = reinterpret_cast<float*>(smem);                 // [600][2]
     float* s_bias = s_img + HROWS * 2;                             // [Cout] (<= 512)
-    char* s_x = smem + HROWS * 8 + 2048;                           // [NPL][256][128 B]
-    char* s_w = s_x + NPL * 256 * 128;                             // [NPL][Cout][128 B]
+    char* s_w = smem + HROWS * 8 + 2048;                           // [NPL][Cout][128 B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
@@ -1206,7 +1211,7 @@ conv3d_cin2_mfma_kernel(const float* __restrict__ src, const float* __restrict__
     const int txi = bid % ntx;
     const int b = bid / ntx;
     const int x0 = txi * TX, y0 = tyi * TY, z0 = tzi * TZ;
-    __syncthreads();  // previous tile done with s_img / s_x
+    __syncthreads();  // previous tile done with s_img
     for (int i = tid; i < HROWS; i += M2_THREADS) {
         const int hx = i / (HY * HZ), hy = (i / HZ) % HY, hz = i % HZ;
         const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
@@ -1240,44 +1245,48 @@ conv3d_cin2_mfma_kernel(const float* __restrict__ src, const float* __restrict__
     }
     }
     __syncthreads();
-    // im2col: row = voxel (x*64 + y*8 + z), k pair kp = tap
-    for (int i = tid; i < 256 * 32; i += M2_THREADS) {
-        const int v = i & 255, kp = i >> 8;
-        float f0 = 0.f, f1 = 0.f;
-        if (kp < 27) {
-            const int vx = v >> 6, vy = (v >> 3) & 7, vz = v & 7;
-            const int r = ((vx + kp / 9) * HY + vy + (kp / 3) % 3) * HZ + vz + kp % 3;
-            f0 = s_img[r * 2];
-            f1 = s_img[r * 2 + 1];
-        }
-        const bf16_t h0 = f32_to_bf16(f0), h1 = f32_to_bf16(f1);
-        const int chunk = kp >> 2, within = (kp & 3) * 4;
-        const int off = v * 128 + ((chunk ^ ((v >> 1) & 7)) << 4) + within;
-        *reinterpret_cast<unsigned*>(s_x + off) = (unsigned)h0 | ((unsigned)h1 << 16);
-        if constexpr (X3) {
-            const bf16_t l0 = f32_to_bf16(f0 - bf16_to_f32(h0)), l1 = f32_to_bf16(f1 - bf16_to_f32(h1));
-            *reinterpret_cast<unsigned*>(s_x + 256 * 128 + off) = (unsigned)l0 | ((unsigned)l1 << 16);
-        }
-    }
-    __syncthreads();
-
-    // this wave's 64 voxels = 2 column tiles; X fragments stay in registers for all cout tiles
+    // X fragments straight from the image patch: for k-step ks a lane holds k = (2 ks + h) * 8 .. + 7 of its voxel, i.e.
+    // taps kp = (2 ks + h) * 4 .. + 3 with both channels -- four 8-byte (moving, fixed) pairs of s_img.  (The first version
+    // materialised the whole 256 x 64 im2col matrix in LDS with 32 scalar read-convert-write rounds per thread per tile;
+    // that pass, not the 64 MFMAs, was what a tile spent its time on besides its 128 KB of output.)
     uint4 xf[NPL][2][4];
 #pragma unroll
-    for (int pl = 0; pl < NPL; ++pl)
+    for (int vt = 0; vt < 2; ++vt) {
+        const int v = wave * 64 + vt * 32 + (lane & 31);
+        const int r0 = (vox_x(v) * HY + vox_y(v)) * HZ + vox_z(v);
 #pragma unroll
-        for (int vt = 0; vt < 2; ++vt) {
-            const int v = wave * 64 + vt * 32 + (lane & 31);
+        for (int ks = 0; ks < 4; ++ks) {
+            unsigned hi[4], lo[4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                xf[pl][vt][ks] = *reinterpret_cast<const uint4*>(s_x + pl * 256 * 128 + v * 128 +
-                                                                 (((2 * ks + h) ^ ((v >> 1) & 7)) << 4));
+            for (int j = 0; j < 4; ++j) {
+                // tap index of this element for the two half-waves (compile-time), its patch offset selected by h
+                constexpr int dummy = 0; (void)dummy;
+                const int kpA = (2 * ks) * 4 + j, kpB = (2 * ks + 1) * 4 + j;
+                const int offA = kpA < 27 ? ((kpA / 9) * HY + (kpA / 3) % 3) * HZ + kpA % 3 : -1;
+                const int offB = kpB < 27 ? ((kpB / 9) * HY + (kpB / 3) % 3) * HZ + kpB % 3 : -1;
+                const int off = h ? offB : offA;
+                float2 f = make_float2(0.f, 0.f);
+                if (offA >= 0 && offB >= 0) f = *reinterpret_cast<const float2*>(s_img + (r0 + off) * 2);
+                else if (offA >= 0 || offB >= 0) {   // only one half-wave has a real tap here (k padding 54..63)
+                    const float2 g = *reinterpret_cast<const float2*>(s_img + (r0 + (off >= 0 ? off : 0)) * 2);
+                    f = off >= 0 ? g : make_float2(0.f, 0.f);
+                }
+                const bf16_t h0 = f32_to_bf16(f.x), h1 = f32_to_bf16(f.y);
+                hi[j] = (unsigned)h0 | ((unsigned)h1 << 16);
+                if constexpr (X3) {
+                    const bf16_t l0 = f32_to_bf16(f.x - bf16_to_f32(h0)), l1 = f32_to_bf16(f.y - bf16_to_f32(h1));
+                    lo[j] = (unsigned)l0 | ((unsigned)l1 << 16);
+                }
+            }
+            xf[0][vt][ks] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            if constexpr (X3) xf[NPL - 1][vt][ks] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
         }
+    }
     int gxv[2], gyv[2], gzv[2];
 #pragma unroll
     for (int vt = 0; vt < 2; ++vt) {
         const int v = wave * 64 + vt * 32 + (lane & 31);
-        gxv[vt] = x0 + (v >> 6); gyv[vt] = y0 + ((v >> 3) & 7); gzv[vt] = z0 + (v & 7);
+        gxv[vt] = x0 + vox_x(v); gyv[vt] = y0 + vox_y(v); gzv[vt] = z0 + vox_z(v);
     }
     for (int n = 0; n < Cout / 32; ++n) {
         f32x16 acc[2];
@@ -1309,11 +1318,9 @@ conv3d_cin2_mfma_kernel(const float* __restrict__ src, const float* __restrict__
             }
         }
         // epilogue: accumulator row = cout n*32 + (r&3) + 8*(r>>2) + 4*h, column = voxel
+        float vals2[2][16];
 #pragma unroll
         for (int vt = 0; vt < 2; ++vt) {
-            const bool ok = gxv[vt] < X && gyv[vt] < Y && gzv[vt] < Z;
-            const size_t obase = ((size_t)b * nvox + ((size_t)gxv[vt] * Y + gyv[vt]) * Z + gzv[vt]) * Cout + n * 32;
-            float vals[16];
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const float4 bq = *reinterpret_cast<const float4*>(s_bias + n * 32 + 8 * gq + 4 * h);
@@ -1322,9 +1329,11 @@ conv3d_cin2_mfma_kernel(const float* __restrict__ src, const float* __restrict__
                 for (int e = 0; e < 4; ++e) {
                     float v = acc[vt][gq * 4 + e] + bb[e];
                     if (leaky && v < 0.f) v *= alpha;
-                    vals[gq * 4 + e] = v;
+                    vals2[vt][gq * 4 + e] = v;
                 }
             }
+        }
+        auto store16 = [&](void* base, size_t obase, const float* vals, bool ok) {
             if constexpr (OUT_BF16) {
                 unsigned pk[4][2];
 #pragma unroll
@@ -1342,19 +1351,43 @@ conv3d_cin2_mfma_kernel(const float* __restrict__ src, const float* __restrict__
                         pk[2 * pr + 1][d] = rsw[1];
                     }
                     if (ok) {
-                        bf16_t* o = reinterpret_cast<bf16_t*>(out) + obase + 16 * pr + 8 * h;
+                        bf16_t* o = reinterpret_cast<bf16_t*>(base) + obase + 16 * pr + 8 * h;
                         *reinterpret_cast<uint4*>(o) = make_uint4(pk[2 * pr][0], pk[2 * pr][1], pk[2 * pr + 1][0], pk[2 * pr + 1][1]);
                     }
                 }
             } else {
                 if (ok) {
-                    float* o = reinterpret_cast<float*>(out) + obase;
+                    float* o = reinterpret_cast<float*>(base) + obase;
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq)
                         *reinterpret_cast<float4*>(o + 8 * gq + 4 * h) =
                             make_float4(vals[gq * 4], vals[gq * 4 + 1], vals[gq * 4 + 2], vals[gq * 4 + 3]);
                 }
             }
+        };
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt) {
+            const bool ok = gxv[vt] < X && gyv[vt] < Y && gzv[vt] < Z;
+            const size_t obase = ((size_t)b * nvox + ((size_t)gxv[vt] * Y + gyv[vt]) * Z + gzv[vt]) * Cout + n * 32;
+            store16(out, obase, vals2[vt], ok);
+        }
+        if (pool) {
+            // MaxPooling3D(2) of the activated output (Keras 'valid': floor on odd sizes): x pair = the two accumulator
+            // tiles, z pair = lane ^ 1 (DPP quad_perm [1,0,3,2]), y pair = lane ^ 8 (DPP row_ror:8); every lane ends up
+            // with the window maximum, the lane with even y and z stores it
+            float pv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float m = fmaxf(vals2[0][r], vals2[1][r]);
+                m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xf, 0xf, true)));
+                m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x128, 0xf, 0xf, true)));
+                pv[r] = m;
+            }
+            const int X2 = X >> 1, Y2 = Y >> 1, Z2 = Z >> 1;
+            const int px = gxv[0] >> 1, py = gyv[0] >> 1, pz = gzv[0] >> 1;   // gxv[0] is the even x of the pair
+            const bool pok = !(lane & 1) && !(lane & 8) && px < X2 && py < Y2 && pz < Z2;
+            const size_t pbase = ((((size_t)b * X2 + px) * Y2 + py) * Z2 + pz) * Cout + n * 32;
+            store16(pool, pbase, pv, pok);
         }
     }
     }  // tile loop
@@ -1540,7 +1573,11 @@ constexpr int MH_TY = 6, MH_TZ = 14, MH_HY = 8, MH_HZ = 16;
 constexpr int MH_ROWS = MH_HY * MH_HZ;  // 128
 constexpr int MH_THREADS = 256;
 
-template <bool X3>
+// NS > 0: Cin = 32 NS known at compile time (bf16 only): ALL A fragments of a plane (NS loads of 16 B per row tile) are
+// issued before the first MFMA, from clamped always-valid addresses, and masked when used.  The generic path (NS = 0)
+// loads one k-step ahead behind `if (row in volume)`, which hipcc turns into a branch and a full wait per load: the
+// 2 x Cin/32 loads of a plane ran as dependent round trips and the kernel streamed 1.8 TB/s of its 2.5 GB input.
+template <bool X3, int NS = 0>
 __global__ void __launch_bounds__(MH_THREADS, 1)
 flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
                        float* __restrict__ out, int B, int X, int Y, int Z, int Cin, int nseg, int seglen, int nty, int ntz,
@@ -1593,11 +1630,13 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
         // this wave's two row tiles = halo y-rows hy = 2 wave + j, lane r16 = halo z
         size_t rowoff[2];
         bool rowok[2];
+        unsigned rowmask[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int gy = y0 + 2 * wave + j - 1, gz = z0 + r16 - 1;
             rowok[j] = gy >= 0 && gy < Y && gz >= 0 && gz < Z;
-            rowoff[j] = rowok[j] ? ((size_t)gy * Z + gz) * Cin * ES + q16 * (X3 ? 32 : 16) : 0;
+            rowmask[j] = rowok[j] ? 0xffffffffu : 0u;
+            rowoff[j] = (rowok[j] ? ((size_t)gy * Z + gz) * Cin * ES : 0) + q16 * (X3 ? 32 : 16);
         }
         const int gyo = y0 + vy, gzo = z0 + vz;
         const bool ook = outthr && gyo < Y && gzo < Z;
@@ -1625,12 +1664,25 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
                         }
                     }
                 };
-                load_raw(0, raw0, raw1);
-                for (int s = 0; s < nsteps; ++s) {
+                uint4 allraw[NS > 0 ? NS : 1][2];
+                if constexpr (NS > 0) {
+#pragma unroll
+                    for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            allraw[s2][j] = *reinterpret_cast<const uint4*>(plane + rowoff[j] + (size_t)s2 * 64);
+                } else {
+                    load_raw(0, raw0, raw1);
+                }
+#pragma unroll
+                for (int s = 0; s < (NS > 0 ? NS : nsteps); ++s) {
                     uint4 ah[2], al[2];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        if constexpr (X3) {
+                        if constexpr (NS > 0) {
+                            ah[j] = make_uint4(allraw[s][j].x & rowmask[j], allraw[s][j].y & rowmask[j], allraw[s][j].z & rowmask[j],
+                                               allraw[s][j].w & rowmask[j]);
+                        } else if constexpr (X3) {
                             const unsigned u[8] = {raw0[j].x, raw0[j].y, raw0[j].z, raw0[j].w, raw1[j].x, raw1[j].y, raw1[j].z, raw1[j].w};
                             unsigned hh[4], ll[4];
 #pragma unroll
@@ -1647,7 +1699,9 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
                             ah[j] = raw0[j];
                         }
                     }
-                    if (s + 1 < nsteps) load_raw(s + 1, raw0, raw1);
+                    if constexpr (NS == 0) {
+                        if (s + 1 < nsteps) load_raw(s + 1, raw0, raw1);
+                    }
 #pragma unroll
                     for (int n = 0; n < 6; ++n) {
                         const int boff = ((4 * s + q16) * 96 + n * 16 + r16) * 16;
@@ -1915,11 +1969,11 @@ extern "C" int mmr_conv3d_k3_dgrad_split(const void* dz, int Cz, const void* w_p
 }
 
 template <bool X3, bool OUT_BF16>
-static int launch_cin2_mfma(const float* src, const float* trg, const float* w, const float* bias, void* out, int B, int X,
-                            int Y, int Z, int Cout, int leaky, float alpha, hipStream_t st)
+static int launch_cin2_mfma(const float* src, const float* trg, const float* w, const float* bias, void* out, void* pool,
+                            int B, int X, int Y, int Z, int Cout, int leaky, float alpha, hipStream_t st)
 {
     const int npl = X3 ? 2 : 1;
-    const int lds = HROWS * 8 + 2048 + npl * 256 * 128 + npl * Cout * 128;
+    const int lds = HROWS * 8 + 2048 + npl * Cout * 128;
     if (lds > 160 * 1024) return MMR_EUNSUPPORTED;
     static bool attr_set = false;
     auto kern = conv3d_cin2_mfma_kernel<X3, OUT_BF16>;
@@ -1933,7 +1987,7 @@ static int launch_cin2_mfma(const float* src, const float* trg, const float* w, 
     const int64_t nt = (int64_t)B * ntx * nty * ntz;
     if (nt > 0x7fffffff) return MMR_EINVAL;
     const int grid = nt < 2048 ? (int)nt : 2048;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(M2_THREADS), lds, st, src, trg, w, bias, out, B, X, Y, Z, Cout,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(M2_THREADS), lds, st, src, trg, w, bias, out, pool, B, X, Y, Z, Cout,
                        leaky, alpha, ntx, nty, ntz, (int)nt);
     return check_launch();
 }
@@ -1943,13 +1997,15 @@ extern "C" int mmr_conv3d_k3_cin2_fwd(const float* src, const float* trg, const 
                                       float alpha, int out_dtype, void* stream)
 {
     if (!src || !trg || !w_keras || !out || B < 1 || X < 1 || Y < 1 || Z < 1 || Cout < 1) return MMR_EINVAL;
-    if (pool_out) return MMR_EUNSUPPORTED;
+    if (pool_out && (X < 2 || Y < 2 || Z < 2)) return MMR_EINVAL;
     hipStream_t st = as_stream(stream);
     // out_dtype: BF16 -> bf16 MFMA, bf16 out; F32X3 -> bf16 hi/lo split MFMA, fp32 out; F32 -> exact fp32 VALU kernel
+    // pool_out (fused MaxPooling3D(2) of the activated output, same element type): the two matrix-core kernels only
     if (Cout % 32 == 0 && Cout <= 512 && out_dtype == MMR_DT_BF16)
-        return launch_cin2_mfma<false, true>(src, trg, w_keras, bias, out, B, X, Y, Z, Cout, leaky, alpha, st);
+        return launch_cin2_mfma<false, true>(src, trg, w_keras, bias, out, pool_out, B, X, Y, Z, Cout, leaky, alpha, st);
     if (Cout % 32 == 0 && Cout <= 320 && out_dtype == MMR_DT_F32X3)
-        return launch_cin2_mfma<true, false>(src, trg, w_keras, bias, out, B, X, Y, Z, Cout, leaky, alpha, st);
+        return launch_cin2_mfma<true, false>(src, trg, w_keras, bias, out, pool_out, B, X, Y, Z, Cout, leaky, alpha, st);
+    if (pool_out) return MMR_EUNSUPPORTED;   // exact-fp32 VALU kernel: use mmr_maxpool3d2_fwd
     if (out_dtype == MMR_DT_F32X3) out_dtype = MMR_DT_F32;
     if (!((Cout <= 256 && 256 % Cout == 0) || Cout % 256 == 0)) return MMR_EINVAL;
     const int ntx = (X + F_TX - 1) / F_TX, nty = (Y + F_TY - 1) / F_TY, ntz = (Z + F_TZ - 1) / F_TZ;
@@ -1981,10 +2037,13 @@ extern "C" int mmr_conv3d_k3_cout3_fwd(const void* in, const float* w_keras, con
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipSuccess;
-        const void* ks[4] = {reinterpret_cast<const void*>(flow_head_kernel<false>), reinterpret_cast<const void*>(flow_head_kernel<true>),
+        const void* ks[7] = {reinterpret_cast<const void*>(flow_head_kernel<false>), reinterpret_cast<const void*>(flow_head_kernel<true>),
                              reinterpret_cast<const void*>(flow_head_march_kernel<false>),
-                             reinterpret_cast<const void*>(flow_head_march_kernel<true>)};
-        for (int i = 0; i < 4 && e == hipSuccess; ++i)
+                             reinterpret_cast<const void*>(flow_head_march_kernel<true>),
+                             reinterpret_cast<const void*>(flow_head_march_kernel<false, 8>),
+                             reinterpret_cast<const void*>(flow_head_march_kernel<false, 4>),
+                             reinterpret_cast<const void*>(flow_head_march_kernel<false, 2>)};
+        for (int i = 0; i < 7 && e == hipSuccess; ++i)
             e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
         attr_set = true;
@@ -2006,6 +2065,15 @@ extern "C" int mmr_conv3d_k3_cout3_fwd(const void* in, const float* w_keras, con
         const int grid = nt < 256 ? (int)nt : 256;
         if (dtype == MMR_DT_F32X3)
             hipLaunchKernelGGL(flow_head_march_kernel<true>, dim3(grid), dim3(MH_THREADS), lds_m, as_stream(stream),
+                               (const char*)in, w_keras, bias, out, B, X, Y, Z, Cin, nseg, seglen, nty, ntz, (int)nt, pbufs);
+        else if (Cin == 256 && !getenv("MMR_FLOW_HEAD_NS0"))
+            hipLaunchKernelGGL((flow_head_march_kernel<false, 8>), dim3(grid), dim3(MH_THREADS), lds_m, as_stream(stream),
+                               (const char*)in, w_keras, bias, out, B, X, Y, Z, Cin, nseg, seglen, nty, ntz, (int)nt, pbufs);
+        else if (Cin == 128 && !getenv("MMR_FLOW_HEAD_NS0"))
+            hipLaunchKernelGGL((flow_head_march_kernel<false, 4>), dim3(grid), dim3(MH_THREADS), lds_m, as_stream(stream),
+                               (const char*)in, w_keras, bias, out, B, X, Y, Z, Cin, nseg, seglen, nty, ntz, (int)nt, pbufs);
+        else if (Cin == 64 && !getenv("MMR_FLOW_HEAD_NS0"))
+            hipLaunchKernelGGL((flow_head_march_kernel<false, 2>), dim3(grid), dim3(MH_THREADS), lds_m, as_stream(stream),
                                (const char*)in, w_keras, bias, out, B, X, Y, Z, Cin, nseg, seglen, nty, ntz, (int)nt, pbufs);
         else
             hipLaunchKernelGGL(flow_head_march_kernel<false>, dim3(grid), dim3(MH_THREADS), lds_m, as_stream(stream),

@@ -341,15 +341,20 @@ class VxmDense:
         """[B,X,Y,Z,1] x2 (f32) -> flow [B,X,Y,Z,3] f32."""
         self._pack()
         w, nlev = self._w, len(self.enc)
-        last = ops.conv3d_k3_cin2(src, trg, w[0], w[1], self.dtype, x3=self.x3)
+        fuse = ops.cin2_pool_supported(int(w[0].shape[-1]), self.dtype, self.x3) and min(src.shape[1:4]) >= 2
+        if fuse:   # MaxPooling3D(2) of the first layer comes out of its own epilogue
+            last, pooled = ops.conv3d_k3_cin2(src, trg, w[0], w[1], self.dtype, x3=self.x3, pool=True)
+        else:
+            last, pooled = ops.conv3d_k3_cin2(src, trg, w[0], w[1], self.dtype, x3=self.x3), None
         skips = [last]
         li = 1
         for _ in range(1, nlev):
-            last = ops.maxpool3d2(last)
+            last = pooled if pooled is not None else ops.maxpool3d2(last)
+            pooled = None
             last = self._conv(li, last)
             skips.append(last)
             li += 1
-        last = ops.maxpool3d2(last)
+        last = pooled if pooled is not None else ops.maxpool3d2(last)
         skip = None
         for _ in range(nlev):
             last = self._conv(li, last, in1=skip, up0=skip is not None)

@@ -254,19 +254,28 @@ def conv3d_k3_dgrad_split(dz, wt_packed, C0, C1, y1=None, dbias1=None, alpha=0.2
     return d0, d1
 
 
-def conv3d_k3_cin2(src, trg, w_keras, bias, out_dtype, leaky=True, alpha=0.2, x3=False):
-    """First U-Net layer on concat([src, trg]) ([B,X,Y,Z,1] each, f32)."""
+def cin2_pool_supported(cout, out_dtype, x3=False):
+    """The fused MaxPooling3D(2) epilogue exists in the two matrix-core first-layer kernels (bf16 out / fp32x3)."""
+    mode = conv_mode(out_dtype, x3)
+    return (mode == BF16 and cout % 32 == 0 and cout <= 512) or (mode == F32X3 and cout % 32 == 0 and cout <= 320)
+
+
+def conv3d_k3_cin2(src, trg, w_keras, bias, out_dtype, leaky=True, alpha=0.2, x3=False, pool=False):
+    """First U-Net layer on concat([src, trg]) ([B,X,Y,Z,1] each, f32).  pool=True also returns MaxPooling3D(2) of the
+    activated output from the same kernel (no separate pass over the full-resolution tensor) -> (out, pooled)."""
     _chk(src, torch.float32, "src")
     _chk(trg, torch.float32, "trg")
     _chk(w_keras, torch.float32, "w_keras")
     B, X, Y, Z = src.shape[:4]
     cout = int(w_keras.shape[-1])
     out = torch.empty((B, X, Y, Z, cout), dtype=out_dtype, device=src.device)
+    pooled = torch.empty((B, X // 2, Y // 2, Z // 2, cout), dtype=out_dtype, device=src.device) if pool else None
     rc = _lib.load().mmr_conv3d_k3_cin2_fwd(src.data_ptr(), trg.data_ptr(), w_keras.data_ptr(),
-                                            bias.data_ptr() if bias is not None else None, out.data_ptr(), None,
+                                            bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                                            pooled.data_ptr() if pool else None,
                                             B, X, Y, Z, cout, int(leaky), float(alpha), conv_mode(out_dtype, x3), _stream())
     _lib.check(rc, "mmr_conv3d_k3_cin2_fwd")
-    return out
+    return (out, pooled) if pool else out
 
 
 def flow_head_supported(cin, dtype, x3=False):

@@ -71,7 +71,11 @@ class SynthMorphTrainer:
         m = self.model
         m._pack()
         w, nlev = m._w, len(m.enc)
-        last = ops.conv3d_k3_cin2(src, trg, w[0], w[1], torch.float32, x3=m.x3)
+        fuse = ops.cin2_pool_supported(int(w[0].shape[-1]), torch.float32, m.x3) and min(src.shape[1:4]) >= 2
+        if fuse:   # the first MaxPooling3D(2) comes out of the first layer's epilogue
+            last, pooled = ops.conv3d_k3_cin2(src, trg, w[0], w[1], torch.float32, x3=m.x3, pool=True)
+        else:
+            last, pooled = ops.conv3d_k3_cin2(src, trg, w[0], w[1], torch.float32, x3=m.x3), None
         tape.append(("conv0", 0, src, trg, last))
         skips = [last]
         li = 1
@@ -90,11 +94,12 @@ class SynthMorphTrainer:
             return y
 
         for _ in range(1, nlev):
-            p = ops.maxpool3d2(last)
+            p = pooled if pooled is not None else ops.maxpool3d2(last)
+            pooled = None
             tape.append(("pool", last, p))
             last = conv(p)
             skips.append(last)
-        p = ops.maxpool3d2(last)
+        p = pooled if pooled is not None else ops.maxpool3d2(last)
         tape.append(("pool", last, p))
         last, skip = p, None
         for _ in range(nlev):

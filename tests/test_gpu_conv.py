@@ -151,3 +151,28 @@ def test_split_k_small_launch_matches_unsplit(dev, mode):
     assert rc == 0
     tol = 1e-2 if mode == "bf16" else 1e-5  # other summation order over K = 3456 (bf16: output rounding on top)
     assert float((y1.float() - ref.float()).abs().max()) <= tol * float(ref.float().abs().max())
+
+
+@pytest.mark.parametrize("shape,Cout,odt", [((8, 8, 16), 64, "bf16"), ((6, 10, 12), 256, "bf16"), ((8, 8, 16), 64, "fp32x3"),
+                                            ((5, 7, 9), 32, "fp32x3"), ((4, 8, 8), 256, "fp32x3")])
+def test_first_layer_fused_maxpool(dev, shape, Cout, odt):
+    """mmr_conv3d_k3_cin2_fwd with pool_out: the full-resolution output is unchanged bit for bit and the pooled output
+    equals MaxPooling3D(2) of it bit for bit (floor on odd sizes, ragged tiles)."""
+    import mmr
+    rng = np.random.default_rng(3)
+    B = 2
+    src = torch.from_numpy(rng.standard_normal((B,) + shape + (1,)).astype(np.float32)).to(dev)
+    trg = torch.from_numpy(rng.standard_normal((B,) + shape + (1,)).astype(np.float32)).to(dev)
+    w = torch.from_numpy((rng.standard_normal((3, 3, 3, 2, Cout)) * 0.3).astype(np.float32)).to(dev)
+    b = torch.from_numpy((rng.standard_normal(Cout) * 0.1).astype(np.float32)).to(dev)
+    tdt = torch.bfloat16 if odt == "bf16" else torch.float32
+    x3 = odt == "fp32x3"
+    assert mmr.ops.cin2_pool_supported(Cout, tdt, x3)
+    plain = mmr.ops.conv3d_k3_cin2(src, trg, w, b, tdt, x3=x3)
+    full, pooled = mmr.ops.conv3d_k3_cin2(src, trg, w, b, tdt, x3=x3, pool=True)
+    assert torch.equal(full, plain)
+    ref = mmr.ops.maxpool3d2(plain)
+    assert pooled.shape == ref.shape == (B, shape[0] // 2, shape[1] // 2, shape[2] // 2, Cout)
+    assert torch.equal(pooled, ref)
+    from oracle import ops_np as O
+    np.testing.assert_array_equal(pooled.float().cpu().numpy(), O.maxpool2(plain.float().cpu().numpy()))
