@@ -140,6 +140,13 @@ __device__ __forceinline__ unsigned lds_addr(const void* p)
 // (hz & 1, swz) takes 16 distinct values -> every tap's fragment read is bank-conflict free with
 // unpadded rows (rocprof before: SQ_LDS_BANK_CONFLICT = 56 % of SQ_LDS_IDX_ACTIVE with 144-B rows).
 __device__ __forceinline__ int swz(int hy, int hz) { return ((hz >> 1) & 3) | ((hy & 1) << 2); }
+// Swizzle of the 16x16x32 kernels.  Their operand lanes are (voxel r16 = 2 y-rows x 8 z, k-chunk q16), so a ds_read_b128
+// lane group {0-3, 12-15, 20-27} holds (y0, z0-3) and (y1, z4-7) at chunk q and (y0, z4-7), (y1, z0-3) at chunk q ^ 1.  Rows
+// are 128 B, i.e. half a 256-B bank row, the half being the parity of hz: per parity the group has 8 cells whose
+// (hz >> 1) & 3 takes every value twice, once under each chunk parity, so chunk ^ (((hz >> 1) & 3) << 1) is a bijection onto
+// the 8 slots.  The 32x32x16 swizzle above was still in use on this path and left 2/3 of the A reads 2-way conflicted
+// (SQ_LDS_BANK_CONFLICT = 31 % of SQ_LDS_IDX_ACTIVE, profiles/r02a_infer_pmc_sq.json).
+__device__ __forceinline__ int swz16(int hz) { return ((hz >> 1) & 3) << 1; }
 
 // MFMA A-row r (= lane & 31) -> voxel y_local*8 + z inside the 4(y) x 8(z) patch of an M-tile, chosen so
 // that the hardware's ds_read_b128 lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} each hold two
@@ -333,7 +340,7 @@ conv3d_k3_kernel(const ConvParams p)
         if (i < A_ITEMS) {
             const int row = X3 ? (i >> 2) : (i >> 3), chunk = X3 ? (i & 3) : (i & 7);
             const int hy = (row / HZ) % HY, hz = row % HZ;
-            const int sz_ = swz(hy, hz);
+            const int sz_ = M16 ? swz16(hz) : swz(hy, hz);
             if constexpr (X3) {
                 const unsigned u[8] = {val.a.x, val.a.y, val.a.z, val.a.w, val.b.x, val.b.y, val.b.z, val.b.w};
                 unsigned hi[4], lo[4];
@@ -392,7 +399,7 @@ conv3d_k3_kernel(const ConvParams p)
                     size_t vox;
                     if (up) vox = (((size_t)b * X2 + (gx >> 1)) * Y2 + (gy >> 1)) * Z2 + (gz >> 1);
                     else vox = (((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz;
-                    q = src + (vox * Cs + chs) * ES + ((cpos ^ swz(hy, hz)) << 4);
+                    q = src + (vox * Cs + chs) * ES + ((cpos ^ (M16 ? swz16(hz) : swz(hy, hz))) << 4);
                 }
                 glds16(q, __builtin_amdgcn_readfirstlane(sA_lds + (it * CONV_THREADS + wave * 64) * 16));
             }
@@ -468,7 +475,7 @@ conv3d_k3_kernel(const ConvParams p)
         const char* bA = sA + tapoff;
         const char* bB = sB + cur * B_BYTES;
         if constexpr (M16) {
-            const int sw16 = swz((r16 >> 3) + dy, (r16 & 7) + dz);
+            const int sw16 = swz16((r16 & 7) + dz);
             if constexpr (X3 && PIPE3) {
                 // fp32x3 / x1 with an explicit fragment pipeline: all B fragments and two A tiles up front, then per A
                 // tile its MFMAs (lo*hi terms first, the dependent accumulations 4 apart) while the A tile two ahead loads

@@ -698,6 +698,7 @@ struct WgradParams {
     float* slab;  // [gridDim.x][nslices][ncob][27][32][64]
     int B, X, Y, Z, C0, C1, up0, Cout;
     int ntx, nty, ntz, ntiles;
+    unsigned bytes_src[2], bytes_dz;   // operand sizes for the buffer-descriptor path (0 = larger than 3.75 GB: plain loads)
 };
 
 // Wave w owns the accumulator tiles (tap = (w >> 1) + 4 j, co-tile = w & 1), j = 0..6 (units 54, 55 of the
@@ -899,7 +900,7 @@ __device__ __forceinline__ unsigned long long wstamp_now()
 // FULLCO: Cout is a multiple of 64, every float4 of dZ exists -> one branch-free load path.  (With the tail path compiled
 // into the same kernel behind a wave-uniform branch, hipcc put `s_waitcnt vmcnt(0)` in front of every dZ load at the
 // join of the two paths: 8 more dependent round trips per tile.)
-template <int COT, bool LO, bool STAMP = false, int PF = 3, bool FULLCO = false>
+template <int COT, bool LO, bool STAMP = false, int PF = 3, bool FULLCO = false, bool BUF = false>
 __global__ void __launch_bounds__(W_THREADS, 2)
 wgrad_x3_kernel(const WgradParams p)
 {
@@ -956,15 +957,17 @@ wgrad_x3_kernel(const WgradParams p)
         b = t / p.ntx;
         x0 = txi * W_TX; y0 = tyi * W_TY; z0 = tzi * W_TZ;
     };
-    struct XItem { float4 a, b; };
+    // prefetched operands stay native 128-bit vectors from the load to the hi/lo split: assembled element-wise (float4 is a
+    // struct) the allocator gave the components of the loop-carried values different registers at the loop header and in
+    // the loop body, and the v_mov copies it put behind the loads to reconcile them waited for every load BEFORE the
+    // k-loop (s_waitcnt vmcnt(7) ... vmcnt(0)): the prefetch hid nothing
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    struct XItem { u32x4_t a, b; };
     // Branch-free prefetch: every lane loads from a clamped (always in-bounds) address and the value is zeroed with a
     // bit mask afterwards.  With `if (in bounds) load` hipcc branches around every load and waits for it before the
     // next one: the 13 loads of a tile became 13 dependent round trips, 16 k of the 45 k cycles a tile took
     // (tools/wgrad_stamps.py), all of them with the matrix cores idle.
-    auto mask4 = [](float4 v, unsigned m) -> float4 {
-        return make_float4(__uint_as_float(__float_as_uint(v.x) & m), __uint_as_float(__float_as_uint(v.y) & m),
-                           __uint_as_float(__float_as_uint(v.z) & m), __uint_as_float(__float_as_uint(v.w) & m));
-    };
+    auto mask4 = [](u32x4_t v, unsigned m) -> u32x4_t { return v & m; };
     unsigned okbits = 0;   // bit it: item `it` of the prefetched X tile is in bounds; bit 16 + it: the same for dZ
     // halo coordinates of this thread's X items, packed once: hx | hy << 4 | hz << 8 | valid << 12 (the row -> (hx, hy, hz)
     // decomposition needs two integer divisions per item; everything derived from it is recomputed per tile, see opaque())
@@ -976,91 +979,139 @@ wgrad_x3_kernel(const WgradParams p)
         xpk[it] = (row / (W_HY * W_HZ)) | (((row / W_HZ) % W_HY) << 4) | ((row % W_HZ) << 8) | ((i0 < W_HROWS * 4 ? 1 : 0) << 12);
     }
     auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
+    // BUF: voxel offset of each X item relative to the tile origin, once per thread (v_mul_lo_u32 runs at a quarter of the
+    // VALU rate and the per-item index chain had six of them: 3.5 k cycles per tile went into issuing 13 loads)
+    int xdelta[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int hx = xpk[it] & 15, hy = (xpk[it] >> 4) & 15, hz = (xpk[it] >> 8) & 15;
+        xdelta[it] = up ? (((hx - 1) >> 1) * Y2 + ((hy - 1) >> 1)) * Z2 + ((hz - 1) >> 1) : ((hx - 1) * p.Y + (hy - 1)) * p.Z + (hz - 1);
+    }
+    // BUF: operands smaller than 3.75 GB are read through buffer descriptors: an out-of-volume halo item gets the
+    // offset 0xF0000000, beyond num_records, and the hardware returns zeros -- no clamping, no masks, 32-bit offsets.
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(src), 0, BUF ? (int)p.bytes_src[first ? 0 : 1] : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dz), 0, BUF ? (int)p.bytes_dz : 0, 0x00020000);
     auto load_x = [&](int tv, int b, int x0, int y0, int z0, int it) -> XItem {
         const int pk = opaque(xpk[it]);
         const int c = tv & 3;
         const int hx = pk & 15, hy = (pk >> 4) & 15, hz = (pk >> 8) & 15;
         const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
         const bool ok = ((pk >> 12) & 1) && gx >= 0 && gx < p.X && gy >= 0 && gy < p.Y && gz >= 0 && gz < p.Z;
-        const int cx = min(max(gx, 0), p.X - 1), cy = min(max(gy, 0), p.Y - 1), cz = min(max(gz, 0), p.Z - 1);
-        size_t vox;
-        if (up) vox = (((size_t)b * X2 + (cx >> 1)) * Y2 + (cy >> 1)) * Z2 + (cz >> 1);
-        else vox = (((size_t)b * p.X + cx) * p.Y + cy) * p.Z + cz;
-        const float* qsrc = src + vox * Cs + chs + c * 8;
-        okbits = ok ? (okbits | (1u << it)) : (okbits & ~(1u << it));
-        XItem val;   // raw: the mask is applied in store_x, AFTER the k-loop -- a use here would make the wave wait for the load
-        val.a = *reinterpret_cast<const float4*>(qsrc);
-        val.b = *reinterpret_cast<const float4*>(qsrc + 4);
+        XItem val;
+        if constexpr (BUF) {
+            // tile origin (wave-uniform, scalar unit) + this item's precomputed delta; x0, y0, z0 are even
+            const int org = up ? ((b * X2 + (x0 >> 1)) * Y2 + (y0 >> 1)) * Z2 + (z0 >> 1) : ((b * p.X + x0) * p.Y + y0) * p.Z + z0;
+            const unsigned vox = (unsigned)(org + opaque(xdelta[it]));
+            const unsigned off = ok ? (vox * (unsigned)Cs + (unsigned)(chs + c * 8)) * 4u : 0xF0000000u;
+            val.a = __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0);
+            val.b = __builtin_amdgcn_raw_buffer_load_b128(rsX, off + 16u, 0, 0);
+            okbits |= 1u << it;   // zeros already delivered by the range check
+        } else {
+            const int cx = min(max(gx, 0), p.X - 1), cy = min(max(gy, 0), p.Y - 1), cz = min(max(gz, 0), p.Z - 1);
+            size_t vox;
+            if (up) vox = (((size_t)b * X2 + (cx >> 1)) * Y2 + (cy >> 1)) * Z2 + (cz >> 1);
+            else vox = (((size_t)b * p.X + cx) * p.Y + cy) * p.Z + cz;
+            const float* qsrc = src + vox * Cs + chs + c * 8;
+            okbits = ok ? (okbits | (1u << it)) : (okbits & ~(1u << it));
+            // raw: the mask is applied in store_x, AFTER the k-loop -- a use here would make the wave wait for the load
+            val.a = *reinterpret_cast<const u32x4_t*>(qsrc);
+            val.b = *reinterpret_cast<const u32x4_t*>(qsrc + 4);
+        }
         return val;
     };
-    auto store_x = [&](int tv, int it, const XItem& vraw) {
+    // fp32 -> (hi, lo) split in registers (convert_*) and the LDS writes (store_*), both after the top-of-tile barrier.
+    // Converting BEFORE the barrier (inside the ~7 k cycles the older half of the workgroup waits there for the younger one)
+    // was measured: the converted values stay live across the barrier, the kernel spills again (52 B) and every spill
+    // reload between the prefetch loads is a vmcnt(0): 2.58 -> 2.71 ms.
+    auto convert_x = [&](int it, const XItem& vraw) -> XItem {   // a = 8 hi halves, b = 8 lo halves (packed pairs)
+        XItem v = vraw;
+        if constexpr (!BUF) {
+            const unsigned m = ((okbits >> it) & 1u) ? 0xffffffffu : 0u;
+            v.a = mask4(vraw.a, m);
+            v.b = mask4(vraw.b, m);
+        }
+        const float f[8] = {__uint_as_float(v.a.x), __uint_as_float(v.a.y), __uint_as_float(v.a.z), __uint_as_float(v.a.w),
+                            __uint_as_float(v.b.x), __uint_as_float(v.b.y), __uint_as_float(v.b.z), __uint_as_float(v.b.w)};
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+            unsigned short h0, l0, h1, l1;
+            split_bf16(f[2 * e2], h0, l0);
+            split_bf16(f[2 * e2 + 1], h1, l1);
+            hi[e2] = (unsigned)h0 | ((unsigned)h1 << 16);
+            lo[e2] = (unsigned)l0 | ((unsigned)l1 << 16);
+        }
+        XItem o;
+        o.a = u32x4_t{hi[0], hi[1], hi[2], hi[3]};
+        o.b = u32x4_t{lo[0], lo[1], lo[2], lo[3]};
+        return o;
+    };
+    auto store_x = [&](int tv, int it, const XItem& v) {          // v = convert_x(...)
         const int i = tv + it * W_THREADS;
         if (i < W_HROWS * 4) {
             const int row = i >> 2, c = i & 3;
             const int hz = (opaque(xpk[it]) >> 8) & 15;
             const int sw = (hz >> 1) & 1;
-            const unsigned m = ((okbits >> it) & 1u) ? 0xffffffffu : 0u;
-            XItem v;
-            v.a = mask4(vraw.a, m);
-            v.b = mask4(vraw.b, m);
-            const float f[8] = {v.a.x, v.a.y, v.a.z, v.a.w, v.b.x, v.b.y, v.b.z, v.b.w};
-            unsigned hi[4], lo[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                unsigned short h0, l0, h1, l1;
-                split_bf16(f[2 * e], h0, l0);
-                split_bf16(f[2 * e + 1], h1, l1);
-                hi[e] = (unsigned)h0 | ((unsigned)h1 << 16);
-                lo[e] = (unsigned)l0 | ((unsigned)l1 << 16);
-            }
-            *reinterpret_cast<uint4*>(sX + row * 128 + ((0 ^ sw) << 6) + c * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-            if constexpr (LO)
-                *reinterpret_cast<uint4*>(sX + row * 128 + ((1 ^ sw) << 6) + c * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            *reinterpret_cast<u32x4_t*>(sX + row * 128 + ((0 ^ sw) << 6) + c * 16) = v.a;
+            if constexpr (LO) *reinterpret_cast<u32x4_t*>(sX + row * 128 + ((1 ^ sw) << 6) + c * 16) = v.b;
         }
     };
-    auto load_z = [&](int tv, int b, int x0, int y0, int z0, int it) -> float4 {
+    auto load_z = [&](int tv, int b, int x0, int y0, int z0, int it) -> u32x4_t {
         const int i = tv + it * W_THREADS;
         const int v = i >> 4, c4 = i & 15;
         const int gx = x0 + (v >> 6), gy = y0 + ((v >> 3) & 7), gz = z0 + (v & 7);
         const int co = cob * 64 + c4 * 4;
-        if constexpr (FULLCO) {   // branch-free (see load_x): clamped address, bit mask applied at store time
+        if constexpr (FULLCO && BUF) {
+            // item `it` = voxel (vx = it >> 1, vy = vy0 + 4 (it & 1), vz): one per-thread base offset, the item part is
+            // wave-uniform and goes into the instruction's scalar offset
+            const int v0 = tv >> 4, vy0 = (v0 >> 3) & 3, vz0 = v0 & 7;
+            const bool ok = (x0 + (it >> 1)) < p.X && (y0 + vy0 + 4 * (it & 1)) < p.Y && (z0 + vz0) < p.Z;
+            const int org = ((b * p.X + x0) * p.Y + y0) * p.Z + z0;
+            const unsigned off0 = ((unsigned)(org + vy0 * p.Z + vz0) * (unsigned)p.Cout + (unsigned)co) * 4u;
+            const int soff = (((it >> 1) * p.Y + 4 * (it & 1)) * p.Z) * p.Cout * 4;
+            okbits |= 0x10000u << it;
+            return __builtin_amdgcn_raw_buffer_load_b128(rsZ, ok ? off0 : 0xF0000000u, soff, 0);
+        } else if constexpr (FULLCO) {   // branch-free (see load_x): clamped address, bit mask applied at store time
             const bool ok = gx < p.X && gy < p.Y && gz < p.Z;
             const int cx = min(gx, p.X - 1), cy = min(gy, p.Y - 1), cz = min(gz, p.Z - 1);
             const float* qq = p.dz + ((((size_t)b * p.X + cx) * p.Y + cy) * p.Z + cz) * p.Cout;
             okbits = ok ? (okbits | (0x10000u << it)) : (okbits & ~(0x10000u << it));
-            return *reinterpret_cast<const float4*>(qq + co);   // raw; masked in store_z
+            return *reinterpret_cast<const u32x4_t*>(qq + co);   // raw; masked in store_z
         } else {
         okbits |= 0x10000u << it;
-        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        u32x4_t val = {0u, 0u, 0u, 0u};
         if (gx < p.X && gy < p.Y && gz < p.Z) {
             const float* qq = p.dz + ((((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz) * p.Cout;
-            if (co + 3 < p.Cout) val = *reinterpret_cast<const float4*>(qq + co);
+            if (co + 3 < p.Cout) val = *reinterpret_cast<const u32x4_t*>(qq + co);
             else {
-                if (co < p.Cout) val.x = qq[co];
-                if (co + 1 < p.Cout) val.y = qq[co + 1];
-                if (co + 2 < p.Cout) val.z = qq[co + 2];
+                if (co < p.Cout) val.x = __float_as_uint(qq[co]);
+                if (co + 1 < p.Cout) val.y = __float_as_uint(qq[co + 1]);
+                if (co + 2 < p.Cout) val.z = __float_as_uint(qq[co + 2]);
             }
         }
         return val;
         }
     };
-    auto store_z = [&](int tv, int it, float4 vraw) {
-        const float4 val = mask4(vraw, ((okbits >> (16 + it)) & 1u) ? 0xffffffffu : 0u);
-        const int i = tv + it * W_THREADS;
-        const int v = i >> 4, c4 = i & 15;
-        const int vz = v & 7;
+    auto convert_z = [&](int it, u32x4_t vraw) -> u32x4_t {       // (x, y) = 4 hi halves, (z, w) = 4 lo halves
+        const u32x4_t vm = (FULLCO && BUF) ? vraw : mask4(vraw, ((okbits >> (16 + it)) & 1u) ? 0xffffffffu : 0u);
         unsigned short h0, l0, h1, l1, h2, l2, h3, l3;
-        split_bf16(val.x, h0, l0); split_bf16(val.y, h1, l1); split_bf16(val.z, h2, l2); split_bf16(val.w, h3, l3);
+        split_bf16(__uint_as_float(vm.x), h0, l0); split_bf16(__uint_as_float(vm.y), h1, l1);
+        split_bf16(__uint_as_float(vm.z), h2, l2); split_bf16(__uint_as_float(vm.w), h3, l3);
+        return u32x4_t{(unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16),
+                       (unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16)};
+    };
+    auto store_z = [&](int tv, int it, u32x4_t v) {               // v = convert_z(...)
+        const int i = tv + it * W_THREADS;
+        const int vv = i >> 4, c4 = i & 15;
+        const int vz = vv & 7;
         const int seg_hi = (0 * 2 + (c4 >> 3)) ^ (vz & 3), seg_lo = (1 * 2 + (c4 >> 3)) ^ (vz & 3);
-        *reinterpret_cast<uint2*>(sZ + v * 256 + (seg_hi << 6) + (c4 & 7) * 8) =
-            make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
-        if constexpr (LO)
-            *reinterpret_cast<uint2*>(sZ + v * 256 + (seg_lo << 6) + (c4 & 7) * 8) =
-                make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
+        *reinterpret_cast<uint2*>(sZ + vv * 256 + (seg_hi << 6) + (c4 & 7) * 8) = make_uint2(v.x, v.y);
+        if constexpr (LO) *reinterpret_cast<uint2*>(sZ + vv * 256 + (seg_lo << 6) + (c4 & 7) * 8) = make_uint2(v.z, v.w);
     };
 
     XItem px[A_IT];
-    float4 pz[B_IT];
+    u32x4_t pz[B_IT];
     // `opaque_tid()`: the staging index arithmetic (row -> halo coordinates -> clamped address, 13 items per thread) is
     // invariant across voxel tiles, so hipcc hoists all of it out of the tile loop and keeps it live across the k-loop,
     // next to 112 accumulator registers: it is what spilled.  An empty asm makes the thread index opaque per use, so
@@ -1098,9 +1149,9 @@ wgrad_x3_kernel(const WgradParams p)
             }
         }
 #pragma unroll
-        for (int it = 0; it < A_IT; ++it) store_x(tv, it, px[it]);
+        for (int it = 0; it < A_IT; ++it) store_x(tv, it, convert_x(it, px[it]));
 #pragma unroll
-        for (int it = 0; it < B_IT; ++it) store_z(tv, it, pz[it]);
+        for (int it = 0; it < B_IT; ++it) store_z(tv, it, convert_z(it, pz[it]));
         __syncthreads();
         if constexpr (STAMP) { const unsigned long long t = wstamp_now(); st_acc[1] += t - st_t; st_t = t; }
         const int nxt = tile + gridDim.x;
@@ -1968,6 +2019,15 @@ static int wgrad_impl(const float* in0, int C0, int up0, const float* in1, int C
     p.B = B; p.X = X; p.Y = Y; p.Z = Z; p.C0 = C0; p.C1 = C1; p.up0 = up0; p.Cout = Cout;
     int nslices, ncob, gx;
     wgrad_geom(B, X, Y, Z, C0 + C1, Cout, p.ntx, p.nty, p.ntz, p.ntiles, nslices, ncob, gx);
+    {
+        const uint64_t nv = (uint64_t)B * X * Y * Z, lim = 0xF0000000ull - 64;
+        const uint64_t b0 = (up0 ? nv / 8 : nv) * (uint64_t)C0 * 4, b1 = nv * (uint64_t)C1 * 4, bz = nv * (uint64_t)Cout * 4;
+        const bool fits = b0 <= lim && b1 <= lim && bz <= lim;
+        p.bytes_src[0] = fits ? (unsigned)b0 : 0;
+        p.bytes_src[1] = fits ? (unsigned)b1 : 0;
+        p.bytes_dz = fits ? (unsigned)bz : 0;
+    }
+    const bool usebuf = p.bytes_dz != 0 && !getenv("MMR_WGRAD_NOBUF");
     constexpr int LDS = W_A_BYTES + W_B_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1998,7 +2058,10 @@ static int wgrad_impl(const float* in0, int C0, int up0, const float* in1, int C
                                 reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, false, 2, true>),
                                 reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, false, 0, true>),
                                 reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, true, 3, true>),
-                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, false, false, 3, true>)};
+                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, false, false, 3, true>),
+                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, false, 3, true, true>),
+                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, true, 3, true, true>),
+                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, false, false, 3, true, true>)};
             for (size_t i = 0; i < sizeof(ks) / sizeof(ks[0]); ++i) {
                 hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDSX);
                 if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
@@ -2011,9 +2074,11 @@ static int wgrad_impl(const float* in0, int C0, int up0, const float* in1, int C
             static const int pf = getenv("MMR_WGRAD_PF") ? atoi(getenv("MMR_WGRAD_PF")) : 3;   // A/B knob
             const bool fullco = (Cout % 64) == 0;
             if (Cout <= 32) hipLaunchKernelGGL((wgrad_x3_kernel<1, true>), g3, b3, LDSX, as_stream(stream), p);
+            else if (fullco && stamp && usebuf) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, true, 3, true, true>), g3, b3, LDSX, as_stream(stream), p);
             else if (fullco && stamp) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, true, 3, true>), g3, b3, LDSX, as_stream(stream), p);
             else if (fullco && pf == 2) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 2, true>), g3, b3, LDSX, as_stream(stream), p);
             else if (fullco && pf == 0) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 0, true>), g3, b3, LDSX, as_stream(stream), p);
+            else if (fullco && usebuf) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 3, true, true>), g3, b3, LDSX, as_stream(stream), p);
             else if (fullco) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 3, true>), g3, b3, LDSX, as_stream(stream), p);
             else if (stamp && pf == 3) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, true, 3>), g3, b3, LDSX, as_stream(stream), p);
             else if (stamp && pf == 2) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, true, 2>), g3, b3, LDSX, as_stream(stream), p);
@@ -2025,6 +2090,7 @@ static int wgrad_impl(const float* in0, int C0, int up0, const float* in1, int C
             else hipLaunchKernelGGL((wgrad_x3_kernel<2, true>), g3, b3, LDSX, as_stream(stream), p);
         } else {
             if (Cout <= 32) hipLaunchKernelGGL((wgrad_x3_kernel<1, false>), g3, b3, LDSX, as_stream(stream), p);
+            else if ((Cout % 64) == 0 && usebuf) hipLaunchKernelGGL((wgrad_x3_kernel<2, false, false, 3, true, true>), g3, b3, LDSX, as_stream(stream), p);
             else if ((Cout % 64) == 0) hipLaunchKernelGGL((wgrad_x3_kernel<2, false, false, 3, true>), g3, b3, LDSX, as_stream(stream), p);
             else hipLaunchKernelGGL((wgrad_x3_kernel<2, false>), g3, b3, LDSX, as_stream(stream), p);
         }

@@ -3,6 +3,8 @@
 
   python profiles/summarize.py stats  <kernel_stats.csv>              -> top kernels table (stdout)
   python profiles/summarize.py pmc    <fetch_counter.csv> <write_counter.csv> <out.json> [kernel-substring]
+  python profiles/summarize.py sq     <counter_collection.csv> <out.json> [kernel-substring]
+  python profiles/summarize.py round  <tag>     (everything tools/profile_round.sh wrote under gpurun_out/<tag>_* -> profiles/)
 
 PMC units and corrections (MI355X_MICROARCH.md section HBM): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950
 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced (16 B/lane) streaming read -> doubled here;
@@ -46,8 +48,95 @@ def pmc(fetch_csv, write_csv, out_json, sub="conv3d_k3_kernel<1, 2, 4, 4, 2>"):
             print(k, json.dumps(v))
 
 
+def sq(counter_csv, out_json, sub=None):
+    """Per kernel: mean of every collected counter per launch, mean launch duration, and the derived figures
+       clock_GHz        = GRBM_GUI_ACTIVE / 8 / duration          (rocprofv3 sums GUI_ACTIVE over the 8 XCDs)
+       mfma_busy_frac   = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)
+       lds_conflict_frac= SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+       wait_frac        = SQ_WAIT_ANY / SQ_WAVE_CYCLES   (waves parked at s_waitcnt / barriers)"""
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    dur = defaultdict(lambda: [0.0, 0])
+    seen = set()
+    for r in csv.DictReader(open(counter_csv)):
+        k = r["Kernel_Name"].split("(")[0]
+        a = acc[k][r["Counter_Name"]]
+        a[0] += float(r["Counter_Value"])
+        a[1] += 1
+        key = (r["Dispatch_Id"], k)
+        if key not in seen:
+            seen.add(key)
+            d = dur[k]
+            d[0] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+            d[1] += 1
+    out = {}
+    for k, cs in acc.items():
+        if sub and sub not in k:
+            continue
+        m = {c: v[0] / v[1] for c, v in cs.items()}
+        e = {"launches": dur[k][1], "avg_launch_us": dur[k][0] / dur[k][1] / 1e3, "counters_per_launch": m}
+        if "GRBM_GUI_ACTIVE" in m and dur[k][0] > 0:
+            cyc = m["GRBM_GUI_ACTIVE"] / 8.0
+            e["clock_GHz"] = cyc / (dur[k][0] / dur[k][1])
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in m:
+                e["mfma_busy_frac"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc)
+        if m.get("SQ_LDS_IDX_ACTIVE"):
+            e["lds_conflict_frac"] = m.get("SQ_LDS_BANK_CONFLICT", 0.0) / m["SQ_LDS_IDX_ACTIVE"]
+        if m.get("SQ_WAVE_CYCLES"):
+            e["wait_frac"] = m.get("SQ_WAIT_ANY", 0.0) / m["SQ_WAVE_CYCLES"]
+        out[k] = e
+    json.dump(out, open(out_json, "w"), indent=1)
+    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["avg_launch_us"] * kv[1]["launches"])[:6]:
+        print(k[-70:], {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items() if a != "counters_per_launch"})
+
+
+def round_(tag):
+    import glob
+    import os
+    import shutil
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    g = lambda pat: sorted(glob.glob(os.path.join(root, "gpurun_out", pat)))
+    head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=root, capture_output=True, text=True).stdout.strip()
+    for wl in ("infer", "train", "ncc"):
+        st = g(f"{tag}_stats_{wl}/*/*kernel_stats.csv")
+        if st:
+            shutil.copy(st[0], os.path.join(here, f"{tag}_{wl}_kernel_stats.csv"))
+        f, w = g(f"{tag}_pmc_{wl}_FETCH_SIZE/*/*counter_collection.csv"), g(f"{tag}_pmc_{wl}_WRITE_SIZE/*/*counter_collection.csv")
+        if f and w:
+            pmc(f[0], w[0], os.path.join(here, f"{tag}_{wl}_pmc_traffic.json"), "conv3d_k3_kernel<1, 2, 4, 4, 2" if wl == "infer" else "")
+        q = g(f"{tag}_pmc_{wl}_SQ/*/*counter_collection.csv")
+        if q:
+            sq(q[0], os.path.join(here, f"{tag}_{wl}_pmc_sq.json"))
+    for name in ("default", "train", "ncc"):
+        b = os.path.join(root, "gpurun_out", f"{tag}_bench_{name}.json")
+        if os.path.exists(b):
+            shutil.copy(b, os.path.join(here, f"{tag}_bench_{name}.json"))
+    # the files bench.py reads `roofline.traffic` from: dominant kernel family -> measured HBM bytes per launch
+    fam = {"infer": ("conv3d_k3_mfma_bf16_bn256", "conv3d_k3_kernel<1, 2, 4, 4, 2"),
+           "train": ("conv3d_k3_mfma_f32x3_bn64", "conv3d_k3_kernel<2, 8, 1, 2, 2"),
+           "ncc": ("ncc_fused_kernel", "ncc_fused_kernel")}
+    for wl, (family, sub) in fam.items():
+        pj = os.path.join(here, f"{tag}_{wl}_pmc_traffic.json")
+        if not os.path.exists(pj):
+            continue
+        d = json.load(open(pj))
+        hit = [(k, v) for k, v in d.items() if sub in k]
+        if hit:
+            k, v = max(hit, key=lambda kv: kv[1]["launches"])
+            json.dump({family: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "kernel": k, "launches": v["launches"],
+                                "git": head, "source": f"profiles/{tag}_{wl}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
+                                "--pmc WRITE_SIZE in separate passes via tools/profile_round.sh; (2*FETCH + WRITE) KiB per "
+                                "launch, fetch doubled per the gfx950 correction)"}},
+                      open(os.path.join(here, f"traffic_{wl}.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "sq":
+        sq(*sys.argv[2:])
+    elif sys.argv[1] == "round":
+        round_(sys.argv[2])
     else:
         pmc(*sys.argv[2:])

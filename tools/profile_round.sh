@@ -1,0 +1,32 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun) from the repo root: every rocprofv3 pass the committed summaries under profiles/
+# come from.  Usage: bash tools/profile_round.sh <tag>   (writes gpurun_out/<tag>_*).  Counters are collected in their
+# own runs (one --pmc set per run, with --kernel-trace only), the program directly after `--` (no wrappers).
+set -o pipefail
+tag=${1:-r02}
+out=gpurun_out
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+step() { echo "[profile_round] $*"; }
+# 1. kernel-trace stats of the exact default bench command (headline line with roofline, cpu_baseline, secondary)
+step "stats: default bench"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats_infer -- python3 bench.py > $out/${tag}_bench_default.json 2> $out/${tag}_bench_default.err || exit 1
+step "stats: train"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats_train -- python3 bench.py --workload train --steps 10 --warmup 3 > $out/${tag}_bench_train.json 2> $out/${tag}_bench_train.err || exit 1
+step "stats: ncc"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats_ncc -- python3 bench.py --workload ncc --steps 20 --warmup 3 > $out/${tag}_bench_ncc.json 2> $out/${tag}_bench_ncc.err || exit 1
+# 2. HBM traffic (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2: separate passes)
+for wl in infer ncc train; do
+  extra="--no-cpu-baseline"; [ $wl = infer ] && extra="--no-cpu-baseline --no-secondary"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    step "pmc $c: $wl"
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${tag}_pmc_${wl}_$c -- python3 bench.py --workload $wl --steps 3 --warmup 1 $extra > /dev/null 2> $out/${tag}_pmc_${wl}_$c.err || exit 1
+  done
+done
+# 3. matrix-core / LDS / clock counters for the inference and training convs
+for wl in infer train; do
+  extra="--no-cpu-baseline"; [ $wl = infer ] && extra="--no-cpu-baseline --no-secondary"
+  step "pmc SQ: $wl"
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/${tag}_pmc_${wl}_SQ -- python3 bench.py --workload $wl --steps 3 --warmup 1 $extra > /dev/null 2> $out/${tag}_pmc_${wl}_SQ.err || exit 1
+done
+step done
