@@ -102,7 +102,9 @@ class MmrError(RuntimeError):
 
 
 def lib_path():
-    return _build.LIB
+    """MMR_LIB=<path> loads a specific prebuilt library instead (development A/B of kernel builds in one gpurun call);
+    the staleness check then does not apply."""
+    return os.environ.get("MMR_LIB") or _build.LIB
 
 
 def load():
@@ -113,7 +115,7 @@ def load():
     if _LIB is not None:
         return _LIB
     path = lib_path()
-    if _build.needs_build():
+    if not os.environ.get("MMR_LIB") and _build.needs_build():
         have_hipcc = os.path.exists(_build.hipcc_path())
         if not os.path.exists(path) or have_hipcc:
             try:

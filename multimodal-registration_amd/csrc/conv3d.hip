@@ -192,6 +192,12 @@ conv3d_k3_kernel(const ConvParams p)
     // fragment reads at once; waves 4-7 keep issuing at the top, now under the older waves' MFMAs.
     constexpr bool SPLITDMA = (PIPE || PIPE3) && !MIDDMA && ((VAR >> 11) & 1);
     constexpr bool BATCHA = (DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) && ((VAR >> 12) & 1);
+    // VAR bit 13 (with bit 11): waves 0-3 issue the weight DMA of BOTH halves after their MFMAs (their own pieces and the
+    // pieces of wave w + 4), waves 4-7 issue none and start every tap with their fragment reads
+    constexpr bool ALLOLD = SPLITDMA && ((VAR >> 13) & 1);
+    // VAR bits 9 + 13: the two mid-stream issue points of MIDDMA, both used by waves 0-3 only (their own pieces at the
+    // first, the pieces of wave w + 4 at the second); waves 4-7 never issue
+    constexpr bool MIDOLD = MIDDMA && ((VAR >> 13) & 1);
     unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = 0;
     static_assert(WM * WN == 8, "8 waves");
     static_assert(TXT == 4 || TXT == 8, "M tile");
@@ -362,12 +368,14 @@ conv3d_k3_kernel(const ConvParams p)
     };
     const unsigned sB_lds = lds_addr(sB);
     const unsigned tid16 = (unsigned)tid * 16u;
-    auto issue_b = [&](int g, int buf) {
+    auto issue_b = [&](int g, int buf, int wv = -1) {   // wv: issue the pieces of wave slot wv (default: this wave's own)
         const char* wt = wtile + (size_t)g * B_BYTES;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(sB_lds + buf * B_BYTES + wave * 1024);
+        const int ws_ = wv < 0 ? wave : wv;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(sB_lds + buf * B_BYTES + ws_ * 1024);
+        const unsigned t16 = (unsigned)((ws_ << 6) | lane) * 16u;
 #pragma unroll
         for (int it = 0; it < B_ITERS; ++it) {
-            if constexpr (MIDDMA || SPLITDMA) glds16_s(wt + it * CONV_THREADS * 16, tid16, dst + it * CONV_THREADS * 16);
+            if constexpr (MIDDMA || SPLITDMA) glds16_s(wt + it * CONV_THREADS * 16, wv < 0 ? tid16 : t16, dst + it * CONV_THREADS * 16);
             else glds16(wt + (it * CONV_THREADS + tid) * 16, dst + it * CONV_THREADS * 16);
         }
         if (B_BYTES < CONV_THREADS * 16) {
@@ -463,7 +471,8 @@ conv3d_k3_kernel(const ConvParams p)
     for (int g = g0; g < g1; ++g) {
         const bool more = g + 1 < g1;
         if constexpr (STAMP) st_t = stamp_now();
-        if constexpr (SPLITDMA) {
+        if constexpr (ALLOLD) {
+        } else if constexpr (SPLITDMA) {
             if (more && wave >= 4) issue_b(g + 1, cur ^ 1);
         } else if constexpr (!MIDDMA) {
             if (more) issue_b(g + 1, cur ^ 1);
@@ -560,33 +569,37 @@ conv3d_k3_kernel(const ConvParams p)
                         __builtin_bit_cast(bf16x8, fb[ks][ni]), __builtin_bit_cast(bf16x8, fa[ks][mi]), acc16[mi][ni], 0, 0, 0);
                 };
                 // One code path, three scheduling regions cut by the two DMA issue points (the asm is a scheduling barrier):
-                // MFMA groups 0..2 | waves 0-3 issue | groups 3..8 | waves 4-7 issue | groups 9..15.  Reads keep
-                // the PIPE order (7 up front, then the per-group counts below), split where the regions are cut.
+                // MFMA groups 0..3 | first issue point | groups 4..9 | second issue point | groups 10..15.  Reads
+                // keep the PIPE order (7 up front, then the per-group counts below), split where the regions are cut.
 #pragma unroll
-                for (int i = 0; i < 10; ++i) rd(i);
+                for (int i = 0; i < 12; ++i) rd(i);
 #pragma unroll
-                for (int j = 0; j < 12; ++j) mm(j);
+                for (int j = 0; j < 16; ++j) mm(j);
                 __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 if (more && wave < 4) issue_b(g + 1, cur ^ 1);
 #pragma unroll
-                for (int i = 10; i < 20; ++i) rd(i);
+                for (int i = 12; i < 21; ++i) rd(i);
 #pragma unroll
-                for (int j = 12; j < 36; ++j) mm(j);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                for (int j = 16; j < 40; ++j) mm(j);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if (more && wave >= 4) issue_b(g + 1, cur ^ 1);
-#pragma unroll
-                for (int i = 20; i < 24; ++i) rd(i);
-#pragma unroll
-                for (int j = 36; j < 64; ++j) mm(j);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if constexpr (MIDOLD) {
+                    if (more && wave < 4) issue_b(g + 1, cur ^ 1, wave + 4);
+                } else {
+                    if (more && wave >= 4) issue_b(g + 1, cur ^ 1);
+                }
+#pragma unroll
+                for (int i = 21; i < 24; ++i) rd(i);
+#pragma unroll
+                for (int j = 40; j < 64; ++j) mm(j);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -703,7 +716,10 @@ conv3d_k3_kernel(const ConvParams p)
         }
         }
         if constexpr (SPLITDMA) {
-            if (more && wave < 4) issue_b(g + 1, cur ^ 1);
+            if (more && wave < 4) {
+                issue_b(g + 1, cur ^ 1);
+                if constexpr (ALLOLD) issue_b(g + 1, cur ^ 1, wave + 4);
+            }
         }
         if constexpr (STAMP) { const unsigned long long t = stamp_now(); st_acc[1] += t - st_t; st_t = t; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA of tap g+1 has landed (this wave's share)
@@ -1081,9 +1097,17 @@ int dispatch_conv(const ConvParams& p, hipStream_t st, int64_t* nblk_out = nullp
             if (var == 160) return launch_conv<DT, 2, 4, 4, 2, 160>(p, nt, st, nblk_out);  // + explicit fragment pipeline
             if (var == 416) return launch_conv<DT, 2, 4, 4, 2, 416>(p, nt, st, nblk_out);  // + A tile by LDS-DMA (round-1 default)
             if (var == 928) return launch_conv<DT, 2, 4, 4, 2, 928>(p, nt, st, nblk_out);  // + staggered mid-tap weight DMA
+            if (var == 2464) return launch_conv<DT, 2, 4, 4, 2, 2464>(p, nt, st, nblk_out); // split weight-DMA placement
             if (var == 1440) return launch_conv<DT, 2, 4, 4, 2, 1440>(p, nt, st, nblk_out); // 416 + cycle stamps (diagnostic)
             if (var == 3488) return launch_conv<DT, 2, 4, 4, 2, 3488>(p, nt, st, nblk_out); // 2464 + cycle stamps (diagnostic)
-            return launch_conv<DT, 2, 4, 4, 2, 2464>(p, nt, st, nblk_out);                  // + split weight-DMA placement (default)
+            if (var == 10656) return launch_conv<DT, 2, 4, 4, 2, 10656>(p, nt, st, nblk_out); // 2464 + all weight DMA by waves 0-3
+            if (var == 11680) return launch_conv<DT, 2, 4, 4, 2, 11680>(p, nt, st, nblk_out); // 10656 + cycle stamps (diagnostic)
+            // default: the weight DMA of the next tap is issued by waves 0-3 only, from two points inside their MFMA stream
+            // (after MFMA groups 4 and 10 of 16: own pieces, then the pieces of wave w + 4); waves 4-7 never issue.
+            // Measured against the alternatives on one box, back to back (ms per C2 pair): all waves at the top of the tap
+            // (round 1) 44.2 | waves 4-7 at the top, 0-3 after their MFMAs 43.7 | waves 0-3 issue everything after their
+            // MFMAs 43.2 | this 42.1-42.7; issue points (2,6) 43.8, (3,9) 43.2, (4,8) 42.4, (5,9) 42.5, (4,10) 42.1
+            return launch_conv<DT, 2, 4, 4, 2, 9120>(p, nt, st, nblk_out);
         case 128:  // 8x8x8-voxel tiles for the narrow N
             if (var == 32) return launch_conv<DT, 4, 2, 4, 2, 32>(p, nt, st, nblk_out);
             if (DT == MMR_DT_BF16)  // neither the bf16 fragment pipeline nor the DMA staging fit 256 VGPRs at this tile
