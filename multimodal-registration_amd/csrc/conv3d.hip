@@ -1098,6 +1098,7 @@ int dispatch_conv(const ConvParams& p, hipStream_t st, int64_t* nblk_out = nullp
             if (var == 416) return launch_conv<DT, 2, 4, 4, 2, 416>(p, nt, st, nblk_out);  // + A tile by LDS-DMA (round-1 default)
             if (var == 928) return launch_conv<DT, 2, 4, 4, 2, 928>(p, nt, st, nblk_out);  // + staggered mid-tap weight DMA
             if (var == 2464) return launch_conv<DT, 2, 4, 4, 2, 2464>(p, nt, st, nblk_out); // split weight-DMA placement
+            if (var == 10144) return launch_conv<DT, 2, 4, 4, 2, 10144>(p, nt, st, nblk_out); // default + cycle stamps (diagnostic)
             if (var == 1440) return launch_conv<DT, 2, 4, 4, 2, 1440>(p, nt, st, nblk_out); // 416 + cycle stamps (diagnostic)
             if (var == 3488) return launch_conv<DT, 2, 4, 4, 2, 3488>(p, nt, st, nblk_out); // 2464 + cycle stamps (diagnostic)
             if (var == 10656) return launch_conv<DT, 2, 4, 4, 2, 10656>(p, nt, st, nblk_out); // 2464 + all weight DMA by waves 0-3
@@ -1672,10 +1673,27 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
         const int gyo = y0 + vy, gzo = z0 + vz;
         const bool ook = outthr && gyo < Y && gzo < Z;
         float a_prev = 0.f, a_cur = 0.f;
+        // NS > 0: the A fragments of plane xp + 1 are loaded while plane xp is multiplied and gathered (native 128-bit vectors,
+        // so that the loop-carried registers get no copies behind the loads).  With one 4-wave workgroup per CU (130 KB of
+        // LDS) nothing else hides the HBM latency: a plane took 12 k cycles for 1.5 k cycles of MFMA.
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+        u32x4_t pre[NS > 0 ? NS : 1][2];
+        auto load_plane = [&](int xq) {
+            const int xc = xq < 0 ? 0 : (xq >= X ? X - 1 : xq);   // planes outside the volume are never used: any valid address
+            const char* pl = in + ((size_t)b * X + xc) * Y * Z * Cin * ES;
+#pragma unroll
+            for (int s2 = 0; s2 < (NS > 0 ? NS : 1); ++s2)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) pre[s2][j] = *reinterpret_cast<const u32x4_t*>(pl + rowoff[j] + (size_t)s2 * 64);
+        };
+        if constexpr (NS > 0) load_plane(xs - 1);
         for (int xp = xs - 1; xp <= xe; ++xp) {
             const int buf = (pbufs == 2) ? ((xp - xs + 1) & 1) : 0;
             float* P = sP + buf * (MH_ROWS * 81);
             const bool inside = xp >= 0 && xp < X;
+            if constexpr (NS > 0) {
+                if (!inside) load_plane(xp + 1);
+            }
             if (inside) {
                 const char* plane = in + ((size_t)b * X + xp) * Y * Z * Cin * ES;
                 f32x4 acc[2][6];
@@ -1695,13 +1713,13 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
                         }
                     }
                 };
-                uint4 allraw[NS > 0 ? NS : 1][2];
+                u32x4_t allraw[NS > 0 ? NS : 1][2];
                 if constexpr (NS > 0) {
 #pragma unroll
                     for (int s2 = 0; s2 < NS; ++s2)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            allraw[s2][j] = *reinterpret_cast<const uint4*>(plane + rowoff[j] + (size_t)s2 * 64);
+                        for (int j = 0; j < 2; ++j) allraw[s2][j] = pre[s2][j] & rowmask[j];
+                    load_plane(xp + 1);
                 } else {
                     load_raw(0, raw0, raw1);
                 }
@@ -1711,8 +1729,7 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         if constexpr (NS > 0) {
-                            ah[j] = make_uint4(allraw[s][j].x & rowmask[j], allraw[s][j].y & rowmask[j], allraw[s][j].z & rowmask[j],
-                                               allraw[s][j].w & rowmask[j]);
+                            ah[j] = make_uint4(allraw[s][j].x, allraw[s][j].y, allraw[s][j].z, allraw[s][j].w);
                         } else if constexpr (X3) {
                             const unsigned u[8] = {raw0[j].x, raw0[j].y, raw0[j].z, raw0[j].w, raw1[j].x, raw1[j].y, raw1[j].z, raw1[j].w};
                             unsigned hh[4], ll[4];
