@@ -71,16 +71,20 @@ def cpu_baseline_infer(enc, dec, full_shape, mov, fix, budget_s=45.0):
         return float(np.median(ts)), ts
 
     def fits(shape):
-        return tuple(min(int(s), int(f)) // 16 * 16 for s, f in zip(shape, full_shape))
-    probe_shape = fits((32, 32, 48))
+        return tuple(max(16, min(int(s), int(f)) // 16 * 16) for s, f in zip(shape, full_shape))
+    # ladder: 1/64 crop as the probe (one warm-up builds the oneDNN primitives, one timed run); the 1/8 crop when the probe
+    # says a run of it stays under ~15 s (work is linear in voxels and larger crops run MORE efficiently, so x8 is an
+    # upper bound), the whole pair when even that is cheap; otherwise the probe crop itself, median of 3
+    probe_shape = fits([s // 4 for s in full_shape])
     t_probe, _ = run(probe_shape, 1, warm=1)
-    ladder = [tuple(full_shape), fits([s // 2 for s in full_shape]), fits([s // 4 for s in full_shape]), probe_shape]
-    sample = probe_shape
-    for shp in ladder:   # work is linear in voxels; small crops run less efficiently, so the estimate is an upper bound
-        if t_probe * np.prod(shp) / np.prod(probe_shape) * 4 <= budget_s:
-            sample = shp
-            break
-    med, ts = (t_probe, [t_probe]) if sample == probe_shape else run(sample, 3, warm=1)
+    eighth = fits([s // 2 for s in full_shape])
+    if t_probe * 64 * 4 <= budget_s:
+        sample = tuple(full_shape)
+    elif t_probe * 8 <= 15.0:
+        sample = eighth
+    else:
+        sample = probe_shape
+    med, ts = run(sample, 3, warm=1 if sample != probe_shape else 0)
     frac = float(np.prod(sample)) / nvox
     one_shape = fits((16, 16, 32))
     torch.set_num_threads(1)

@@ -5,16 +5,20 @@ from .layers import to_device
 
 
 class Dice:
-    """``vxm.losses.Dice().loss(y_true, y_pred)`` -> scalar (Appendix A6)."""
+    """``vxm.losses.Dice().loss(y_true, y_pred)`` -> scalar (Appendix A6).  ``eps_mode`` picks the upstream
+    variant ('divide_no_nan' | 'max_eps'); None = the process-wide setting of ``mmr.semantics``."""
+
+    def __init__(self, eps_mode=None):
+        self.eps_mode = eps_mode
 
     def loss(self, y_true, y_pred):
-        return ops.dice_loss(to_device(y_true), to_device(y_pred))
+        return ops.dice_loss(to_device(y_true), to_device(y_pred), eps_mode=self.eps_mode)
 
     def grad(self, y_true, y_pred, scale=1.0):
         """d loss / d y_pred, [B,*S,L]."""
         t = to_device(y_true)
-        _, tb = ops.dice_loss(t, to_device(y_pred), return_parts=True)
-        return ops.dice_loss_bwd(t, tb, scale)
+        _, tb = ops.dice_loss(t, to_device(y_pred), return_parts=True, eps_mode=self.eps_mode)
+        return ops.dice_loss_bwd(t, tb, scale, eps_mode=self.eps_mode)
 
 
 class Grad:
@@ -34,18 +38,21 @@ class Grad:
 
 
 class NCC:
-    """``vxm.losses.NCC(win).loss(I, J)`` -> [B]; cc = cross^2/(I_var*J_var+eps) (Appendix A8)."""
+    """``vxm.losses.NCC(win).loss(I, J)`` -> [B]; cc = cross^2/(I_var*J_var+eps) (Appendix A8).  ``form``
+    picks the upstream variant ('classic' | 'clamped'); None = the process-wide setting of ``mmr.semantics``."""
 
-    def __init__(self, win=None, eps=1e-5):
+    def __init__(self, win=None, eps=1e-5, form=None):
         self.win = 9 if win is None else int(win if not isinstance(win, (list, tuple)) else win[0])
         self.eps = eps
+        self.form = form
 
     def loss(self, y_true, y_pred):
-        return ops.ncc_loss(to_device(y_true), to_device(y_pred), self.win, self.eps)
+        return ops.ncc_loss(to_device(y_true), to_device(y_pred), self.win, self.eps, form=self.form)
 
     def grad(self, y_true, y_pred, gout=None):
         """d loss / d y_pred (the moved image), [B,*S,1]."""
-        return ops.ncc_loss_bwd(to_device(y_true), to_device(y_pred), gout, self.win, self.eps, want=("J",))[1]
+        return ops.ncc_loss_bwd(to_device(y_true), to_device(y_pred), gout, self.win, self.eps, want=("J",),
+                                form=self.form)[1]
 
 
 class BendingEnergy:

@@ -42,8 +42,9 @@ def compose(transforms, interp_method="linear", shift_center=True, indexing="ij"
     return _ret(curr[0], numpy_in)
 
 
-def rescale_dense_transform(transform, factor, interp_method="linear"):
-    """``vxm.utils.rescale_dense_transform``; batched iff rank > ndims + 1 (Appendix A4)."""
+def rescale_dense_transform(transform, factor, interp_method="linear", grid=None):
+    """``vxm.utils.rescale_dense_transform``; batched iff rank > ndims + 1 (Appendix A4).  ``grid`` picks the
+    upstream resize grid ('align_corners' | 'arange_over_f'); None = the setting of ``mmr.semantics``."""
     if interp_method != "linear":
         raise ValueError("rescale_dense_transform supports interp_method='linear' only")
     numpy_in = not isinstance(transform, torch.Tensor)
@@ -51,7 +52,7 @@ def rescale_dense_transform(transform, factor, interp_method="linear"):
     batched = t.dim() > t.shape[-1] + 1
     if not batched:
         t = t[None].contiguous()
-    out = ops.rescale_transform(t, factor)
+    out = ops.rescale_transform(t, factor, grid=grid)
     if not batched:
         out = out[0]
     return _ret(out, numpy_in)
