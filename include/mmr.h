@@ -233,6 +233,10 @@ int mmr_conv3d_k3_wgrad_f32x1(const float* in0, int C0, int up0, const float* in
 int64_t mmr_conv3d_k3_cin2_wgrad_ws_bytes(int Cout);
 int mmr_conv3d_k3_cin2_wgrad_f32(const float* src, const float* trg, const float* dz, float* dw, void* ws,
                                  int B, int X, int Y, int Z, int Cout, int accumulate, void* stream);
+/* same contract, bf16 hi/lo split products (pairs with MMR_DT_F32X3); widths that are not a multiple of 64 take the
+ * exact path */
+int mmr_conv3d_k3_cin2_wgrad_f32x3(const float* src, const float* trg, const float* dz, float* dw, void* ws,
+                                   int B, int X, int Y, int Z, int Cout, int accumulate, void* stream);
 /* flow head (Cout = 3) input gradient */
 int mmr_conv3d_k3_cout3_dgrad_f32(const float* dy, const float* w_keras, float* dx, int B, int X, int Y, int Z, int Cin,
                                   void* stream);

@@ -88,6 +88,7 @@ SIGNATURES = {
     "mmr_conv3d_k3_wgrad_f32x1": (I, [P, I, I, P, I, P, P, P, I, I, I, I, I, I, P]),
     "mmr_conv3d_k3_cin2_wgrad_ws_bytes": (c_int64, [I]),
     "mmr_conv3d_k3_cin2_wgrad_f32": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
+    "mmr_conv3d_k3_cin2_wgrad_f32x3": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
     "mmr_conv3d_k3_cout3_dgrad_f32": (I, [P, P, P, I, I, I, I, I, P]),
     "mmr_adam_step_f32": (I, [P, P, P, P, c_int64, F, F, F, F, c_int64, F, P]),
     "mmr_jacobian_det_f64": (I, [P, P, I, I, I, P]),

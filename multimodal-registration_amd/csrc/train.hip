@@ -1563,6 +1563,239 @@ smallch_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------- //
+// The same thin-layer weight gradient on the bf16 cores (fp32x3)              //
+// ------------------------------------------------------------------------- //
+// Same GEMM and the same partial layout as smallch_wgrad_kernel (T[d][g] = sum_v Dn[v][d] * G[v][g]), every product as
+// three v_mfma_f32_32x32x16_bf16 of bf16 (hi, lo) halves.  The contraction runs over voxels, so both operands need 8
+// consecutive voxels per lane: a k-step is two z-rows of 8 voxels and LDS holds, per operand, 16-byte cells of 8
+// z-consecutive bf16 -- one ds_read_b128 per fragment, no transposing read:
+//   sD [hi|lo][d = 64][z-row = 16] cells (+16 B per d: lanes = consecutive d, conflict-free)
+//   sS [hi|lo][c][dz = 3][haloed (x, y) row = 40] cells: the z window of every tap shift is stored as its own
+//      aligned cell, so the gather G[v][tap, c] = S[v +- off(tap)][c] is a lane-constant offset + the row.
+// Tile = 2 x 8 x 8 voxels (16 z-rows = 8 k-steps, two per wave); the next tile's dense operand (8 x 16 B per thread)
+// and S rows are prefetched into registers under the MFMAs; fp32 -> (hi, lo) happens on the way into LDS.  The
+// wave partials are summed in a fixed order through LDS: one [64][96] partial per workgroup.
+constexpr int TW_TX = 2, TW_TY = 8, TW_TZ = 8;
+constexpr int TW_HX = TW_TX + 2, TW_HY = TW_TY + 2;
+constexpr int TW_DSTR = 16 * 16 + 16;                 // bytes per dense channel
+constexpr int TW_DHL = 64 * TW_DSTR;                  // hi -> lo plane
+constexpr int TW_D_BYTES = 2 * TW_DHL;                // 34,816
+constexpr int TW_SPL = TW_HX * TW_HY * 16 + 16;       // bytes per (c, dz) plane of S
+constexpr int TW_SHL = 9 * TW_SPL;                    // hi -> lo plane (Cs <= 3)
+constexpr int TW_S_BYTES = 2 * TW_SHL;                // 11,808
+constexpr int TW_LDS = TW_D_BYTES + TW_S_BYTES;
+
+typedef __attribute__((ext_vector_type(4))) unsigned tw_u32x4;
+typedef __attribute__((ext_vector_type(2))) float tw_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 tw_bf16x2;
+
+// (a, b) -> packed bf16 (hi(a) | hi(b) << 16) and the packed bf16 of the remainders
+__device__ __forceinline__ void tw_split_pair(float a, float b, unsigned& hi, unsigned& lo)
+{
+    const tw_f32x2 v = {a, b};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, tw_bf16x2));
+    const tw_f32x2 r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, tw_bf16x2));
+}
+
+__global__ void __launch_bounds__(SM_THREADS, 2)
+thin_wgrad_x3_kernel(const float* __restrict__ dense, int Cd, const float* __restrict__ s0, const float* __restrict__ s1,
+                     int Cs, int sign, float* __restrict__ part, int B, int X, int Y, int Z, int ntx, int nty, int ntz,
+                     int ntiles)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sD = smem;
+    char* sS = smem + TW_D_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, li = lane & 31;
+    const int cb = blockIdx.y;
+    const int KG = 27 * Cs;
+    // lane-constant fragment offsets
+    int aoff[2], boff[3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) aoff[m] = (m * 32 + li) * TW_DSTR;
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        const int g = n * 32 + li;
+        int o = 0;
+        if (g < KG) {
+            const int tap = g / Cs, c = g - tap * Cs;
+            const int ox = sign * (tap / 9 - 1), oy = sign * ((tap / 3) % 3 - 1), oz = sign * (tap % 3 - 1);
+            o = (c * 3 + oz + 1) * TW_SPL + ((ox + 1) * TW_HY + (oy + 1)) * 16;
+        }
+        boff[n] = o;
+    }
+    // staging roles: dense = (z-row tid >> 4, channel quad tid & 15) x 8 z;  S = (haloed (x, y) row, channel) x 10 z
+    const int drow = tid >> 4, dc4 = tid & 15;
+    const int nS = TW_HX * TW_HY * Cs;
+    const bool s_on = tid < nS;
+    const int sc = s_on ? tid / (TW_HX * TW_HY) : 0;
+    const int shxy = s_on ? tid - sc * (TW_HX * TW_HY) : 0;
+    const float* sbase = s1 ? (sc ? s1 : s0) : s0 + sc;
+    const int sstr = s1 ? 1 : Cs;
+    const size_t nvox = (size_t)X * Y * Z;
+
+    tw_u32x4 dpf[8];
+    float spf[10];
+    unsigned dmask = 0, smask = 0;
+    auto issue = [&](int tile) {
+        int t = tile;
+        const int tzi = t % ntz; t /= ntz;
+        const int tyi = t % nty; t /= nty;
+        const int txi = t % ntx;
+        const int b = t / ntx;
+        const int x0 = txi * TW_TX, y0 = tyi * TW_TY, z0 = tzi * TW_TZ;
+        {
+            const int gx = x0 + (drow >> 3), gy = y0 + (drow & 7);
+            const bool okr = gx < X && gy < Y;
+            const float* p = dense + ((size_t)b * nvox + ((size_t)min(gx, X - 1) * Y + min(gy, Y - 1)) * Z) * Cd + cb * 64 +
+                             dc4 * 4;
+            unsigned mk = 0;
+#pragma unroll
+            for (int z = 0; z < 8; ++z) {
+                const int gz = z0 + z;
+                mk |= (okr && gz < Z) ? (1u << z) : 0u;
+                dpf[z] = *reinterpret_cast<const tw_u32x4*>(p + (size_t)min(gz, Z - 1) * Cd);
+            }
+            dmask = mk;
+        }
+        if (s_on) {
+            const int gx = x0 + shxy / TW_HY - 1, gy = y0 + shxy % TW_HY - 1;
+            const bool okr = gx >= 0 && gx < X && gy >= 0 && gy < Y;
+            const float* p = sbase + ((size_t)b * nvox + ((size_t)min(max(gx, 0), X - 1) * Y + min(max(gy, 0), Y - 1)) * Z) * sstr;
+            unsigned mk = 0;
+#pragma unroll
+            for (int hz = 0; hz < 10; ++hz) {
+                const int gz = z0 + hz - 1;
+                mk |= (okr && gz >= 0 && gz < Z) ? (1u << hz) : 0u;
+                spf[hz] = p[(size_t)min(max(gz, 0), Z - 1) * sstr];
+            }
+            smask = mk;
+        }
+    };
+
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        // fp32 -> packed (hi, lo) cells in registers
+        tw_u32x4 dh[4], dl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float a = (dmask >> (2 * q)) & 1 ? __uint_as_float(dpf[2 * q][j]) : 0.f;
+                const float b2 = (dmask >> (2 * q + 1)) & 1 ? __uint_as_float(dpf[2 * q + 1][j]) : 0.f;
+                unsigned hi, lo;
+                tw_split_pair(a, b2, hi, lo);
+                dh[j][q] = hi; dl[j][q] = lo;
+            }
+        unsigned se_h[5], se_l[5], so_h[4], so_l[4];   // pairs (2q, 2q+1) and (2q+1, 2q+2) of the 10 z values
+        {
+            float v[10];
+#pragma unroll
+            for (int hz = 0; hz < 10; ++hz) v[hz] = (smask >> hz) & 1 ? spf[hz] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) tw_split_pair(v[2 * q], v[2 * q + 1], se_h[q], se_l[q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                so_h[q] = (se_h[q] >> 16) | (se_h[q + 1] << 16);
+                so_l[q] = (se_l[q] >> 16) | (se_l[q + 1] << 16);
+            }
+        }
+        __syncthreads();   // every wave has finished the previous tile's fragments
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            char* o = sD + (dc4 * 4 + j) * TW_DSTR + drow * 16;
+            *reinterpret_cast<tw_u32x4*>(o) = dh[j];
+            *reinterpret_cast<tw_u32x4*>(o + TW_DHL) = dl[j];
+        }
+        if (s_on) {
+            char* o = sS + sc * 3 * TW_SPL + shxy * 16;
+            const tw_u32x4 w0h = {se_h[0], se_h[1], se_h[2], se_h[3]}, w0l = {se_l[0], se_l[1], se_l[2], se_l[3]};
+            const tw_u32x4 w1h = {so_h[0], so_h[1], so_h[2], so_h[3]}, w1l = {so_l[0], so_l[1], so_l[2], so_l[3]};
+            const tw_u32x4 w2h = {se_h[1], se_h[2], se_h[3], se_h[4]}, w2l = {se_l[1], se_l[2], se_l[3], se_l[4]};
+            *reinterpret_cast<tw_u32x4*>(o) = w0h;               *reinterpret_cast<tw_u32x4*>(o + TW_SHL) = w0l;
+            *reinterpret_cast<tw_u32x4*>(o + TW_SPL) = w1h;      *reinterpret_cast<tw_u32x4*>(o + TW_SPL + TW_SHL) = w1l;
+            *reinterpret_cast<tw_u32x4*>(o + 2 * TW_SPL) = w2h;  *reinterpret_cast<tw_u32x4*>(o + 2 * TW_SPL + TW_SHL) = w2l;
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int row = wave * 4 + e * 2 + h;
+            const char* ap = sD + row * 16;
+            const char* bp = sS + ((row >> 3) * TW_HY + (row & 7)) * 16;
+            bf16x8_t ah[2], al[2], bh[3], bl[3];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                ah[m] = *reinterpret_cast<const bf16x8_t*>(ap + aoff[m]);
+                al[m] = *reinterpret_cast<const bf16x8_t*>(ap + aoff[m] + TW_DHL);
+            }
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                bh[n] = *reinterpret_cast<const bf16x8_t*>(bp + boff[n]);
+                bl[n] = *reinterpret_cast<const bf16x8_t*>(bp + boff[n] + TW_SHL);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 3; ++n) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+                }
+        }
+    }
+    // ordered sum of the four wave partials through LDS, one partial per workgroup
+    float* red = reinterpret_cast<float*>(smem);   // [64][96]
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 3; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int d = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        float* o = red + d * 96 + n * 32 + li;
+                        *o = (w == 0) ? acc[m][n][r] : *o + acc[m][n][r];
+                    }
+        }
+    }
+    __syncthreads();
+    float* o = part + ((size_t)blockIdx.x * gridDim.y + cb) * (64 * 96);
+    for (int i = tid; i < 64 * 96; i += SM_THREADS) o[i] = red[i];
+}
+
+static int launch_thin_wgrad_x3(const float* dense, int Cd, const float* s0, const float* s1, int Cs, int sign, float* dw,
+                                void* ws, int B, int X, int Y, int Z, int mode, int accumulate, void* stream)
+{
+    const int ntx = (X + TW_TX - 1) / TW_TX, nty = (Y + TW_TY - 1) / TW_TY, ntz = (Z + TW_TZ - 1) / TW_TZ;
+    const int ntiles = B * ntx * nty * ntz;
+    const int ncb = Cd / 64;
+    int gx = 512 / ncb;
+    if (gx > ntiles) gx = ntiles;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(thin_wgrad_x3_kernel, dim3(gx, ncb), dim3(SM_THREADS), TW_LDS, as_stream(stream), dense, Cd, s0, s1,
+                       Cs, sign, (float*)ws, B, X, Y, Z, ntx, nty, ntz, ntiles);
+    int rc = check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(smallch_wgrad_reduce_kernel, dim3(Cd * 27 * Cs), dim3(64), 0, as_stream(stream), (const float*)ws, dw,
+                       gx, ncb, Cd, Cs, mode, accumulate);
+    return check_launch();
+}
+
 // flow-head dgrad: dX[v][ci] = sum_g G[v][g] * Wr[g][ci], g = tap*3 + co, G[v][g] = dY[v - off(tap)][co]
 // (M = 256 voxels per block, N = 64 input channels per blockIdx.y, K = 81 padded to 82)
 __global__ void __launch_bounds__(SM_THREADS, 2)
@@ -1992,6 +2225,8 @@ static int wgrad_impl(const float* in0, int C0, int up0, const float* in1, int C
         return MMR_EINVAL;
     if (up0 && ((X | Y | Z) & 1)) return MMR_EINVAL;
     if (Cout == 3 && C1 == 0 && !up0 && C0 % 64 == 0) {  // flow head: taps folded into the GEMM N axis (81 of 96 used)
+        if (x3 == 1 && !getenv("MMR_THIN_WGRAD_F32"))
+            return launch_thin_wgrad_x3(in0, C0, dz, nullptr, 3, -1, dw, ws, B, X, Y, Z, 0, accumulate, stream);
         const int ntx = (X + W_TX - 1) / W_TX, nty = (Y + W_TY - 1) / W_TY, ntz = (Z + W_TZ - 1) / W_TZ;
         const int ntiles = B * ntx * nty * ntz;
         const int ncb = C0 / 64;
@@ -2144,10 +2379,12 @@ extern "C" int64_t mmr_conv3d_k3_cin2_wgrad_ws_bytes(int Cout)
     return a > b ? a : b;
 }
 
-extern "C" int mmr_conv3d_k3_cin2_wgrad_f32(const float* src, const float* trg, const float* dz, float* dw, void* ws,
-                                            int B, int X, int Y, int Z, int Cout, int accumulate, void* stream)
+static int cin2_wgrad_impl(const float* src, const float* trg, const float* dz, float* dw, void* ws, int B, int X, int Y,
+                           int Z, int Cout, int accumulate, int x3, void* stream)
 {
     if (!src || !trg || !dz || !dw || !ws || B < 1 || X < 1 || Y < 1 || Z < 1) return MMR_EINVAL;
+    if (Cout % 64 == 0 && x3 && !getenv("MMR_THIN_WGRAD_F32"))
+        return launch_thin_wgrad_x3(dz, Cout, src, trg, 2, +1, dw, ws, B, X, Y, Z, 1, accumulate, stream);
     if (Cout % 64 == 0) {  // fp32 matrix cores: T[co][tap*2 + ci] = sum_v dZ[v][co] * img_ci[v + off(tap)]
         const int ntx = (X + W_TX - 1) / W_TX, nty = (Y + W_TY - 1) / W_TY, ntz = (Z + W_TZ - 1) / W_TZ;
         const int ntiles = B * ntx * nty * ntz;
@@ -2182,6 +2419,19 @@ extern "C" int mmr_conv3d_k3_cin2_wgrad_f32(const float* src, const float* trg, 
     hipLaunchKernelGGL(sum_partials_kernel, dim3(stream_grid(54 * Cout, TB)), dim3(TB), 0, as_stream(stream),
                        (const float*)ws, dw, (int64_t)54 * Cout, nblk, accumulate);
     return check_launch();
+}
+
+extern "C" int mmr_conv3d_k3_cin2_wgrad_f32(const float* src, const float* trg, const float* dz, float* dw, void* ws,
+                                            int B, int X, int Y, int Z, int Cout, int accumulate, void* stream)
+{
+    return cin2_wgrad_impl(src, trg, dz, dw, ws, B, X, Y, Z, Cout, accumulate, 0, stream);
+}
+
+// same contract; products as bf16 hi/lo splits on the bf16 MFMA (Cout % 64 == 0; other widths use the exact path)
+extern "C" int mmr_conv3d_k3_cin2_wgrad_f32x3(const float* src, const float* trg, const float* dz, float* dw, void* ws,
+                                              int B, int X, int Y, int Z, int Cout, int accumulate, void* stream)
+{
+    return cin2_wgrad_impl(src, trg, dz, dw, ws, B, X, Y, Z, Cout, accumulate, 1, stream);
 }
 
 extern "C" int mmr_conv3d_k3_cout3_dgrad_f32(const float* dy, const float* w_keras, float* dx, int B, int X, int Y,

@@ -725,11 +725,12 @@ def conv3d_k3_wgrad(in0, dz, dw, in1=None, up0=False, accumulate=False, x3=False
     return dw
 
 
-def conv3d_k3_cin2_wgrad(src, trg, dz, dw, accumulate=False):
+def conv3d_k3_cin2_wgrad(src, trg, dz, dw, accumulate=False, x3=False):
     B, X, Y, Z, Cout = dz.shape
     lib = _lib.load()
     ws = _ws(lib.mmr_conv3d_k3_cin2_wgrad_ws_bytes(Cout), dz.device)
-    rc = lib.mmr_conv3d_k3_cin2_wgrad_f32(src.data_ptr(), trg.data_ptr(), dz.data_ptr(), dw.data_ptr(), ws.data_ptr(),
+    fn = lib.mmr_conv3d_k3_cin2_wgrad_f32x3 if x3 else lib.mmr_conv3d_k3_cin2_wgrad_f32
+    rc = fn(src.data_ptr(), trg.data_ptr(), dz.data_ptr(), dw.data_ptr(), ws.data_ptr(),
                                           B, X, Y, Z, Cout, int(accumulate), _stream())
     _lib.check(rc, "mmr_conv3d_k3_cin2_wgrad_f32")
     return dw

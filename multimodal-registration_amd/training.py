@@ -244,7 +244,7 @@ class SynthMorphTrainer:
                 _, li, src, trg, y = rec
                 dy = grads.pop(id(y))
                 dz = dy if id(y) in premasked else ops.leaky_bwd_bias_(y, dy, self.g[1], leaky=True)
-                ops.conv3d_k3_cin2_wgrad(src, trg, dz, self.g[0])
+                ops.conv3d_k3_cin2_wgrad(src, trg, dz, self.g[0], x3=bool(self.bwd_x3))
         return grads
 
     # ------------------------------------------------------------------ one step

@@ -186,7 +186,8 @@ def test_conv_backward_pieces(dev, shape, C0, C1, up0, Cout, x3):
         assert _rel(dcat, t0.grad) < 1e-4
 
 
-def test_first_layer_wgrad_and_maxpool_bwd(dev):
+@pytest.mark.parametrize("x3", [False, True])
+def test_first_layer_wgrad_and_maxpool_bwd(dev, x3):
     import mmr
     from oracle import grad_torch as G
     rng = np.random.default_rng(5)
@@ -198,8 +199,10 @@ def test_first_layer_wgrad_and_maxpool_bwd(dev):
     y = G.conv(torch.cat([torch.from_numpy(src), torch.from_numpy(trg)], -1).double(), wt, None, leaky=False)
     (y * torch.from_numpy(gz).double()).sum().backward()
     dw = torch.zeros((3, 3, 3, 2, 64), device=dev)
-    mmr.ops.conv3d_k3_cin2_wgrad(_t(src, dev), _t(trg, dev), _t(gz, dev), dw)
-    assert _rel(dw, wt.grad) < 1e-4
+    mmr.ops.conv3d_k3_cin2_wgrad(_t(src, dev), _t(trg, dev), _t(gz, dev), dw, x3=x3)
+    assert _rel(dw, wt.grad) < (2e-5 if x3 else 1e-5)
+    mmr.ops.conv3d_k3_cin2_wgrad(_t(src, dev), _t(trg, dev), _t(gz, dev), dw, accumulate=True, x3=x3)
+    assert _rel(dw, 2 * wt.grad) < (2e-5 if x3 else 1e-5)
     x = rng.standard_normal((2, 6, 8, 10, 32)).astype(np.float32)
     gp = rng.standard_normal((2, 3, 4, 5, 32)).astype(np.float32)
     xt = torch.from_numpy(x).double().requires_grad_(True)
@@ -209,6 +212,28 @@ def test_first_layer_wgrad_and_maxpool_bwd(dev):
     acc = torch.ones_like(got)
     mmr.ops.maxpool3d2_bwd(_t(x, dev), _t(gp, dev), dx=acc)
     assert _rel(acc - 1, xt.grad) < 1e-6
+
+
+@pytest.mark.parametrize("shape,Cin", [((4, 8, 8), 64), ((7, 13, 21), 128), ((2, 3, 5), 64)])
+def test_flow_head_wgrad_x3_thin_kernel(dev, shape, Cin):
+    """thin_wgrad_x3_kernel (taps folded into N, bf16 hi/lo products): several channel blocks, tiles that overhang
+    the volume on every axis, volumes smaller than one tile, accumulate; vs float64 autograd and vs the exact path."""
+    import mmr
+    from oracle import grad_torch as G
+    rng = np.random.default_rng(11)
+    B = 2
+    x = rng.standard_normal((B,) + shape + (Cin,)).astype(np.float32)
+    gy = rng.standard_normal((B,) + shape + (3,)).astype(np.float32)
+    wt = torch.zeros((3, 3, 3, Cin, 3), dtype=torch.float64, requires_grad=True)
+    (G.conv(torch.from_numpy(x).double(), wt, None, leaky=False) * torch.from_numpy(gy).double()).sum().backward()
+    dw = torch.full((3, 3, 3, Cin, 3), 7.0, device=dev)
+    mmr.ops.conv3d_k3_wgrad(_t(x, dev), _t(gy, dev), dw, x3=True)
+    assert _rel(dw, wt.grad) < 2e-5
+    mmr.ops.conv3d_k3_wgrad(_t(x, dev), _t(gy, dev), dw, x3=True, accumulate=True)
+    assert _rel(dw, 2 * wt.grad) < 2e-5
+    ex = torch.zeros_like(dw)
+    mmr.ops.conv3d_k3_wgrad(_t(x, dev), _t(gy, dev), ex, x3=False)
+    assert _rel(ex, wt.grad) < 1e-5
 
 
 def test_adam_matches_keras_formula(dev):
