@@ -240,6 +240,9 @@ int mmr_conv3d_k3_cin2_wgrad_f32x3(const float* src, const float* trg, const flo
 /* flow head (Cout = 3) input gradient */
 int mmr_conv3d_k3_cout3_dgrad_f32(const float* dy, const float* w_keras, float* dx, int B, int X, int Y, int Z, int Cin,
                                   void* stream);
+/* same, bf16 hi/lo split products (pairs with MMR_DT_F32X3); Cin % 64 == 0 */
+int mmr_conv3d_k3_cout3_dgrad_f32x3(const float* dy, const float* w_keras, float* dx, int B, int X, int Y, int Z, int Cin,
+                                    void* stream);
 /* Concat / upsample and max-pool backward with the same fusion: every gradient contribution to an activated tensor is
  * multiplied by LeakyReLU'(y) where it is produced and its column sums are added to that layer's bias gradient, so
  * no separate leaky-backward pass runs.  Channel counts must be multiples of 4 (else MMR_EUNSUPPORTED). */
@@ -263,6 +266,9 @@ int64_t mmr_conv3d_k3_cout3_dgrad_masked_ws_bytes(int B, int X, int Y, int Z, in
 int mmr_conv3d_k3_cout3_dgrad_masked_f32(const float* dy, const float* w_keras, float* dx, int B, int X, int Y, int Z,
                                          int Cin, const float* ymask, float alpha, float* dbias, void* ws,
                                          int accumulate, void* stream);
+int mmr_conv3d_k3_cout3_dgrad_masked_f32x3(const float* dy, const float* w_keras, float* dx, int B, int X, int Y, int Z,
+                                           int Cin, const float* ymask, float alpha, float* dbias, void* ws,
+                                           int accumulate, void* stream);
 /* Data gradient of a k3 conv fused with the LeakyReLU backward + bias gradient of the layer that produced the
  * conv's input (replaces mmr_leaky_bwd_bias_f32 after a dgrad; vxm Unet conv blocks):
  * out = conv(in0; w_packed = transposed/flipped weights) * (ymask < 0 ? alpha : 1); dbias (+)= sum_voxels out.

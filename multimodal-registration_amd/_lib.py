@@ -70,6 +70,7 @@ SIGNATURES = {
     "mmr_conv3d_k3_dgrad_masked": (I, [P, I, P, P, I, I, I, I, I, P, F, P, P, I, I, P]),
     "mmr_conv3d_k3_cout3_dgrad_masked_ws_bytes": (c_int64, [I, I, I, I, I]),
     "mmr_conv3d_k3_cout3_dgrad_masked_f32": (I, [P, P, P, I, I, I, I, I, P, F, P, P, I, P]),
+    "mmr_conv3d_k3_cout3_dgrad_masked_f32x3": (I, [P, P, P, I, I, I, I, I, P, F, P, P, I, P]),
     "mmr_dice_bwd_f32": (I, [P, P, P, I, c_int64, I, F, I, I, P]),
     "mmr_ncc_bwd_ws_bytes": (c_int64, [I, I, I, I]),
     "mmr_ncc_bwd_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, F, I, P]),
@@ -90,6 +91,7 @@ SIGNATURES = {
     "mmr_conv3d_k3_cin2_wgrad_f32": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
     "mmr_conv3d_k3_cin2_wgrad_f32x3": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
     "mmr_conv3d_k3_cout3_dgrad_f32": (I, [P, P, P, I, I, I, I, I, P]),
+    "mmr_conv3d_k3_cout3_dgrad_f32x3": (I, [P, P, P, I, I, I, I, I, P]),
     "mmr_adam_step_f32": (I, [P, P, P, P, c_int64, F, F, F, F, c_int64, F, P]),
     "mmr_jacobian_det_f64": (I, [P, P, I, I, I, P]),
     "mmr_joint_hist_f64": (I, [P, P, P, P, P, c_int64, I, P]),

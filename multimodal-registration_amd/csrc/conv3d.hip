@@ -1677,14 +1677,17 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
         // so that the loop-carried registers get no copies behind the loads).  With one 4-wave workgroup per CU (130 KB of
         // LDS) nothing else hides the HBM latency: a plane took 12 k cycles for 1.5 k cycles of MFMA.
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-        u32x4_t pre[NS > 0 ? NS : 1][2];
+        constexpr int NL = NS > 0 ? NS * (X3 ? 2 : 1) : 1;   // 16-B loads per row and plane (fp32: two per k-step)
+        u32x4_t pre[NL][2];
         auto load_plane = [&](int xq) {
             const int xc = xq < 0 ? 0 : (xq >= X ? X - 1 : xq);   // planes outside the volume are never used: any valid address
             const char* pl = in + ((size_t)b * X + xc) * Y * Z * Cin * ES;
 #pragma unroll
-            for (int s2 = 0; s2 < (NS > 0 ? NS : 1); ++s2)
+            for (int s2 = 0; s2 < NL; ++s2)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) pre[s2][j] = *reinterpret_cast<const u32x4_t*>(pl + rowoff[j] + (size_t)s2 * 64);
+                for (int j = 0; j < 2; ++j)
+                    pre[s2][j] = *reinterpret_cast<const u32x4_t*>(pl + rowoff[j] +
+                                                                   (X3 ? (size_t)(s2 >> 1) * 128 + (s2 & 1) * 16 : (size_t)s2 * 64));
         };
         if constexpr (NS > 0) load_plane(xs - 1);
         for (int xp = xs - 1; xp <= xe; ++xp) {
@@ -1713,10 +1716,10 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
                         }
                     }
                 };
-                u32x4_t allraw[NS > 0 ? NS : 1][2];
+                u32x4_t allraw[NL][2];
                 if constexpr (NS > 0) {
 #pragma unroll
-                    for (int s2 = 0; s2 < NS; ++s2)
+                    for (int s2 = 0; s2 < NL; ++s2)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) allraw[s2][j] = pre[s2][j] & rowmask[j];
                     load_plane(xp + 1);
@@ -1728,9 +1731,14 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
                     uint4 ah[2], al[2];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        if constexpr (NS > 0) {
+                        if constexpr (NS > 0 && !X3) {
                             ah[j] = make_uint4(allraw[s][j].x, allraw[s][j].y, allraw[s][j].z, allraw[s][j].w);
                         } else if constexpr (X3) {
+                            if constexpr (NS > 0) {
+                                const u32x4_t p0 = allraw[2 * s][j], p1 = allraw[2 * s + 1][j];
+                                raw0[j] = make_uint4(p0.x, p0.y, p0.z, p0.w);
+                                raw1[j] = make_uint4(p1.x, p1.y, p1.z, p1.w);
+                            }
                             const unsigned u[8] = {raw0[j].x, raw0[j].y, raw0[j].z, raw0[j].w, raw1[j].x, raw1[j].y, raw1[j].z, raw1[j].w};
                             unsigned hh[4], ll[4];
 #pragma unroll
@@ -2085,33 +2093,70 @@ extern "C" int mmr_conv3d_k3_cout3_fwd(const void* in, const float* w_keras, con
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipSuccess;
-        const void* ks[7] = {reinterpret_cast<const void*>(flow_head_kernel<false>), reinterpret_cast<const void*>(flow_head_kernel<true>),
+        const void* ks[10] = {reinterpret_cast<const void*>(flow_head_kernel<false>), reinterpret_cast<const void*>(flow_head_kernel<true>),
+                             reinterpret_cast<const void*>(flow_head_march_kernel<true, 4>),
+                             reinterpret_cast<const void*>(flow_head_march_kernel<true, 2>),
+                             reinterpret_cast<const void*>(flow_head_march_kernel<true, 1>),
                              reinterpret_cast<const void*>(flow_head_march_kernel<false>),
                              reinterpret_cast<const void*>(flow_head_march_kernel<true>),
                              reinterpret_cast<const void*>(flow_head_march_kernel<false, 8>),
                              reinterpret_cast<const void*>(flow_head_march_kernel<false, 4>),
                              reinterpret_cast<const void*>(flow_head_march_kernel<false, 2>)};
-        for (int i = 0; i < 7 && e == hipSuccess; ++i)
+        for (int i = 0; i < 10 && e == hipSuccess; ++i)
             e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
         attr_set = true;
     }
     // double-buffered P plane when it fits, else a single buffer (one more barrier per plane): fp32x3 at Cin = 256
     const int lds_w = npl * (Cin / 8) * 96 * 16;
-    const int pbufs = (lds_w + 2 * MH_ROWS * 81 * 4 <= 160 * 1024) ? 2 : 1;
+    int pbufs = (lds_w + 2 * MH_ROWS * 81 * 4 <= 160 * 1024) ? 2 : 1;
+    // narrow inputs: two workgroups per CU with a single P buffer each (one more barrier per plane, but a second workgroup
+    // to cover it: 0.52 -> 0.40 ms for fp32x3 at 160^3 x 64); MMR_FLOW_HEAD_1WG=1 restores one double-buffered workgroup
+    static const bool one_wg_env = getenv("MMR_FLOW_HEAD_1WG") != nullptr;
+    const bool two_wg = !one_wg_env && 2 * (lds_w + MH_ROWS * 81 * 4) <= 160 * 1024;
+    if (two_wg) pbufs = 1;
     const int lds_m = lds_w + pbufs * MH_ROWS * 81 * 4;
     if (use_march && lds_m <= 160 * 1024) {
         const int nty = (Y + MH_TY - 1) / MH_TY, ntz = (Z + MH_TZ - 1) / MH_TZ;
         const int64_t tyz = (int64_t)B * nty * ntz;
-        int nseg = (int)((1024 + tyz - 1) / tyz);  // enough tiles to balance 256 persistent blocks
-        if (nseg > (X + 7) / 8) nseg = (X + 7) / 8;
-        if (nseg < 1) nseg = 1;
+        // x segments: the makespan of the persistent grid is (tiles of the busiest workgroup) x (planes per tile, + 2 of
+        // halo); pick the segment count that minimises it (at C2: 2 segments = 3 x 82 plane steps against 5 x 56 for the
+        // "about 1024 tiles" rule this replaces)
+        const int gmax = two_wg ? 512 : 256;
+        int nseg = 1;
+        {
+            static const bool old_rule = getenv("MMR_FLOW_HEAD_SEG1024") != nullptr;   // A/B knob
+            int64_t best = -1;
+            const int smax = (X + 3) / 4;
+            for (int c = 1; c <= smax && c <= 64; ++c) {
+                const int sl = (X + c - 1) / c;
+                const int ns = (X + sl - 1) / sl;
+                const int64_t per = (tyz * ns + gmax - 1) / gmax;
+                const int64_t cost = per * (sl + 2);
+                if (best < 0 || cost < best) { best = cost; nseg = ns; }
+            }
+            if (old_rule) {
+                nseg = (int)((1024 + tyz - 1) / tyz);
+                if (nseg > (X + 7) / 8) nseg = (X + 7) / 8;
+                if (nseg < 1) nseg = 1;
+            }
+        }
         const int seglen = (X + nseg - 1) / nseg;
         nseg = (X + seglen - 1) / seglen;
         const int64_t nt = tyz * nseg;
         if (nt > 0x7fffffff) return MMR_EINVAL;
-        const int grid = nt < 256 ? (int)nt : 256;
-        if (dtype == MMR_DT_F32X3)
+        const int grid = nt < gmax ? (int)nt : gmax;
+        const bool ns0 = getenv("MMR_FLOW_HEAD_NS0") != nullptr;   // A/B knob: the un-prefetched generic path
+        if (dtype == MMR_DT_F32X3 && Cin == 128 && !ns0)
+            hipLaunchKernelGGL((flow_head_march_kernel<true, 4>), dim3(grid), dim3(MH_THREADS), lds_m, as_stream(stream),
+                               (const char*)in, w_keras, bias, out, B, X, Y, Z, Cin, nseg, seglen, nty, ntz, (int)nt, pbufs);
+        else if (dtype == MMR_DT_F32X3 && Cin == 64 && !ns0)
+            hipLaunchKernelGGL((flow_head_march_kernel<true, 2>), dim3(grid), dim3(MH_THREADS), lds_m, as_stream(stream),
+                               (const char*)in, w_keras, bias, out, B, X, Y, Z, Cin, nseg, seglen, nty, ntz, (int)nt, pbufs);
+        else if (dtype == MMR_DT_F32X3 && Cin == 32 && !ns0)
+            hipLaunchKernelGGL((flow_head_march_kernel<true, 1>), dim3(grid), dim3(MH_THREADS), lds_m, as_stream(stream),
+                               (const char*)in, w_keras, bias, out, B, X, Y, Z, Cin, nseg, seglen, nty, ntz, (int)nt, pbufs);
+        else if (dtype == MMR_DT_F32X3)
             hipLaunchKernelGGL(flow_head_march_kernel<true>, dim3(grid), dim3(MH_THREADS), lds_m, as_stream(stream),
                                (const char*)in, w_keras, bias, out, B, X, Y, Z, Cin, nseg, seglen, nty, ntz, (int)nt, pbufs);
         else if (Cin == 256 && !getenv("MMR_FLOW_HEAD_NS0"))

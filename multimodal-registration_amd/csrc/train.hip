@@ -1796,6 +1796,204 @@ static int launch_thin_wgrad_x3(const float* dense, int Cd, const float* s0, con
     return check_launch();
 }
 
+// ------------------------------------------------------------------------- //
+// Flow-head data gradient on the bf16 cores (fp32x3)                          //
+// ------------------------------------------------------------------------- //
+// dX^T[ci][v] = sum_k W^T[ci][k] * G^T[k][v]: channels are the MFMA rows, so a lane ends up with 4 consecutive channels
+// of one voxel (16-B stores / mask loads instead of 4-B ones).  The contraction index is ordered (dx, dy | dz, co):
+// for a fixed in-plane shift the 9 (dz, co) values of a voxel are 9 consecutive floats of dY, stored per haloed voxel
+// as one 16-element bf16 cell (9 used; the weight image is zero elsewhere), i.e. a k-step of 16 = one (dx, dy) and a
+// fragment = one ds_read_b128; K = 9 x 16 = 144 for 81 real taps.  LDS: cells [hi|lo][half][(x, y) row 40][z 8] x 16 B,
+// weights [hi|lo][k-step 9][half][ci 64] x 16 B, raw dY halo [40][10][3] fp32.  Persistent over 2 x 8 x 8 tiles (one
+// 32-voxel column block per wave); the next tile's dY halo is prefetched into registers, the LeakyReLU mask of the
+// current tile is loaded under the MFMAs; the bias-gradient column sums stay in registers until the end.
+constexpr int FD_CELLS = TW_HX * TW_HY * 8;        // 320
+constexpr int FD_G_PLANE = FD_CELLS * 16;          // per (hi|lo, half)
+constexpr int FD_G_BYTES = 4 * FD_G_PLANE;         // 20,480
+constexpr int FD_W_PLANE = 9 * 2 * 64 * 16;        // per hi|lo: 18,432
+constexpr int FD_W_BYTES = 2 * FD_W_PLANE;         // 36,864
+constexpr int FD_RAW = TW_HX * TW_HY * 30;         // 1200 floats
+constexpr int FD_LDS = FD_G_BYTES + FD_W_BYTES + FD_RAW * 4;   // 62,144
+constexpr int FD_RAW_IT = (FD_RAW + SM_THREADS - 1) / SM_THREADS;   // 5
+
+__global__ void __launch_bounds__(SM_THREADS, 2)
+flow_dgrad_x3_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int B, int X, int Y,
+                     int Z, int Cin, int ntx, int nty, int ntz, int ntiles, const float* __restrict__ ymask, float alpha,
+                     double* __restrict__ part)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sG = smem;
+    char* sW = smem + FD_G_BYTES;
+    float* sRaw = reinterpret_cast<float*>(smem + FD_G_BYTES + FD_W_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, li = lane & 31;
+    const int cb = blockIdx.y;
+    const size_t nvox = (size_t)X * Y * Z;
+
+    for (int i = tid; i < 9 * 64 * 16; i += SM_THREADS) {   // weight image, once per workgroup
+        const int idx = i & 15, ci = (i >> 4) & 63, ks = i >> 10;
+        float f = 0.f;
+        if (idx < 9) {
+            const int tap = (2 - ks / 3) * 9 + (2 - ks % 3) * 3 + (2 - idx / 3);
+            f = w[((size_t)tap * Cin + cb * 64 + ci) * 3 + idx % 3];
+        }
+        unsigned short hi, lo;
+        split_bf16(f, hi, lo);
+        const int off = ((ks * 2 + (idx >> 3)) * 64 + ci) * 16 + (idx & 7) * 2;
+        *reinterpret_cast<unsigned short*>(sW + off) = hi;
+        *reinterpret_cast<unsigned short*>(sW + FD_W_PLANE + off) = lo;
+    }
+
+    float rpf[FD_RAW_IT];
+    unsigned rmask = 0;
+    auto issue = [&](int tile) {
+        int t = tile;
+        const int tzi = t % ntz; t /= ntz;
+        const int tyi = t % nty; t /= nty;
+        const int txi = t % ntx;
+        const int b = t / ntx;
+        const int x0 = txi * TW_TX, y0 = tyi * TW_TY, z0 = tzi * TW_TZ;
+        unsigned mk = 0;
+#pragma unroll
+        for (int it = 0; it < FD_RAW_IT; ++it) {
+            const int i = tid + it * SM_THREADS;
+            const int ic = i < FD_RAW ? i : 0;
+            const int hxy = ic / 30, r = ic - hxy * 30;
+            const int gx = x0 + hxy / TW_HY - 1, gy = y0 + hxy % TW_HY - 1, gz = z0 + r / 3 - 1;
+            const bool ok = i < FD_RAW && gx >= 0 && gx < X && gy >= 0 && gy < Y && gz >= 0 && gz < Z;
+            mk |= ok ? (1u << it) : 0u;
+            rpf[it] = dy[((size_t)b * nvox + ((size_t)min(max(gx, 0), X - 1) * Y + min(max(gy, 0), Y - 1)) * Z +
+                          min(max(gz, 0), Z - 1)) * 3 + r % 3];
+        }
+        rmask = mk;
+    };
+
+    // this lane's voxel inside a tile and its fragment bases
+    const int zrow = wave * 4 + (li >> 3);
+    const int vx = zrow >> 3, vy = zrow & 7, vz = li & 7;
+    const char* gbase = sG + ((vx * TW_HY + vy) * 8 + vz) * 16 + h * FD_G_PLANE;
+    const char* wbase = sW + (h * 64 + li) * 16;
+
+    float4 cs[2][4];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cs[n][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tzi = t % ntz; t /= ntz;
+        const int tyi = t % nty; t /= nty;
+        const int txi = t % ntx;
+        const int b = t / ntx;
+        const int gx = txi * TW_TX + vx, gy = tyi * TW_TY + vy, gz = tzi * TW_TZ + vz;
+        const bool vok = gx < X && gy < Y && gz < Z;
+        const size_t e = vok ? ((size_t)b * nvox + ((size_t)gx * Y + gy) * Z + gz) * Cin + cb * 64 + 4 * h : 0;
+#pragma unroll
+        for (int it = 0; it < FD_RAW_IT; ++it) {
+            const int i = tid + it * SM_THREADS;
+            if (i < FD_RAW) sRaw[i] = (rmask >> it) & 1 ? rpf[it] : 0.f;
+        }
+        __syncthreads();   // raw halo complete; every wave is past the previous tile's fragments
+        for (int c = tid; c < FD_CELLS; c += SM_THREADS) {
+            const float* r = sRaw + (c >> 3) * 30 + (c & 7) * 3;
+            unsigned hp[5], lp[5];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tw_split_pair(r[2 * q], r[2 * q + 1], hp[q], lp[q]);
+            tw_split_pair(r[8], 0.f, hp[4], lp[4]);
+            const tw_u32x4 h0 = {hp[0], hp[1], hp[2], hp[3]}, l0 = {lp[0], lp[1], lp[2], lp[3]};
+            const tw_u32x4 h1 = {hp[4], 0u, 0u, 0u}, l1 = {lp[4], 0u, 0u, 0u};
+            char* o = sG + c * 16;
+            *reinterpret_cast<tw_u32x4*>(o) = h0;
+            *reinterpret_cast<tw_u32x4*>(o + FD_G_PLANE) = h1;
+            *reinterpret_cast<tw_u32x4*>(o + 2 * FD_G_PLANE) = l0;
+            *reinterpret_cast<tw_u32x4*>(o + 3 * FD_G_PLANE) = l1;
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
+        float4 mk4[2][4];
+        if (ymask) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mk4[n][q] = *reinterpret_cast<const float4*>(ymask + e + n * 32 + 8 * q);
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 9; ++ks) {
+            const char* gp = gbase + ((ks / 3) * TW_HY + ks % 3) * 8 * 16;
+            const bf16x8_t g_hi = *reinterpret_cast<const bf16x8_t*>(gp);
+            const bf16x8_t g_lo = *reinterpret_cast<const bf16x8_t*>(gp + 2 * FD_G_PLANE);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const char* wp = wbase + (ks * 2 * 64 + n * 32) * 16;
+                const bf16x8_t w_hi = *reinterpret_cast<const bf16x8_t*>(wp);
+                const bf16x8_t w_lo = *reinterpret_cast<const bf16x8_t*>(wp + FD_W_PLANE);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_lo, g_hi, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi, g_lo, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi, g_hi, acc[n], 0, 0, 0);
+            }
+        }
+        if (vok) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 v = make_float4(acc[n][4 * q], acc[n][4 * q + 1], acc[n][4 * q + 2], acc[n][4 * q + 3]);
+                    if (ymask) {   // LeakyReLU backward of the layer that made the flow head's input, and its bias gradient
+                        const float4 m = mk4[n][q];
+                        v.x *= m.x < 0.f ? alpha : 1.f; v.y *= m.y < 0.f ? alpha : 1.f;
+                        v.z *= m.z < 0.f ? alpha : 1.f; v.w *= m.w < 0.f ? alpha : 1.f;
+                        cs[n][q].x += v.x; cs[n][q].y += v.y; cs[n][q].z += v.z; cs[n][q].w += v.w;
+                    }
+                    *reinterpret_cast<float4*>(dx + e + n * 32 + 8 * q) = v;
+                }
+        }
+    }
+    if (ymask) {   // column sums: [wave][lane][n][q][4] through LDS, one double per channel and workgroup
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);   // 4 x 64 x 32 floats = 32 KB
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(red + ((wave * 64 + lane) * 8 + n * 4 + q) * 4) = cs[n][q];
+        __syncthreads();
+        if (tid < 64) {
+            const int n = tid >> 5, q = (tid >> 3) & 3, hh = (tid >> 2) & 1, k = tid & 3;   // channel = n*32 + 8q + 4h + k
+            double s = 0.0;
+            for (int wv = 0; wv < 4; ++wv)
+                for (int l = 0; l < 32; ++l) s += (double)red[((wv * 64 + hh * 32 + l) * 8 + n * 4 + q) * 4 + k];
+            part[(size_t)blockIdx.x * Cin + cb * 64 + tid] = s;
+        }
+    }
+}
+
+static int launch_flow_dgrad_x3(const float* dy, const float* w, float* dx, int B, int X, int Y, int Z, int Cin,
+                                const float* ymask, float alpha, float* dbias, void* ws, int accumulate, void* stream)
+{
+    const int ntx = (X + TW_TX - 1) / TW_TX, nty = (Y + TW_TY - 1) / TW_TY, ntz = (Z + TW_TZ - 1) / TW_TZ;
+    const int64_t nt = (int64_t)B * ntx * nty * ntz;
+    if (nt > 0x7fffffff) return MMR_EINVAL;
+    const int ncb = Cin / 64;
+    int gx = 512 / ncb;
+    if (gx > nt) gx = (int)nt;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(flow_dgrad_x3_kernel, dim3(gx, ncb), dim3(SM_THREADS), FD_LDS, as_stream(stream), dy, w, dx, B, X, Y, Z,
+                       Cin, ntx, nty, ntz, (int)nt, ymask, alpha, (double*)ws);
+    if (ymask)
+        hipLaunchKernelGGL(bias_final_kernel, dim3(Cin), dim3(64), 0, as_stream(stream), (const double*)ws, dbias, Cin, gx,
+                           accumulate);
+    return check_launch();
+}
+
 // flow-head dgrad: dX[v][ci] = sum_g G[v][g] * Wr[g][ci], g = tap*3 + co, G[v][g] = dY[v - off(tap)][co]
 // (M = 256 voxels per block, N = 64 input channels per blockIdx.y, K = 81 padded to 82)
 __global__ void __launch_bounds__(SM_THREADS, 2)
@@ -2466,9 +2664,20 @@ extern "C" int mmr_conv3d_k3_cout3_dgrad_f32(const float* dy, const float* w_ker
     return check_launch();
 }
 
+// same contract as mmr_conv3d_k3_cout3_dgrad_f32, bf16 hi/lo split products (Cin % 64 == 0, else MMR_EUNSUPPORTED)
+extern "C" int mmr_conv3d_k3_cout3_dgrad_f32x3(const float* dy, const float* w_keras, float* dx, int B, int X, int Y,
+                                               int Z, int Cin, void* stream)
+{
+    if (!dy || !w_keras || !dx || B < 1 || X < 1 || Y < 1 || Z < 1 || Cin < 1 || Cin > 512) return MMR_EINVAL;
+    if (Cin % 64) return MMR_EUNSUPPORTED;
+    return launch_flow_dgrad_x3(dy, w_keras, dx, B, X, Y, Z, Cin, nullptr, 0.f, nullptr, nullptr, 0, stream);
+}
+
 extern "C" int64_t mmr_conv3d_k3_cout3_dgrad_masked_ws_bytes(int B, int X, int Y, int Z, int Cin)
 {
-    return (int64_t)B * ((X + W_TX - 1) / W_TX) * ((Y + W_TY - 1) / W_TY) * ((Z + W_TZ - 1) / W_TZ) * Cin * (int64_t)sizeof(double);
+    // one double per (workgroup, channel); the exact path has one workgroup per 4 x 8 x 8 tile, the fp32x3 path at most 512
+    const int64_t a = (int64_t)B * ((X + W_TX - 1) / W_TX) * ((Y + W_TY - 1) / W_TY) * ((Z + W_TZ - 1) / W_TZ);
+    return (a > 512 ? a : 512) * Cin * (int64_t)sizeof(double);
 }
 
 // flow-head data gradient fused with the LeakyReLU backward + bias gradient of the layer feeding the flow head:
@@ -2488,6 +2697,16 @@ extern "C" int mmr_conv3d_k3_cout3_dgrad_masked_f32(const float* dy, const float
     hipLaunchKernelGGL(bias_final_kernel, dim3(Cin), dim3(64), 0, as_stream(stream), (const double*)ws, dbias, Cin,
                        (int)nblk, accumulate);
     return check_launch();
+}
+
+extern "C" int mmr_conv3d_k3_cout3_dgrad_masked_f32x3(const float* dy, const float* w_keras, float* dx, int B, int X, int Y,
+                                                      int Z, int Cin, const float* ymask, float alpha, float* dbias,
+                                                      void* ws, int accumulate, void* stream)
+{
+    if (!dy || !w_keras || !dx || !ymask || !dbias || !ws || B < 1 || X < 1 || Y < 1 || Z < 1 || Cin < 1 || Cin > 512)
+        return MMR_EINVAL;
+    if (Cin % 64) return MMR_EUNSUPPORTED;
+    return launch_flow_dgrad_x3(dy, w_keras, dx, B, X, Y, Z, Cin, ymask, alpha, dbias, ws, accumulate, stream);
 }
 
 extern "C" int mmr_adam_step_f32(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1,

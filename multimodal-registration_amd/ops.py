@@ -736,17 +736,20 @@ def conv3d_k3_cin2_wgrad(src, trg, dz, dw, accumulate=False, x3=False):
     return dw
 
 
-def conv3d_k3_cout3_dgrad(dy, w_keras):
+def conv3d_k3_cout3_dgrad(dy, w_keras, x3=False):
+    """Flow-head data gradient; ``x3``: bf16 hi/lo split products (Cin % 64 == 0), else exact fp32."""
     _chk(dy, torch.float32, "dy")
     B, X, Y, Z, _ = dy.shape
     Cin = w_keras.shape[3]
     dx = torch.empty((B, X, Y, Z, Cin), dtype=torch.float32, device=dy.device)
-    rc = _lib.load().mmr_conv3d_k3_cout3_dgrad_f32(dy.data_ptr(), w_keras.data_ptr(), dx.data_ptr(), B, X, Y, Z, Cin, _stream())
+    lib = _lib.load()
+    fn = lib.mmr_conv3d_k3_cout3_dgrad_f32x3 if (x3 and Cin % 64 == 0) else lib.mmr_conv3d_k3_cout3_dgrad_f32
+    rc = fn(dy.data_ptr(), w_keras.data_ptr(), dx.data_ptr(), B, X, Y, Z, Cin, _stream())
     _lib.check(rc, "mmr_conv3d_k3_cout3_dgrad_f32")
     return dx
 
 
-def conv3d_k3_cout3_dgrad_masked(dy, w_keras, ymask, dbias, alpha=0.2, accumulate=False):
+def conv3d_k3_cout3_dgrad_masked(dy, w_keras, ymask, dbias, alpha=0.2, accumulate=False, x3=False):
     """Flow-head dgrad with the producing layer's LeakyReLU backward + bias gradient fused (Cin % 64 == 0);
     returns None when the fused kernel does not cover the width (caller uses the unfused pair)."""
     _chk(dy, torch.float32, "dy")
@@ -760,9 +763,9 @@ def conv3d_k3_cout3_dgrad_masked(dy, w_keras, ymask, dbias, alpha=0.2, accumulat
     dx = torch.empty((B, X, Y, Z, Cin), dtype=torch.float32, device=dy.device)
     lib = _lib.load()
     ws = _ws(lib.mmr_conv3d_k3_cout3_dgrad_masked_ws_bytes(B, X, Y, Z, Cin), dy.device)
-    rc = lib.mmr_conv3d_k3_cout3_dgrad_masked_f32(dy.data_ptr(), w_keras.data_ptr(), dx.data_ptr(), B, X, Y, Z, Cin,
-                                                  ymask.data_ptr(), float(alpha), dbias.data_ptr(), ws.data_ptr(),
-                                                  int(accumulate), _stream())
+    fn = lib.mmr_conv3d_k3_cout3_dgrad_masked_f32x3 if x3 else lib.mmr_conv3d_k3_cout3_dgrad_masked_f32
+    rc = fn(dy.data_ptr(), w_keras.data_ptr(), dx.data_ptr(), B, X, Y, Z, Cin,
+            ymask.data_ptr(), float(alpha), dbias.data_ptr(), ws.data_ptr(), int(accumulate), _stream())
     _lib.check(rc, "mmr_conv3d_k3_cout3_dgrad_masked_f32")
     return dx
 

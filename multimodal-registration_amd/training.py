@@ -182,10 +182,10 @@ class SynthMorphTrainer:
                     dcat = None
                     if plain and want_mask(x) and C0 % 64 == 0:
                         db, acc = bias_of(x)
-                        dcat = ops.conv3d_k3_cout3_dgrad_masked(dz, m._w[2 * li], x, db, accumulate=acc)
+                        dcat = ops.conv3d_k3_cout3_dgrad_masked(dz, m._w[2 * li], x, db, accumulate=acc, x3=bool(self.bwd_x3))
                         premasked.add(id(x))
                     if dcat is None:
-                        dcat = ops.conv3d_k3_cout3_dgrad(dz, m._w[2 * li])
+                        dcat = ops.conv3d_k3_cout3_dgrad(dz, m._w[2 * li], x3=bool(self.bwd_x3))
                 else:
                     wt = ops.pack_conv_weights(m._w[2 * li], torch.float32, transpose_flip=True, x3=self.bwd_x3)
                     if plain and want_mask(x):

@@ -404,6 +404,33 @@ def test_dgrad_masked_equals_dgrad_then_leaky_bwd(dev, shape, Cmid, Cin, x3):
     assert _rel(db2, 2 * db_ref) < 1e-5
 
 
+@pytest.mark.parametrize("shape,Cin", [((8, 8, 8), 64), ((5, 9, 11), 128), ((2, 17, 3), 64)])
+def test_flow_dgrad_x3_kernel(dev, shape, Cin):
+    """flow_dgrad_x3_kernel (channels as MFMA rows, K ordered (dx, dy | dz, co), bf16 hi/lo products): vs float64
+    autograd, fused LeakyReLU mask + bias gradient vs the unfused pair (bit-equal), accumulate, batch of 2."""
+    import mmr
+    from oracle import grad_torch as G
+    ops = mmr.ops
+    rng = np.random.default_rng(12)
+    B = 2
+    gy = rng.standard_normal((B,) + shape + (3,)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, Cin, 3)) * 0.1).astype(np.float32)
+    xt = torch.zeros((B,) + shape + (Cin,), dtype=torch.float64, requires_grad=True)
+    (G.conv(xt, torch.from_numpy(w).double(), None, leaky=False) * torch.from_numpy(gy).double()).sum().backward()
+    dy, wd = _t(gy, dev), _t(w, dev)
+    got = ops.conv3d_k3_cout3_dgrad(dy, wd, x3=True)
+    assert _rel(got, xt.grad) < 2e-5
+    assert _rel(ops.conv3d_k3_cout3_dgrad(dy, wd), xt.grad) < 1e-5
+    y = _t(rng.standard_normal((B,) + shape + (Cin,)).astype(np.float32), dev)
+    db_ref = torch.zeros(Cin, device=dev)
+    ref = ops.leaky_bwd_bias_(y, got.clone(), db_ref, leaky=True)
+    db = torch.full((Cin,), -3.0, device=dev)
+    fused = ops.conv3d_k3_cout3_dgrad_masked(dy, wd, y, db, x3=True)
+    assert torch.equal(fused, ref) and _rel(db, db_ref) < 1e-5
+    ops.conv3d_k3_cout3_dgrad_masked(dy, wd, y, db, accumulate=True, x3=True)
+    assert _rel(db, 2 * db_ref) < 1e-5
+
+
 @pytest.mark.parametrize("shape,Cin", [((8, 8, 8), 64), ((5, 9, 11), 128)])
 def test_flow_dgrad_masked_equals_unfused(dev, shape, Cin):
     import mmr

@@ -39,14 +39,19 @@ def main():
         print(f"flow-head wgrad  x3={x3}: {t:.3f} ms  ({gb / t * 1e3:.0f} GB/s of the dense operand)")
         t = timeit(lambda: ops.conv3d_k3_cin2_wgrad(src, trg, x, dw0, x3=x3))
         print(f"first-layer wgrad x3={x3}: {t:.3f} ms  ({gb / t * 1e3:.0f} GB/s)")
-    t = timeit(lambda: ops.conv3d_k3_cout3_dgrad(dflow, w))
-    print(f"flow-head dgrad: {t:.3f} ms  ({gb / t * 1e3:.0f} GB/s written)")
     db = torch.zeros(64, device=dev)
-    t = timeit(lambda: ops.conv3d_k3_cout3_dgrad_masked(dflow, w, x, db))
-    print(f"flow-head dgrad masked: {t:.3f} ms")
+    for x3 in (False, True):
+        t = timeit(lambda: ops.conv3d_k3_cout3_dgrad(dflow, w, x3=x3))
+        print(f"flow-head dgrad x3={x3}: {t:.3f} ms  ({gb / t * 1e3:.0f} GB/s written)")
+        t = timeit(lambda: ops.conv3d_k3_cout3_dgrad_masked(dflow, w, x, db, x3=x3))
+        print(f"flow-head dgrad masked x3={x3}: {t:.3f} ms  ({2 * gb / t * 1e3:.0f} GB/s read + written)")
     b = torch.zeros(3, device=dev)
     t = timeit(lambda: ops.conv3d_k3_cout3(x, w, b, x3=True))
     print(f"flow head fwd x3: {t:.3f} ms  ({gb / t * 1e3:.0f} GB/s read)")
+    xb = torch.randn((1, 160, 160, 192, 256), device=dev, generator=g).to(torch.bfloat16)
+    wb = torch.randn((3, 3, 3, 256, 3), device=dev, generator=g) * 0.05
+    t = timeit(lambda: ops.conv3d_k3_cout3(xb, wb, b))
+    print(f"flow head fwd bf16 C2: {t:.3f} ms  ({xb.numel() * 2 / 1e9 / t * 1e3:.0f} GB/s read)")
 
 
 if __name__ == "__main__":
