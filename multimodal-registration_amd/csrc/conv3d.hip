@@ -1114,8 +1114,9 @@ int dispatch_conv(const ConvParams& p, hipStream_t st, int64_t* nblk_out = nullp
             if (DT == MMR_DT_BF16)  // neither the bf16 fragment pipeline nor the DMA staging fit 256 VGPRs at this tile
                 return launch_conv<DT, 4, 2, 4, 2, 32>(p, nt, st, nblk_out);
             if (var == 2464) return launch_conv<DT, 4, 2, 4, 2, 2464>(p, nt, st, nblk_out);
-            if (var == 4512) return launch_conv<DT, 4, 2, 4, 2, 4512>(p, nt, st, nblk_out);  // 416 + batched branch-free A staging
-            return launch_conv<DT, 4, 2, 4, 2, 416>(p, nt, st, nblk_out);
+            if (var == 416) return launch_conv<DT, 4, 2, 4, 2, 416>(p, nt, st, nblk_out);   // round-1 default
+            // fp32x3 / x1 / exact fp32: 416 + batched branch-free A staging (-2.3 % on the C3 dgrad convs, same-box A/B)
+            return launch_conv<DT, 4, 2, 4, 2, 4512>(p, nt, st, nblk_out);
         case 64:
             if (var == 32) return launch_conv<DT, 8, 1, 2, 2, 32>(p, nt, st, nblk_out);
             if (var == 2464) return launch_conv<DT, 8, 1, 2, 2, 2464>(p, nt, st, nblk_out);

@@ -346,6 +346,88 @@ compose_bwd_kernel(const float* __restrict__ a, const float* __restrict__ bf, co
     }
 }
 
+// Same gradients, scatter accumulated per tile in LDS: a workgroup owns an 8 x 8 x 16 voxel tile, the trilinear splat of
+// d out / d a lands in an LDS image of the tile + 2 voxels of margin (LDS atomics), which is flushed to HBM with one atomic
+// per touched entry instead of one per (voxel, corner): displacements of scaling-and-squaring steps are a few voxels at
+// most, so almost every splat stays inside the image; anything farther goes straight to HBM as before.  db (the
+// gradient through the sampling location and the additive term) is exclusive per voxel: it joins the LDS image when it
+// aliases da (VecInt: out = v + warp(v, v)), else it is stored.
+constexpr int CB_TX = 8, CB_TY = 8, CB_TZ = 16, CB_M = 2;
+constexpr int CB_RX = CB_TX + 2 * CB_M, CB_RY = CB_TY + 2 * CB_M, CB_RZ = CB_TZ + 2 * CB_M;
+constexpr int CB_REGION = CB_RX * CB_RY * CB_RZ;   // 2880 voxels x 3 floats = 34,560 B
+__global__ void __launch_bounds__(TB)
+compose_bwd_tiled_kernel(const float* __restrict__ a, const float* __restrict__ bf, const float* __restrict__ dout,
+                         float* __restrict__ da, float* __restrict__ db, int B, int X, int Y, int Z, float s, int ntx,
+                         int nty, int ntz)
+{
+    __shared__ float img[CB_REGION * 3];
+    for (int i = threadIdx.x; i < CB_REGION * 3; i += TB) img[i] = 0.f;
+    int t = blockIdx.x;
+    const int tzi = t % ntz; t /= ntz;
+    const int tyi = t % nty; t /= nty;
+    const int txi = t % ntx;
+    const int b = t / ntx;
+    const int x0 = txi * CB_TX, y0 = tyi * CB_TY, z0 = tzi * CB_TZ;
+    const int64_t nvox = (int64_t)X * Y * Z;
+    const int64_t sy = (int64_t)Z * 3, sx = (int64_t)Y * Z * 3;
+    const float* abase = a + b * nvox * 3;
+    float* dabase = da + b * nvox * 3;
+    const bool alias = (da == db);
+    __syncthreads();
+    for (int lv = threadIdx.x; lv < CB_TX * CB_TY * CB_TZ; lv += TB) {
+        const int lz = lv % CB_TZ, ly = (lv / CB_TZ) % CB_TY, lx = lv / (CB_TZ * CB_TY);
+        const int x = x0 + lx, y = y0 + ly, z = z0 + lz;
+        if (x >= X || y >= Y || z >= Z) continue;
+        const int64_t v = b * nvox + ((int64_t)x * Y + y) * Z + z;
+        const float* f = bf + v * 3;
+        const AxisG ax = axis_setup_g((float)x + f[0] * s, X - 1);
+        const AxisG ay = axis_setup_g((float)y + f[1] * s, Y - 1);
+        const AxisG az = axis_setup_g((float)z + f[2] * s, Z - 1);
+        const float g[3] = {dout[v * 3], dout[v * 3 + 1], dout[v * 3 + 2]};
+        float dl[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+            const int qx = cc >> 2, qy = (cc >> 1) & 1, qz = cc & 1;
+            const int ix = qx ? ax.i1 : ax.i0, iy = qy ? ay.i1 : ay.i0, iz = qz ? az.i1 : az.i0;
+            const int64_t off = ix * sx + iy * sy + (int64_t)iz * 3;
+            const float wx = qx ? ax.w1 : ax.w0, wy = qy ? ay.w1 : ay.w0, wz = qz ? az.w1 : az.w0;
+            const float w = (wx * wy) * wz;
+            const int rx = ix - x0 + CB_M, ry = iy - y0 + CB_M, rz = iz - z0 + CB_M;
+            const bool inimg = (unsigned)rx < (unsigned)CB_RX && (unsigned)ry < (unsigned)CB_RY && (unsigned)rz < (unsigned)CB_RZ;
+            const int ro = ((rx * CB_RY + ry) * CB_RZ + rz) * 3;
+            float dotv = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                dotv += g[c] * (abase[off + c] * s);
+                if (w != 0.f) {
+                    if (inimg) atomicAdd(&img[ro + c], s * w * g[c]);
+                    else atomicAdd(dabase + off + c, s * w * g[c]);
+                }
+            }
+            dl[0] += (qx ? 1.f : -1.f) * wy * wz * dotv;
+            dl[1] += (qy ? 1.f : -1.f) * wx * wz * dotv;
+            dl[2] += (qz ? 1.f : -1.f) * wx * wy * dotv;
+        }
+        const float d0 = s * (g[0] + ax.inr * dl[0]), d1 = s * (g[1] + ay.inr * dl[1]), d2 = s * (g[2] + az.inr * dl[2]);
+        if (alias) {
+            float* o = img + (((lx + CB_M) * CB_RY + ly + CB_M) * CB_RZ + lz + CB_M) * 3;
+            atomicAdd(o, d0); atomicAdd(o + 1, d1); atomicAdd(o + 2, d2);
+        } else {
+            db[v * 3] = d0; db[v * 3 + 1] = d1; db[v * 3 + 2] = d2;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < CB_REGION * 3; i += TB) {
+        const float val = img[i];
+        if (val == 0.f) continue;
+        const int c = i % 3, r = i / 3;
+        const int rz = r % CB_RZ, ry = (r / CB_RZ) % CB_RY, rx = r / (CB_RZ * CB_RY);
+        const int gx = x0 + rx - CB_M, gy = y0 + ry - CB_M, gz = z0 + rz - CB_M;
+        if (gx < 0 || gx >= X || gy < 0 || gy >= Y || gz < 0 || gz >= Z) continue;   // never touched: indices are clamped
+        atomicAdd(dabase + (int64_t)gx * sx + (int64_t)gy * sy + (int64_t)gz * 3 + c, val);
+    }
+}
+
 // general linear-warp gradient w.r.t. the flow: dflow[b,v,:] = sum_c dout[b,v,c] * d interp(vol_c)/d loc
 __global__ void __launch_bounds__(TB)
 warp_bwd_flow_kernel(const float* __restrict__ vol, const float* __restrict__ flow, const float* __restrict__ dout,
@@ -2214,6 +2296,22 @@ extern "C" int mmr_resize_trilinear_bwd_f32(const float* dout, float* din, int B
     return check_launch();
 }
 
+// da, db zeroed by the caller.  MMR_COMPOSE_BWD_FLAT=1: the one-atomic-per-corner kernel (A/B runs).
+static int launch_compose_bwd(const float* a, const float* b, const float* dout, float* da, float* db, int B, int X, int Y,
+                              int Z, float s, hipStream_t st)
+{
+    static const bool flat = getenv("MMR_COMPOSE_BWD_FLAT") != nullptr;
+    const int ntx = (X + CB_TX - 1) / CB_TX, nty = (Y + CB_TY - 1) / CB_TY, ntz = (Z + CB_TZ - 1) / CB_TZ;
+    const int64_t nt = (int64_t)B * ntx * nty * ntz;
+    if (flat || nt > 0x7fffffff)
+        hipLaunchKernelGGL(compose_bwd_kernel, dim3(stream_grid((int64_t)B * X * Y * Z, TB)), dim3(TB), 0, st, a, b, dout,
+                           da, db, B, X, Y, Z, s);
+    else
+        hipLaunchKernelGGL(compose_bwd_tiled_kernel, dim3((unsigned)nt), dim3(TB), 0, st, a, b, dout, da, db, B, X, Y, Z, s,
+                           ntx, nty, ntz);
+    return check_launch();
+}
+
 extern "C" int mmr_compose_bwd_f32(const float* a, const float* b, const float* dout, float* da, float* db, int B,
                                    int X, int Y, int Z, void* stream)
 {
@@ -2222,9 +2320,7 @@ extern "C" int mmr_compose_bwd_f32(const float* a, const float* b, const float* 
     const size_t bytes = (size_t)B * X * Y * Z * 3 * sizeof(float);
     if (hipMemsetAsync(da, 0, bytes, st) != hipSuccess) return MMR_EHIP;
     if (db != da && hipMemsetAsync(db, 0, bytes, st) != hipSuccess) return MMR_EHIP;
-    hipLaunchKernelGGL(compose_bwd_kernel, dim3(stream_grid((int64_t)B * X * Y * Z, TB)), dim3(TB), 0, st, a, b, dout,
-                       da, db, B, X, Y, Z, 1.0f);
-    return check_launch();
+    return launch_compose_bwd(a, b, dout, da, db, B, X, Y, Z, 1.0f, st);
 }
 
 // steps: [nsteps][B,X,Y,Z,3] = the input of every squaring step as saved by mmr_vecint_save_f32
@@ -2246,14 +2342,12 @@ extern "C" int mmr_vecint_bwd_f32(const float* vel, const float* steps, const fl
     const float* g = dout;
     float* bufs[2] = {dvel, tmp};
     int cur = (nsteps % 2 == 1) ? 0 : 1;  // so that the last written buffer is dvel
-    const int grid = stream_grid((int64_t)B * X * Y * Z, TB);
     for (int k = nsteps - 1; k >= 0; --k) {
         float* dst = bufs[cur];
         if (hipMemsetAsync(dst, 0, nel * sizeof(float), st) != hipSuccess) return MMR_EHIP;
         const float* in = (k == 0) ? vel : steps + (int64_t)(k - 1) * nel;
         const float s = (k == 0) ? 1.0f / (float)(1 << nsteps) : 1.0f;
-        hipLaunchKernelGGL(compose_bwd_kernel, dim3(grid), dim3(TB), 0, st, in, in, g, dst, dst, B, X, Y, Z, s);
-        int rc = check_launch();
+        int rc = launch_compose_bwd(in, in, g, dst, dst, B, X, Y, Z, s, st);
         if (rc) return rc;
         g = dst;
         cur ^= 1;

@@ -106,6 +106,30 @@ def test_resize_bwd_is_adjoint(dev, shape, new, mul):
     assert _rel(got, xt.grad) < 1e-5
 
 
+@pytest.mark.parametrize("scale", [0.4, 2.5])
+def test_compose_bwd_tiled_multi_tile(dev, scale):
+    """compose_bwd_tiled_kernel: several 8x8x16 tiles with overhang, batch of 2, splats inside the LDS image (small
+    displacements) and beyond its 2-voxel margin (large ones, global-atomic path), aliased (VecInt) and separate outputs."""
+    import mmr
+    from oracle import grad_torch as G
+    rng = np.random.default_rng(13)
+    S = (19, 10, 37)
+    a = (rng.standard_normal((2,) + S + (3,)) * scale).astype(np.float32)
+    b = (rng.standard_normal((2,) + S + (3,)) * scale).astype(np.float32)
+    g = rng.standard_normal((2,) + S + (3,)).astype(np.float32)
+    da, db = mmr.ops.compose_bwd(_t(a, dev), _t(b, dev), _t(g, dev))
+    for i in range(2):
+        at, bt = torch.from_numpy(a[i]).double().requires_grad_(True), torch.from_numpy(b[i]).double().requires_grad_(True)
+        ((bt + G.transform(at, bt)) * torch.from_numpy(g[i]).double()).sum().backward()
+        assert _rel(da[i], at.grad) < 1e-5 and _rel(db[i], bt.grad) < 1e-5
+    for i in range(2):
+        vt = torch.from_numpy(a[i]).double().requires_grad_(True)
+        (G.vecint(vt, 3) * torch.from_numpy(g[i]).double()).sum().backward()
+        out, steps = mmr.ops.vecint_save(_t(a[i][None], dev), 3)
+        dv = mmr.ops.vecint_bwd(_t(a[i][None], dev), steps, _t(g[i][None], dev), 3)
+        assert _rel(dv[0], vt.grad) < 1e-5
+
+
 def test_compose_vecint_warp_bwd(dev):
     import mmr
     from oracle import grad_torch as G

@@ -54,5 +54,17 @@ def main():
     print(f"flow head fwd bf16 C2: {t:.3f} ms  ({xb.numel() * 2 / 1e9 / t * 1e3:.0f} GB/s read)")
 
 
+def compose_bwd_times():
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(1)
+    for sc in (0.01, 0.5, 2.0):
+        v = torch.randn((1, 80, 80, 80, 3), device=dev, generator=g) * sc
+        go = torch.randn((1, 80, 80, 80, 3), device=dev, generator=g)
+        out, steps = ops.vecint_save(v, 5)
+        t = timeit(lambda: ops.vecint_bwd(v, steps, go, 5))
+        print(f"vecint_bwd 80^3, 5 steps, velocity std {sc}: {t:.3f} ms")
+
+
 if __name__ == "__main__":
+    compose_bwd_times()
     main()
