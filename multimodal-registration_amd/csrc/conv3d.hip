@@ -198,6 +198,10 @@ conv3d_k3_kernel(const ConvParams p)
     // VAR bits 9 + 13: the two mid-stream issue points of MIDDMA, both used by waves 0-3 only (their own pieces at the
     // first, the pieces of wave w + 4 at the second); waves 4-7 never issue
     constexpr bool MIDOLD = MIDDMA && ((VAR >> 13) & 1);
+    // VAR bit 14 (64-column tile only: four 8-KB weight buffers fit beside the A tile): TWO taps per barrier interval.  The
+    // stamps of the fp32x3 training conv show ~390 clk per tap of 2 380 at the top-of-tap DMA issue, the vmcnt(0) and the
+    // barrier, against 48 MFMAs per wave: pairs (0,1) .. (24,25), then tap 26 alone in front of the A restage.
+    constexpr bool PAIR = ((VAR >> 14) & 1) != 0;
     unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = 0;
     static_assert(WM * WN == 8, "8 waves");
     static_assert(TXT == 4 || TXT == 8, "M tile");
@@ -206,6 +210,7 @@ conv3d_k3_kernel(const ConvParams p)
     constexpr int KC = Elt<DT>::kc;
     constexpr int B_BYTES = BN * 128;
     constexpr int B_ITERS = B_BYTES / (CONV_THREADS * 16);
+    static_assert(!PAIR || (A_BYTES_T + 4 * B_BYTES <= 160 * 1024 && !MIDDMA && !SPLITDMA), "PAIR: LDS budget / DMA placement");
     constexpr int A_ITERS = (((DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) ? HROWS_T * 4 : HROWS_T * 8) + CONV_THREADS - 1) / CONV_THREADS;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -419,6 +424,9 @@ conv3d_k3_kernel(const ConvParams p)
     const int g1 = p.kpart ? min(g0 + p.gsplit, G) : G;
     int cur = 0, tap = g0 % 27, s = g0 / 27;
     issue_b(g0, 0);
+    if constexpr (PAIR) {
+        if (tap < 26 && g0 + 1 < g1) issue_b(g0 + 1, 1);
+    }
     // a macro, not a lambda: wrapped in one more closure, hipcc no longer scalarises the by-value kernel argument
     // struct and every instantiation reads ConvParams from scratch (288 B/lane; the bn64 convs ran 1.8x slower)
     // named scalars, not an array: an indexed array of structs stays in scratch here even when unrolled
@@ -468,21 +476,33 @@ conv3d_k3_kernel(const ConvParams p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    for (int g = g0; g < g1; ++g) {
-        const bool more = g + 1 < g1;
+    for (int g = g0; g < g1;) {
+        int ntap = 1;                                  // taps of this barrier interval
+        if constexpr (PAIR) ntap = (tap < 26 && g + 1 < g1) ? 2 : 1;
+        const int gn = g + ntap;                       // first tap of the next interval
+        const bool more = gn < g1;
         if constexpr (STAMP) st_t = stamp_now();
         if constexpr (ALLOLD) {
         } else if constexpr (SPLITDMA) {
             if (more && wave >= 4) issue_b(g + 1, cur ^ 1);
+        } else if constexpr (PAIR) {
+            if (more) {
+                const int tapn = (tap + ntap == 27) ? 0 : tap + ntap;
+                issue_b(gn, (cur ^ 1) * 2);
+                if (tapn < 26 && gn + 1 < g1) issue_b(gn + 1, (cur ^ 1) * 2 + 1);
+            }
         } else if constexpr (!MIDDMA) {
             if (more) issue_b(g + 1, cur ^ 1);
         }
         if constexpr (STAMP) { const unsigned long long t = stamp_now(); st_acc[0] += t - st_t; st_t = t; }
-        const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+#pragma unroll 1
+        for (int jt = 0; jt < ntap; ++jt) {
+        const int tpj = tap + jt;
+        const int dx = tpj / 9, dy = (tpj / 3) % 3, dz = tpj % 3;
         const int tapoff = (dx * (HY * HZ) + dy * HZ + dz) * ROWB;
         const int sw = (swz(vyl + dy, vz + dz) ^ h) << 4;
         const char* bA = sA + tapoff;
-        const char* bB = sB + cur * B_BYTES;
+        const char* bB = sB + (PAIR ? cur * 2 + jt : cur) * B_BYTES;
         if constexpr (M16) {
             const int sw16 = swz16((r16 & 7) + dz);
             if constexpr (X3 && PIPE3) {
@@ -715,6 +735,7 @@ conv3d_k3_kernel(const ConvParams p)
             }
         }
         }
+        }   // jt
         if constexpr (SPLITDMA) {
             if (more && wave < 4) {
                 issue_b(g + 1, cur ^ 1);
@@ -725,12 +746,14 @@ conv3d_k3_kernel(const ConvParams p)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA of tap g+1 has landed (this wave's share)
         if constexpr (STAMP) { const unsigned long long t = stamp_now(); st_acc[2] += t - st_t; st_t = t; }
         __syncthreads();                                  // ... everyone's has; buffer `cur` is free
-        if constexpr (STAMP) { const unsigned long long t = stamp_now(); st_acc[3] += t - st_t; st_t = t; st_acc[5] += 1; }
+        if constexpr (STAMP) { const unsigned long long t = stamp_now(); st_acc[3] += t - st_t; st_t = t; st_acc[5] += ntap; }
         cur ^= 1;
-        if (++tap == 27) {
+        tap += ntap;
+        g = gn;
+        if (tap == 27) {
             tap = 0;
             ++s;
-            if (s < nslices && g + 1 < g1) {  // every wave is past its last read of sA: install the next slice
+            if (s < nslices && g < g1) {  // every wave is past its last read of sA: install the next slice
                 if constexpr (DMA_A) {
                     dma_stage_a(s);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1045,7 +1068,7 @@ int launch_conv(const ConvParams& p, int ntiles_n, hipStream_t st, int64_t* nblk
 {
     constexpr int BN = WN * NT * 32;
     constexpr int TXT = WM * MT * 32 / (TY * TZ);
-    constexpr int LDS = (TXT + 2) * HY * HZ * ROWB + 2 * BN * 128;
+    constexpr int LDS = (TXT + 2) * HY * HZ * ROWB + ((((VAR >> 14) & 1) != 0) ? 4 : 2) * BN * 128;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     auto kern = conv3d_k3_kernel<DT, WM, WN, MT, NT, VAR>;
@@ -1125,6 +1148,8 @@ int dispatch_conv(const ConvParams& p, hipStream_t st, int64_t* nblk_out = nullp
             if (var == 4512) return launch_conv<DT, 8, 1, 2, 2, 4512>(p, nt, st, nblk_out);  // 416 + batched branch-free A staging
             if (var == 5536) return launch_conv<DT, 8, 1, 2, 2, 5536>(p, nt, st, nblk_out);  // 4512 + cycle stamps (diagnostic)
             if (var == 416) return launch_conv<DT, 8, 1, 2, 2, 416>(p, nt, st, nblk_out);    // round-1 default
+            if (var == 20896) return launch_conv<DT, 8, 1, 2, 2, 20896>(p, nt, st, nblk_out); // 4512 + two taps per barrier
+            if (var == 21920) return launch_conv<DT, 8, 1, 2, 2, 21920>(p, nt, st, nblk_out); // 20896 + cycle stamps (diagnostic)
             // fp32x3 / x1: batched branch-free A staging (-5 % on the C3 training convs); bf16 / exact fp32 stage A by DMA
             return launch_conv<DT, 8, 1, 2, 2, 4512>(p, nt, st, nblk_out);
         default: return launch_conv<DT, 8, 1, 2, 1, 256>(p, nt, st, nblk_out);

@@ -401,7 +401,7 @@ ncc_fused_kernel(const float* __restrict__ I, const float* __restrict__ J, doubl
         rmask[r] = in ? 1.f : 0.f;
         roff[r] = in ? y * Z + z : 0;
     }
-    float ra[9][NF_RPW], rc[9][NF_RPW];                     // raw ring, slot 8 = newest plane
+    float ra[9][NF_RPW], rc[9][NF_RPW];                     // raw ring of the last 9 planes, plane s in slot s % 9
 #pragma unroll
     for (int k = 0; k < 9; ++k)
 #pragma unroll
@@ -428,26 +428,32 @@ ncc_fused_kernel(const float* __restrict__ I, const float* __restrict__ J, doubl
     for (int r = 0; r < NF_RPW; ++r)
 #pragma unroll
         for (int q = 0; q < 5; ++q) W[r][q] = 0.f;
+    int slot = 0;                                           // ring slot of plane s = s % 9: the slot the leaving plane holds
     for (int s = 0; s < nstep; ++s) {
-        // slide the window sums (the leaving plane is ring slot 0), rotate the ring, take the prefetched plane
-        const bool refresh = (s - 8) % 9 == 0;              // s = 8, 17, 26, ...: exact re-sum instead (uniform)
-        if (s > 8 && !refresh) {
-#pragma unroll
-            for (int r = 0; r < NF_RPW; ++r) {
-                const float a = pa[r], c = pc[r], ao = ra[0][r], co = rc[0][r];
-                W[r][0] += a - ao;
-                W[r][1] += c - co;
-                W[r][2] += a * a - ao * ao;
-                W[r][3] += c * c - co * co;
-                W[r][4] += a * c - ao * co;
-            }
+        // slide the window sums (the leaving plane sits in the slot the new one takes) and take the prefetched plane.
+        // The ring is addressed through a uniform switch over the slot: every case names its registers statically, so the
+        // ring never moves (rotating it cost 80 v_mov per plane and wave).
+        const bool refresh = slot == 8;                     // s = 8, 17, 26, ...: exact re-sum instead (uniform)
+#define MMR_NCC_SLOT(K)                                                                       \
+    case K: {                                                                                 \
+        if (s > 8 && K != 8) {                                                                \
+            _Pragma("unroll") for (int r = 0; r < NF_RPW; ++r) {                              \
+                const float a = pa[r], c = pc[r], ao = ra[K][r], co = rc[K][r];               \
+                W[r][0] += a - ao;                                                            \
+                W[r][1] += c - co;                                                            \
+                W[r][2] += a * a - ao * ao;                                                   \
+                W[r][3] += c * c - co * co;                                                   \
+                W[r][4] += a * c - ao * co;                                                   \
+            }                                                                                 \
+        }                                                                                     \
+        _Pragma("unroll") for (int r = 0; r < NF_RPW; ++r) { ra[K][r] = pa[r]; rc[K][r] = pc[r]; } \
+    } break;
+        switch (slot) {
+            MMR_NCC_SLOT(0) MMR_NCC_SLOT(1) MMR_NCC_SLOT(2) MMR_NCC_SLOT(3) MMR_NCC_SLOT(4)
+            MMR_NCC_SLOT(5) MMR_NCC_SLOT(6) MMR_NCC_SLOT(7) MMR_NCC_SLOT(8)
         }
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-#pragma unroll
-            for (int r = 0; r < NF_RPW; ++r) { ra[k][r] = ra[k + 1][r]; rc[k][r] = rc[k + 1][r]; }
-#pragma unroll
-        for (int r = 0; r < NF_RPW; ++r) { ra[8][r] = pa[r]; rc[8][r] = pc[r]; }
+#undef MMR_NCC_SLOT
+        slot = slot == 8 ? 0 : slot + 1;
         {
             const int xn = xi0 + s + 1;
             const bool xin = xn >= 0 && xn < X;             // the plane after the last step is loaded but never used
@@ -581,29 +587,35 @@ bending_fused_kernel(const float* __restrict__ u, double* __restrict__ part, int
         load_plane(p1, xa);
         load_plane(p2, xa + 1);
         const bool zout = lane >= 1 && lane <= BF_ZOUT && z <= Z - 2;
-        for (int x = xa; x < xb; ++x) {
-            load_plane(pn, (x + 2 < X) ? x + 2 : X - 1);     // one plane ahead of the stencil: its latency hides under this step
+        // one stencil step on planes (q0, q1, q2) = x - 1, x, x + 1 while plane x + 2 lands in qn.  The x loop is unrolled by
+        // four with the plane names rotated, so the four plane sets never move (rotating them cost 54 v_mov per step).
+        auto step = [&](const F3* q0, const F3* q1, const F3* q2, F3* qn, int x) {
+            load_plane(qn, (x + 2 < X) ? x + 2 : X - 1);     // one plane ahead of the stencil: its latency hides under this step
 #pragma unroll
             for (int j = 0; j < BF_R; ++j) {
                 float e = 0.f;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const float c0 = p1[j + 1].v[k];
-                    const float dxx = p2[j + 1].v[k] - 2.f * c0 + p0[j + 1].v[k];
-                    const float dyy = p1[j + 2].v[k] - 2.f * c0 + p1[j].v[k];
+                    const float c0 = q1[j + 1].v[k];
+                    const float dxx = q2[j + 1].v[k] - 2.f * c0 + q0[j + 1].v[k];
+                    const float dyy = q1[j + 2].v[k] - 2.f * c0 + q1[j].v[k];
                     const float dzz = wave_shl1(c0) - 2.f * c0 + wave_shr1(c0);
-                    const float dxy = (p2[j + 2].v[k] - p2[j].v[k] - p0[j + 2].v[k] + p0[j].v[k]) * 0.25f;
+                    const float dxy = (q2[j + 2].v[k] - q2[j].v[k] - q0[j + 2].v[k] + q0[j].v[k]) * 0.25f;
                     // mixed z differences: difference across x (or y) first, then ONE pair of lane shifts of it
-                    const float dx = p2[j + 1].v[k] - p0[j + 1].v[k];
-                    const float dy = p1[j + 2].v[k] - p1[j].v[k];
+                    const float dx = q2[j + 1].v[k] - q0[j + 1].v[k];
+                    const float dy = q1[j + 2].v[k] - q1[j].v[k];
                     const float dxz = (wave_shl1(dx) - wave_shr1(dx)) * 0.25f;
                     const float dyz = (wave_shl1(dy) - wave_shr1(dy)) * 0.25f;
                     e += dxx * dxx + dyy * dyy + dzz * dzz + 2.f * (dxy * dxy + dxz * dxz + dyz * dyz);
                 }
                 if (zout && (yh0 + 1 + j) <= Y - 2) acc += e;
             }
-#pragma unroll
-            for (int r = 0; r < BF_R + 2; ++r) { p0[r] = p1[r]; p1[r] = p2[r]; p2[r] = pn[r]; }
+        };
+        for (int x = xa; x < xb; x += 4) {
+            step(p0, p1, p2, pn, x);
+            if (x + 1 < xb) step(p1, p2, pn, p0, x + 1);
+            if (x + 2 < xb) step(p2, pn, p0, p1, x + 2);
+            if (x + 3 < xb) step(pn, p0, p1, p2, x + 3);
         }
     }
     const double r = block_sum((double)acc, sh);
