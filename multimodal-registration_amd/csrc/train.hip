@@ -282,17 +282,38 @@ resize_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int B
         axis_range(z, stz, Zo, z0, z1);
         const float* src = dout + b * nvo * C + c;
         float acc = 0.f;
-        for (int ix = x0; ix <= x1; ++ix) {
-            const float wx = axis_weight(ix, stx, X - 1, x);
-            if (wx == 0.f) continue;
-            for (int iy = y0; iy <= y1; ++iy) {
-                const float wy = axis_weight(iy, sty, Y - 1, y);
-                if (wy == 0.f) continue;
-                const float wxy = wx * wy;
-                const float* row = src + ((int64_t)ix * Yo + iy) * Zo * C;
-                for (int iz = z0; iz <= z1; ++iz) {
-                    const float wz = axis_weight(iz, stz, Z - 1, z);
-                    if (wz != 0.f) acc += (wxy * wz) * (row[(int64_t)iz * C] * mul);
+        constexpr int RW = 10;   // candidates per axis for factors down to 1/2 (8); longer ranges take the generic loop
+        if (z1 - z0 < RW) {
+            // the z weights do not depend on (ix, iy): once per thread, in registers (they were re-derived per row)
+            float wzv[RW];
+#pragma unroll
+            for (int k = 0; k < RW; ++k) wzv[k] = (z0 + k <= z1) ? axis_weight(z0 + k, stz, Z - 1, z) : 0.f;
+            for (int ix = x0; ix <= x1; ++ix) {
+                const float wx = axis_weight(ix, stx, X - 1, x);
+                if (wx == 0.f) continue;
+                for (int iy = y0; iy <= y1; ++iy) {
+                    const float wy = axis_weight(iy, sty, Y - 1, y);
+                    if (wy == 0.f) continue;
+                    const float wxy = wx * wy;
+                    const float* row = src + (((int64_t)ix * Yo + iy) * Zo + z0) * C;
+#pragma unroll
+                    for (int k = 0; k < RW; ++k)
+                        if (wzv[k] != 0.f) acc += (wxy * wzv[k]) * (row[(int64_t)k * C] * mul);
+                }
+            }
+        } else {
+            for (int ix = x0; ix <= x1; ++ix) {
+                const float wx = axis_weight(ix, stx, X - 1, x);
+                if (wx == 0.f) continue;
+                for (int iy = y0; iy <= y1; ++iy) {
+                    const float wy = axis_weight(iy, sty, Y - 1, y);
+                    if (wy == 0.f) continue;
+                    const float wxy = wx * wy;
+                    const float* row = src + ((int64_t)ix * Yo + iy) * Zo * C;
+                    for (int iz = z0; iz <= z1; ++iz) {
+                        const float wz = axis_weight(iz, stz, Z - 1, z);
+                        if (wz != 0.f) acc += (wxy * wz) * (row[(int64_t)iz * C] * mul);
+                    }
                 }
             }
         }
@@ -982,7 +1003,8 @@ __device__ __forceinline__ unsigned long long wstamp_now()
 // FULLCO: Cout is a multiple of 64, every float4 of dZ exists -> one branch-free load path.  (With the tail path compiled
 // into the same kernel behind a wave-uniform branch, hipcc put `s_waitcnt vmcnt(0)` in front of every dZ load at the
 // join of the two paths: 8 more dependent round trips per tile.)
-template <int COT, bool LO, bool STAMP = false, int PF = 3, bool FULLCO = false, bool BUF = false>
+template <int N> struct IC { static constexpr int value = N; };
+template <int COT, bool LO, bool STAMP = false, int PF = 3, bool FULLCO = false, bool BUF = false, bool SPREAD = false>
 __global__ void __launch_bounds__(W_THREADS, 2)
 wgrad_x3_kernel(const WgradParams p)
 {
@@ -1237,21 +1259,38 @@ wgrad_x3_kernel(const WgradParams p)
         __syncthreads();
         if constexpr (STAMP) { const unsigned long long t = wstamp_now(); st_acc[1] += t - st_t; st_t = t; }
         const int nxt = tile + gridDim.x;
-        if (nxt < p.ntiles) {
-            const int tv = opaque_tid();
-            int b, x0, y0, z0;
-            tile_origin(nxt, b, x0, y0, z0);
-            if constexpr (PFX) {
+        // SPREAD (opt-in, MMR_WGRAD_SPREAD=1; measured, not faster): the next tile's loads issued in four groups between the
+        // quarters of the k-loop instead of in one burst in front of it.  The burst takes 2.8 - 3.9 k cycles per tile with the
+        // matrix cores idle (141 KB per workgroup through a 64 B/clk address path; tools/wgrad_stamps.py, "issue next loads").
+        // Spread out, the issue phase drops to 0.35 - 0.67 k but the k-loop grows by 2.6 - 3.1 k: its 32 transposing LDS reads
+        // per k-block and the returning global loads compete for the same VGPR write path, and the four loop entries each
+        // expose an LDS round trip.  Net: 2.74 ms either way for the 64 -> 64 layer at 160^3 against 2.58 ms for the burst
+        // in front of one 16-iteration loop.
+        int nb = 0, nx0 = 0, ny0 = 0, nz0 = 0;
+        if (nxt < p.ntiles) tile_origin(nxt, nb, nx0, ny0, nz0);
+        auto issue_group = [&](auto gc) {
+            constexpr int GQ = decltype(gc)::value;          // 0, 1: X items; 2, 3: dZ items
+            if (nxt < p.ntiles) {
+                const int tv2 = opaque_tid();
+                if constexpr (GQ < 2 && PFX) {
+                    constexpr int A0 = GQ == 0 ? 0 : (A_IT + 1) / 2, A1 = GQ == 0 ? (A_IT + 1) / 2 : A_IT;
 #pragma unroll
-                for (int it = 0; it < A_IT; ++it) px[it] = load_x(tv, b, x0, y0, z0, it);
-            }
-            if constexpr (PFZ) {
+                    for (int it = A0; it < A1; ++it) px[it] = load_x(tv2, nb, nx0, ny0, nz0, it);
+                }
+                if constexpr (GQ >= 2 && PFZ) {
+                    constexpr int B0 = GQ == 2 ? 0 : (B_IT + 1) / 2, B1 = GQ == 2 ? (B_IT + 1) / 2 : B_IT;
 #pragma unroll
-                for (int it = 0; it < B_IT; ++it) pz[it] = load_z(tv, b, x0, y0, z0, it);
+                    for (int it = B0; it < B1; ++it) pz[it] = load_z(tv2, nb, nx0, ny0, nz0, it);
+                }
             }
+        };
+        if constexpr (!SPREAD) {
+            issue_group(IC<0>{}); issue_group(IC<1>{}); issue_group(IC<2>{}); issue_group(IC<3>{});
         }
         if constexpr (STAMP) { const unsigned long long t = wstamp_now(); st_acc[2] += t - st_t; st_t = t; }
-        for (int kb = 0; kb < 16; ++kb) {  // 16 voxels per k-block: (vx = kb>>2, vy = (kb&3)*2 + {0,1}, vz = 0..7)
+        auto k_range = [&](int k0, int k1) {
+#pragma unroll 1
+        for (int kb = k0; kb < k1; ++kb) {  // 16 voxels per k-block: (vx = kb>>2, vy = (kb&3)*2 + {0,1}, vz = 0..7)
             const char* xa = sX + ((kb >> 2) * (W_HY * W_HZ) + (kb & 3) * 2 * W_HZ) * 128;
             const char* zb = sZ + kb * 16 * 256;
             const bf16x8_t b_hi = frag8(tr_read(zb + laneBh[0]), tr_read(zb + laneBh[1]));
@@ -1275,6 +1314,15 @@ wgrad_x3_kernel(const WgradParams p)
                 MMR_WG(1); MMR_WG(1); MMR_WG(1); MMR_WG(1); MMR_WG(1); MMR_WG(0); MMR_WG(0);
 #undef MMR_WG
             }
+        }
+        };
+        if constexpr (SPREAD) {
+            issue_group(IC<0>{}); k_range(0, 4);
+            issue_group(IC<1>{}); k_range(4, 8);
+            issue_group(IC<2>{}); k_range(8, 12);
+            issue_group(IC<3>{}); k_range(12, 16);
+        } else {
+            k_range(0, 16);
         }
         if constexpr (STAMP) { const unsigned long long t = wstamp_now(); st_acc[3] += t - st_t; st_acc[4] += 1; }
     }
@@ -2588,7 +2636,9 @@ static int wgrad_impl(const float* in0, int C0, int up0, const float* in1, int C
                                 reinterpret_cast<const void*>(wgrad_x3_kernel<2, false, false, 3, true>),
                                 reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, false, 3, true, true>),
                                 reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, true, 3, true, true>),
-                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, false, false, 3, true, true>)};
+                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, false, false, 3, true, true>),
+                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, false, 3, true, true, true>),
+                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, true, 3, true, true, true>)};
             for (size_t i = 0; i < sizeof(ks) / sizeof(ks[0]); ++i) {
                 hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDSX);
                 if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
@@ -2600,11 +2650,14 @@ static int wgrad_impl(const float* in0, int C0, int up0, const float* in1, int C
             static const bool stamp = getenv("MMR_WGRAD_STAMP") != nullptr;   // diagnostic build, tools/wgrad_stamps.py
             static const int pf = getenv("MMR_WGRAD_PF") ? atoi(getenv("MMR_WGRAD_PF")) : 3;   // A/B knob
             const bool fullco = (Cout % 64) == 0;
+            static const bool spread = getenv("MMR_WGRAD_SPREAD") != nullptr;   // A/B knob: next tile's loads spread over the k-loop
             if (Cout <= 32) hipLaunchKernelGGL((wgrad_x3_kernel<1, true>), g3, b3, LDSX, as_stream(stream), p);
+            else if (fullco && stamp && usebuf && spread) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, true, 3, true, true, true>), g3, b3, LDSX, as_stream(stream), p);
             else if (fullco && stamp && usebuf) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, true, 3, true, true>), g3, b3, LDSX, as_stream(stream), p);
             else if (fullco && stamp) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, true, 3, true>), g3, b3, LDSX, as_stream(stream), p);
             else if (fullco && pf == 2) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 2, true>), g3, b3, LDSX, as_stream(stream), p);
             else if (fullco && pf == 0) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 0, true>), g3, b3, LDSX, as_stream(stream), p);
+            else if (fullco && usebuf && spread && pf == 3) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 3, true, true, true>), g3, b3, LDSX, as_stream(stream), p);
             else if (fullco && usebuf) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 3, true, true>), g3, b3, LDSX, as_stream(stream), p);
             else if (fullco) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 3, true>), g3, b3, LDSX, as_stream(stream), p);
             else if (stamp && pf == 3) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, true, 3>), g3, b3, LDSX, as_stream(stream), p);
