@@ -202,6 +202,14 @@ conv3d_k3_kernel(const ConvParams p)
     // stamps of the fp32x3 training conv show ~390 clk per tap of 2 380 at the top-of-tap DMA issue, the vmcnt(0) and the
     // barrier, against 48 MFMAs per wave: pairs (0,1) .. (24,25), then tap 26 alone in front of the A restage.
     constexpr bool PAIR = ((VAR >> 14) & 1) != 0;
+    // VAR bit 15: static priority for the younger half of the workgroup (waves 4-7: s_setprio 1 once, in front of the loop).
+    // VAR bit 16 (with 15): the older half starts every tap at priority 2 and drops to 0 after half of its MFMAs, so that
+    // the matrix pipe goes to the older wave of a SIMD first and to the younger one second and both reach the barrier
+    // together (by age alone the older wave finishes ~700 clk early and the younger one then runs alone at 22 instead of
+    // 16 clk per MFMA).
+    constexpr bool PRIO_Y = ((VAR >> 15) & 1) != 0;
+    constexpr bool PRIO_SW = PRIO_Y && ((VAR >> 16) & 1) != 0;
+    constexpr bool PRIO_EARLY = ((VAR >> 17) & 1) != 0;   // main conv: switch at the first DMA issue point instead of the second
     unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = 0;
     static_assert(WM * WN == 8, "8 waves");
     static_assert(TXT == 4 || TXT == 8, "M tile");
@@ -475,12 +483,18 @@ conv3d_k3_kernel(const ConvParams p)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if constexpr (PRIO_Y) {
+        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    }
 
     for (int g = g0; g < g1;) {
         int ntap = 1;                                  // taps of this barrier interval
         if constexpr (PAIR) ntap = (tap < 26 && g + 1 < g1) ? 2 : 1;
         const int gn = g + ntap;                       // first tap of the next interval
         const bool more = gn < g1;
+        if constexpr (PRIO_SW) {
+            if (wave < 4) __builtin_amdgcn_s_setprio(2);
+        }
         if constexpr (STAMP) st_t = stamp_now();
         if constexpr (ALLOLD) {
         } else if constexpr (SPLITDMA) {
@@ -537,12 +551,29 @@ conv3d_k3_kernel(const ConvParams p)
                     for (int ni = 0; ni < 4; ++ni)
                         acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             __builtin_bit_cast(bf16x8, bh16[ni]), __builtin_bit_cast(bf16x8, ah16[mi]), acc16[mi][ni], 0, 0, 0);
+                    if constexpr (PRIO_SW) {
+                        if (mi == MT - 1) {   // half of this tap's MFMAs issued: the partner wave goes first from here on
+                            constexpr int NA1 = LO ? 2 : 1, NM1 = LO ? 12 : 4;
+                            __builtin_amdgcn_sched_group_barrier(0x100, 4 * NA1 + 2 * NA1, 0);
+                            if constexpr (MT == 4) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, NM1, 0); __builtin_amdgcn_sched_group_barrier(0x100, NA1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x008, NM1, 0); __builtin_amdgcn_sched_group_barrier(0x100, NA1, 0);
+                            }
+                            __builtin_amdgcn_sched_group_barrier(0x008, NM1, 0); __builtin_amdgcn_sched_group_barrier(0x100, NA1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, NM1, 0); __builtin_amdgcn_sched_group_barrier(0x100, NA1, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (wave < 4) __builtin_amdgcn_s_setprio(0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
                 }
                 constexpr int NA = LO ? 2 : 1, NM = LO ? 12 : 4;
-                __builtin_amdgcn_sched_group_barrier(0x100, 4 * NA + 2 * NA, 0);
 #define MMR_GRP3(rd) __builtin_amdgcn_sched_group_barrier(0x008, NM, 0); if (rd) __builtin_amdgcn_sched_group_barrier(0x100, NA, 0)
-                if constexpr (MT == 4) { MMR_GRP3(1); MMR_GRP3(1); MMR_GRP3(1); MMR_GRP3(1); }
-                MMR_GRP3(1); MMR_GRP3(1); MMR_GRP3(0); MMR_GRP3(0);
+                if constexpr (!PRIO_SW) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4 * NA + 2 * NA, 0);
+                    if constexpr (MT == 4) { MMR_GRP3(1); MMR_GRP3(1); MMR_GRP3(1); MMR_GRP3(1); }
+                    MMR_GRP3(1); MMR_GRP3(1); MMR_GRP3(0); MMR_GRP3(0);
+                }
 #undef MMR_GRP3
             } else if constexpr (X3) {
                 // one 32-channel k-step per tap: chunks 0..3 = hi, 4..7 = lo
@@ -601,6 +632,9 @@ conv3d_k3_kernel(const ConvParams p)
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 if (more && wave < 4) issue_b(g + 1, cur ^ 1);
+                if constexpr (PRIO_SW && PRIO_EARLY) {
+                    if (wave < 4) __builtin_amdgcn_s_setprio(0);   // 16 of 64 MFMAs issued: the partner wave goes first from here on
+                }
 #pragma unroll
                 for (int i = 12; i < 21; ++i) rd(i);
 #pragma unroll
@@ -615,6 +649,11 @@ conv3d_k3_kernel(const ConvParams p)
                     if (more && wave < 4) issue_b(g + 1, cur ^ 1, wave + 4);
                 } else {
                     if (more && wave >= 4) issue_b(g + 1, cur ^ 1);
+                }
+                if constexpr (PRIO_SW && !PRIO_EARLY) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (wave < 4) __builtin_amdgcn_s_setprio(0);   // 40 of 64 MFMAs issued
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int i = 21; i < 24; ++i) rd(i);
@@ -1002,7 +1041,7 @@ __host__ __device__ inline int conv_cout_of_col(int col)
 
 template <int DT>
 __global__ void pack_kernel(const float* __restrict__ w, char* __restrict__ wp, int Cin, int Cout, int BN, int ntiles,
-                            int transpose_flip)
+                            int transpose_flip, int plain_cols)
 {
     constexpr int KC = Elt<DT>::kc;
     constexpr int EPC = (DT == MMR_DT_F32) ? 4 : 8;  // elements per 16-B chunk (fp32x3 chunks hold 8 bf16)
@@ -1015,7 +1054,7 @@ __global__ void pack_kernel(const float* __restrict__ w, char* __restrict__ wp, 
         const int tap = (int)(r % 27); r /= 27;
         const int s = (int)(r % nslices);
         const int t = (int)(r / nslices);
-        const int co = t * BN + (conv_uses_m16(DT, BN) ? conv_cout_of_col(col) : col);
+        const int co = t * BN + ((conv_uses_m16(DT, BN) && !plain_cols) ? conv_cout_of_col(col) : col);
         char* dst = wp + i * 16;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
@@ -1125,6 +1164,9 @@ int dispatch_conv(const ConvParams& p, hipStream_t st, int64_t* nblk_out = nullp
             if (var == 1440) return launch_conv<DT, 2, 4, 4, 2, 1440>(p, nt, st, nblk_out); // 416 + cycle stamps (diagnostic)
             if (var == 3488) return launch_conv<DT, 2, 4, 4, 2, 3488>(p, nt, st, nblk_out); // 2464 + cycle stamps (diagnostic)
             if (var == 10656) return launch_conv<DT, 2, 4, 4, 2, 10656>(p, nt, st, nblk_out); // 2464 + all weight DMA by waves 0-3
+            if (var == 41888) return launch_conv<DT, 2, 4, 4, 2, 41888>(p, nt, st, nblk_out); // default + static priority 1 for waves 4-7
+            if (var == 107424) return launch_conv<DT, 2, 4, 4, 2, 107424>(p, nt, st, nblk_out); // + waves 0-3: priority 2 until MFMA 40 of 64, then 0
+            if (var == 238496) return launch_conv<DT, 2, 4, 4, 2, 238496>(p, nt, st, nblk_out); // + waves 0-3: priority 2 until MFMA 16 of 64, then 0
             if (var == 11680) return launch_conv<DT, 2, 4, 4, 2, 11680>(p, nt, st, nblk_out); // 10656 + cycle stamps (diagnostic)
             // default: the weight DMA of the next tap is issued by waves 0-3 only, from two points inside their MFMA stream
             // (after MFMA groups 4 and 10 of 16: own pieces, then the pieces of wave w + 4); waves 4-7 never issue.
@@ -1138,6 +1180,7 @@ int dispatch_conv(const ConvParams& p, hipStream_t st, int64_t* nblk_out = nullp
                 return launch_conv<DT, 4, 2, 4, 2, 32>(p, nt, st, nblk_out);
             if (var == 2464) return launch_conv<DT, 4, 2, 4, 2, 2464>(p, nt, st, nblk_out);
             if (var == 416) return launch_conv<DT, 4, 2, 4, 2, 416>(p, nt, st, nblk_out);   // round-1 default
+            if (var == 37280 || var == 41888) return launch_conv<DT, 4, 2, 4, 2, 37280>(p, nt, st, nblk_out);  // + static priority 1 for waves 4-7
             // fp32x3 / x1 / exact fp32: 416 + batched branch-free A staging (-2.3 % on the C3 dgrad convs, same-box A/B)
             return launch_conv<DT, 4, 2, 4, 2, 4512>(p, nt, st, nblk_out);
         case 64:
@@ -1148,10 +1191,18 @@ int dispatch_conv(const ConvParams& p, hipStream_t st, int64_t* nblk_out = nullp
             if (var == 4512) return launch_conv<DT, 8, 1, 2, 2, 4512>(p, nt, st, nblk_out);  // 416 + batched branch-free A staging
             if (var == 5536) return launch_conv<DT, 8, 1, 2, 2, 5536>(p, nt, st, nblk_out);  // 4512 + cycle stamps (diagnostic)
             if (var == 416) return launch_conv<DT, 8, 1, 2, 2, 416>(p, nt, st, nblk_out);    // round-1 default
+            if (var == 4096 && DT != MMR_DT_BF16) return launch_conv<DT, 8, 1, 2, 2, 4096>(p, nt, st, nblk_out);  // 32x32x16 MFMA + batched A staging
+            if (var == 53664) return launch_conv<DT, 8, 1, 2, 2, 53664>(p, nt, st, nblk_out);   // 37280 + two taps per barrier
+            if (var == 37280 || var == 41888) return launch_conv<DT, 8, 1, 2, 2, 37280>(p, nt, st, nblk_out);   // 4512 + static priority 1 for waves 4-7
+            if (var == 102816) return launch_conv<DT, 8, 1, 2, 2, 102816>(p, nt, st, nblk_out); // + older half 2 -> 0 at mid-tap
+            if (var == 103840) return launch_conv<DT, 8, 1, 2, 2, 103840>(p, nt, st, nblk_out); // 102816 + cycle stamps (diagnostic)
             if (var == 20896) return launch_conv<DT, 8, 1, 2, 2, 20896>(p, nt, st, nblk_out); // 4512 + two taps per barrier
             if (var == 21920) return launch_conv<DT, 8, 1, 2, 2, 21920>(p, nt, st, nblk_out); // 20896 + cycle stamps (diagnostic)
-            // fp32x3 / x1: batched branch-free A staging (-5 % on the C3 training convs); bf16 / exact fp32 stage A by DMA
-            return launch_conv<DT, 8, 1, 2, 2, 4512>(p, nt, st, nblk_out);
+            // fp32x3 / x1: batched branch-free A staging (-5 % on the C3 training convs) + static priority 1 for waves 4-7
+            // (-1 %: 2.445 / 2.463 vs 2.475 / 2.487 ms on the 64 -> 64 layer at 160^3, alternated on one box; the same bit costs
+            // the 256-column bf16 tile +14 %, whose weight DMA is issued by waves 0-3 from inside their MFMA stream, and
+            // nothing on the 128-column tile); bf16 / exact fp32 stage A by DMA
+            return launch_conv<DT, 8, 1, 2, 2, 37280>(p, nt, st, nblk_out);
         default: return launch_conv<DT, 8, 1, 2, 1, 256>(p, nt, st, nblk_out);
     }
 }
@@ -1919,15 +1970,18 @@ extern "C" int mmr_conv3d_k3_pack(const float* w_keras, void* w_packed, int Cin,
     const int BN = conv_bn(Cout);
     const int nt = (Cout + BN - 1) / BN;
     const int grid = stream_grid(bytes / 16, 256);
+    // A/B runs of the 32x32x16 instantiation of the 64-column fp32x3 tile (MMR_CONV_VARIANT=4096) need unpermuted columns
+    static const bool plain64 = getenv("MMR_CONV_VARIANT") && atoi(getenv("MMR_CONV_VARIANT")) == 4096;
+    const int plain = (plain64 && BN == 64 && dtype != MMR_DT_BF16) ? 1 : 0;
     if (dtype == MMR_DT_BF16)
         hipLaunchKernelGGL(pack_kernel<MMR_DT_BF16>, dim3(grid), dim3(256), 0, as_stream(stream), w_keras,
-                           (char*)w_packed, Cin, Cout, BN, nt, transpose_flip);
+                           (char*)w_packed, Cin, Cout, BN, nt, transpose_flip, 0);
     else if (dtype == MMR_DT_F32X3 || dtype == MMR_DT_F32X1)
         hipLaunchKernelGGL(pack_kernel<MMR_DT_F32X3>, dim3(grid), dim3(256), 0, as_stream(stream), w_keras,
-                           (char*)w_packed, Cin, Cout, BN, nt, transpose_flip);
+                           (char*)w_packed, Cin, Cout, BN, nt, transpose_flip, plain);
     else
         hipLaunchKernelGGL(pack_kernel<MMR_DT_F32>, dim3(grid), dim3(256), 0, as_stream(stream), w_keras,
-                           (char*)w_packed, Cin, Cout, BN, nt, transpose_flip);
+                           (char*)w_packed, Cin, Cout, BN, nt, transpose_flip, 0);
     return check_launch();
 }
 
