@@ -538,6 +538,200 @@ __device__ __forceinline__ float wave_shl1(float v)   // lane l <- lane l+1, lan
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
+// ------------------------------ local NCC, single pass, four z per lane ------------------------------ //
+// Same three mechanisms as ncc_fused_kernel (x: raw 9-plane ring in registers with sliding sums and an exact re-sum every
+// 9th plane; y: LDS exchange; z: DPP), re-balanced around the z window, which was 45 % of that kernel (140 half-rate
+// v_add_f32_dpp per plane step and wave).  A lane owns FOUR consecutive z (one 16-B load per row and plane, all plain
+// arithmetic as packed v_pk_*), so a row of up to 256 voxels is one wave and the centred 9-window of a lane's four
+// outputs needs its neighbours' values only from lanes l - 1 and l + 1:
+//   out0 = P[l-1] + P + v0[l+1]      out1 = (v1+v2+v3)[l-1] + P + (v0+v1)[l+1]
+//   out2 = (v2+v3)[l-1] + P + (v0+v1+v2)[l+1]      out3 = v3[l-1] + P + P[l+1]        (P = v0+v1+v2+v3)
+// = 5 plain + 8 DPP additions per field for four outputs (2 DPP per output instead of 8); whole rows also mean no z
+// halo.  The ring costs 72 VGPRs per row, so a wave holds 2 haloed rows, the tile is 16 rows -> 8 outputs and every
+// wave sums the 9-row y window of ONE output row from LDS (45 ds_read_b128; 80 KB tile, single buffer, two barriers
+// per plane).  The next plane is loaded straight into the ring slot of the plane that leaves the window (its
+// contribution is subtracted right after the sums are published), one plane step ahead of its use.
+// Requires Z % 4 == 0 and Z <= 256 (else the one-z-per-lane kernel runs).
+constexpr int N4_WAVES = 8, N4_RPW = 2, N4_ROWS = N4_WAVES * N4_RPW, N4_YOUT = N4_ROWS - 8;
+constexpr int N4_TILE_BYTES = N4_ROWS * 5 * 64 * 16;                  // 81,920: the published x-sums
+constexpr int N4_WSAVE = N4_RPW * 5;                                  // window sums parked in LDS during the y / z phase
+constexpr int N4_LDS_BYTES = N4_TILE_BYTES + N4_WSAVE * N4_WAVES * 64 * 16;   // 155,648
+typedef float f4_t __attribute__((ext_vector_type(4)));
+// y + x[lane - 1] / y + x[lane + 1] (0 beyond the wave's ends) as ONE v_add_f32_dpp.  Written out because hipcc kept the
+// shifts of this kernel as v_mov_b32_dpp + a separate add (40 extra VALU per plane step); the s_nop covers the two wait
+// states a DPP read needs after a VALU write of its source (the hazard recogniser does not look inside inline asm).
+__device__ __forceinline__ float add_shr1(float x, float y)
+{
+    float d;
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(x), "v"(y));
+    return d;
+}
+__device__ __forceinline__ float add_shl1(float x, float y)
+{
+    float d;
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(x), "v"(y));
+    return d;
+}
+
+__global__ void __launch_bounds__(N4_WAVES * 64)
+ncc_fused4_kernel(const float* __restrict__ I, const float* __restrict__ J, double* __restrict__ part, int X, int Y, int Z,
+                  int xseg, int nxs, int nyt, float eps, int form)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f4_t* buf = reinterpret_cast<f4_t*>(smem);             // [N4_ROWS][5][64]
+    // The sliding sums (40 VGPRs) are not needed between their publication and the next plane: they wait in a private LDS
+    // area so that the y / z phase has their registers (with them resident the kernel spilled 248 B per lane).
+    f4_t* wsave = reinterpret_cast<f4_t*>(smem + N4_TILE_BYTES) + threadIdx.x;   // [N4_WSAVE][512]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int t = blockIdx.x;
+    const int yt = t % nyt; t /= nyt;
+    const int xs = t % nxs;
+    const int b = t / nxs;
+    const int x0 = xs * xseg;
+    const int x1 = (x0 + xseg < X) ? x0 + xseg : X;
+    const bool zin = 4 * lane < Z;
+    const size_t nvox = (size_t)X * Y * Z;
+    const float* Ib = I + (size_t)b * nvox;
+    const float* Jb = J + (size_t)b * nvox;
+    // Loads go through buffer descriptors (one batch item = at most 64 MB): a row or plane outside the volume gets the
+    // offset 0xF0000000, beyond num_records, and the hardware returns zeros -- 'SAME' zero padding with no masks, no clamps
+    // and 32-bit offsets.
+    unsigned rofs[N4_RPW];                                 // byte offset of this lane's 4 z in row r of a plane, or out of range
+#pragma unroll
+    for (int r = 0; r < N4_RPW; ++r) {
+        const int y = yt * N4_YOUT - 4 + w * N4_RPW + r;
+        const bool in = zin && y >= 0 && y < Y;
+        rofs[r] = in ? (unsigned)(y * Z + 4 * lane) * 4u : 0xF0000000u;
+    }
+    const unsigned vol_bytes = (unsigned)(nvox * 4);
+    const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ib), 0, (int)vol_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsJ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Jb), 0, (int)vol_bytes, 0x00020000);
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    auto ldp = [&](const __amdgpu_buffer_rsrc_t& rs, int xq, int r) -> f4_t {   // plane xq (wave-uniform), row r
+        const bool xin = xq >= 0 && xq < X;
+        const unsigned soff = xin ? (unsigned)xq * (unsigned)(Y * Z) * 4u : 0u;
+        const unsigned voff = xin ? rofs[r] : 0xF0000000u;
+        return __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+    };
+    const f4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+    f4_t ra[9][N4_RPW], rc[9][N4_RPW];                     // raw ring: plane s sits in slot s % 9
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int r = 0; r < N4_RPW; ++r) ra[k][r] = rc[k][r] = zero4;
+    f4_t W[N4_RPW][5];
+#pragma unroll
+    for (int r = 0; r < N4_RPW; ++r)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) W[r][q] = zero4;
+    const bool oval = zin && (yt * N4_YOUT + w) < Y;       // this wave's output row / this lane's four z are in the volume
+    const float ws = 729.f;
+    float acc = 0.f;
+    const int xi0 = x0 - 4, nstep = (x1 - x0) + 8;
+#pragma unroll
+    for (int r = 0; r < N4_RPW; ++r) {                     // plane xi0 -> slot 0
+        ra[0][r] = ldp(rsI, xi0, r);
+        rc[0][r] = ldp(rsJ, xi0, r);
+    }
+    // The plane loop is unrolled by nine with the ring slot as the unroll index: every access names its registers
+    // statically and the ring never moves.  (A uniform `switch (slot)` around the two ring accesses of one loop body
+    // compiled to PHI copies of the whole ring and 250 B of spills per lane.)
+    for (int s0 = 0; s0 < nstep; s0 += 9) {
+#pragma unroll
+        for (int K = 0; K < 9; ++K) {
+            const int s = s0 + K;
+            if (s >= nstep) break;
+            // the plane in ring slot K (loaded one step ago) joins the window now
+            if (s > 0) {
+#pragma unroll
+                for (int i = 0; i < N4_WSAVE; ++i) W[i / 5][i % 5] = wsave[i * (N4_WAVES * 64)];
+            }
+#pragma unroll
+            for (int r = 0; r < N4_RPW; ++r) {
+                const f4_t a = ra[K][r], c = rc[K][r];
+                W[r][0] += a; W[r][1] += c; W[r][2] += a * a; W[r][3] += c * c; W[r][4] += a * c;
+            }
+            if (K == 8) {                                   // s = 8, 17, 26, ...: exact re-sum (no drift along x)
+#pragma unroll
+                for (int r = 0; r < N4_RPW; ++r) {
+                    f4_t sI = zero4, sJ = zero4, sII = zero4, sJJ = zero4, sIJ = zero4;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        const f4_t a = ra[k][r], c = rc[k][r];
+                        sI += a; sJ += c; sII += a * a; sJJ += c * c; sIJ += a * c;
+                    }
+                    W[r][0] = sI; W[r][1] = sJ; W[r][2] = sII; W[r][3] = sJJ; W[r][4] = sIJ;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const bool full = s >= 8;                       // window complete (uniform)
+            if (full) {
+#pragma unroll
+                for (int r = 0; r < N4_RPW; ++r)
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) buf[((w * N4_RPW + r) * 5 + q) * 64 + lane] = W[r][q];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the plane that leaves the window at the next step gives up its slot now: subtract it, load plane s + 1 there
+            {
+                constexpr int dummy = 0; (void)dummy;
+                const int KN = (K + 1) % 9;
+                const int xn = xi0 + s + 1;                 // the plane after the last step is loaded but never used
+#pragma unroll
+                for (int r = 0; r < N4_RPW; ++r) {
+                    const f4_t a = ra[KN][r], c = rc[KN][r];
+                    W[r][0] -= a; W[r][1] -= c; W[r][2] -= a * a; W[r][3] -= c * c; W[r][4] -= a * c;
+                }
+                __builtin_amdgcn_sched_barrier(0);          // subtract first: the loads then land in the freed registers
+#pragma unroll
+                for (int r = 0; r < N4_RPW; ++r) {
+                    ra[KN][r] = ldp(rsI, xn, r);
+                    rc[KN][r] = ldp(rsJ, xn, r);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < N4_WSAVE; ++i) wsave[i * (N4_WAVES * 64)] = W[i / 5][i % 5];
+            if (!full) continue;
+            __syncthreads();
+            // y window of this wave's output row (haloed rows w .. w + 8), then the centred z window from lanes l - 1, l + 1
+            // one field at a time, its nine rows in two batches (5 + 4 reads in flight): nine at once spill 164 B per lane,
+            // two fields at once 280 B
+            float S[4][5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                f4_t v = buf[((w + 0) * 5 + q) * 64 + lane];
+#pragma unroll
+                for (int k = 1; k < 5; ++k) v += buf[((w + k) * 5 + q) * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 5; k < 9; ++k) v += buf[((w + k) * 5 + q) * 64 + lane];
+                const float p01 = v.x + v.y, p012 = p01 + v.z, P = p012 + v.w, s23 = v.z + v.w, s123 = v.y + s23;
+                S[0][q] = add_shl1(v.x, add_shr1(P, P));
+                S[1][q] = add_shl1(p01, add_shr1(s123, P));
+                S[2][q] = add_shl1(p012, add_shr1(s23, P));
+                S[3][q] = add_shl1(P, add_shr1(v.w, P));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (oval) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc += ncc_terms<true>(S[k], ws, eps, form).cc;
+            }
+            __syncthreads();                                // the tile is rewritten by the next plane
+        }
+    }
+    double v = wave_sum((double)acc);
+    double* sh = reinterpret_cast<double*>(smem);           // the tile is free: every wave is past the last barrier
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0.0;
+#pragma unroll
+        for (int i = 0; i < N4_WAVES; ++i) r += sh[i];
+        part[blockIdx.x] = r;
+    }
+}
+
 struct F3 { float v[3]; };
 
 template <int BF_R>              // output rows per wave (BF_R + 2 rows loaded per plane)
@@ -936,13 +1130,35 @@ inline void ncc_fused_geom(int B, int X, int Y, int Z, int& nzt, int& nyt, int& 
 }
 }  // namespace
 
-// workspace = one double per workgroup of the single-pass kernel
+namespace {
+// four-z-per-lane kernel: whole rows per wave (Z <= 256, Z % 4 == 0), 8 output rows per tile, x segments >= 16 planes
+inline bool ncc_fused4_ok(int64_t nvox, int Z) { return Z % 4 == 0 && Z <= 256 && nvox * 4 < 0xF0000000ll; }
+inline void ncc_fused4_geom(int B, int X, int Y, int& nyt, int& nxs, int& xseg)
+{
+    nyt = (Y + N4_YOUT - 1) / N4_YOUT;
+    const int64_t tiles = (int64_t)B * nyt;
+    int want = (int)((256 + tiles - 1) / tiles);
+    if (tiles * want > 256 && want > 1) --want;
+    const int max_by_len = X / 16 > 0 ? X / 16 : 1;
+    nxs = want < 1 ? 1 : (want > max_by_len ? max_by_len : want);
+    xseg = (X + nxs - 1) / nxs;
+    nxs = (X + xseg - 1) / xseg;
+}
+}  // namespace
+
+// workspace = one double per workgroup of the single-pass kernel (the larger of the two geometries)
 extern "C" int64_t mmr_ncc_ws_bytes(int B, int X, int Y, int Z)
 {
     if (B < 1 || X < 1 || Y < 1 || Z < 1) return MMR_EINVAL;
     int nzt, nyt, nxs, xseg;
     ncc_fused_geom(B, X, Y, Z, nzt, nyt, nxs, xseg);
-    return (int64_t)B * nzt * nyt * nxs * sizeof(double);
+    int64_t n = (int64_t)B * nzt * nyt * nxs;
+    if (ncc_fused4_ok((int64_t)X * Y * Z, Z)) {
+        ncc_fused4_geom(B, X, Y, nyt, nxs, xseg);
+        const int64_t n4 = (int64_t)B * nyt * nxs;
+        if (n4 > n) n = n4;
+    }
+    return n * (int64_t)sizeof(double);
 }
 
 extern "C" int mmr_ncc_fwd_f32(const float* I, const float* J, float* out, void* ws, int B, int X, int Y, int Z,
@@ -953,6 +1169,27 @@ extern "C" int mmr_ncc_fwd_f32(const float* I, const float* J, float* out, void*
     if (win != 9) return MMR_EUNSUPPORTED;
     if ((int64_t)Y * Z > 0x7fffffff) return MMR_EINVAL;
     int nzt, nyt, nxs, xseg;
+    static const bool force_v1 = getenv("MMR_NCC_1Z") != nullptr;   // A/B knob: the one-z-per-lane kernel
+    if (ncc_fused4_ok((int64_t)X * Y * Z, Z) && !force_v1) {
+        ncc_fused4_geom(B, X, Y, nyt, nxs, xseg);
+        const int64_t nblk4 = (int64_t)nyt * nxs;            // per batch item
+        if ((int64_t)B * nblk4 > 0x7fffffff) return MMR_EINVAL;
+        static bool attr4 = false;
+        if (!attr4) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ncc_fused4_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
+            if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
+            attr4 = true;
+        }
+        double* part4 = (double*)ws;
+        hipLaunchKernelGGL(ncc_fused4_kernel, dim3((unsigned)(B * nblk4)), dim3(N4_WAVES * 64), N4_LDS_BYTES, as_stream(stream),
+                           I, J, part4, X, Y, Z, xseg, nxs, nyt, eps, ncc_form);
+        int rc4 = check_launch();
+        if (rc4) return rc4;
+        hipLaunchKernelGGL(mean_final_kernel, dim3(B), dim3(RED_BLOCK), 0, as_stream(stream), (const double*)part4, out, B,
+                           nblk4, (double)X * Y * Z, -1.0f);
+        return check_launch();
+    }
     ncc_fused_geom(B, X, Y, Z, nzt, nyt, nxs, xseg);
     const int64_t nblk = (int64_t)nzt * nyt * nxs;          // per batch item
     if ((int64_t)B * nblk > 0x7fffffff) return MMR_EINVAL;
