@@ -548,14 +548,16 @@ __device__ __forceinline__ float wave_shl1(float v)   // lane l <- lane l+1, lan
 //   out2 = (v2+v3)[l-1] + P + (v0+v1+v2)[l+1]      out3 = v3[l-1] + P + P[l+1]        (P = v0+v1+v2+v3)
 // = 5 plain + 8 DPP additions per field for four outputs (2 DPP per output instead of 8); whole rows also mean no z
 // halo.  The ring costs 72 VGPRs per row, so a wave holds 2 haloed rows, the tile is 16 rows -> 8 outputs and every
-// wave sums the 9-row y window of ONE output row from LDS (45 ds_read_b128; 80 KB tile, single buffer, two barriers
-// per plane).  The next plane is loaded straight into the ring slot of the plane that leaves the window (its
+// wave sums the 9-row y window of ONE output row from LDS (45 ds_read_b128, one field at a time in batches of 5 + 4:
+// more reads in flight spill; 80 KB tile, single buffer, two barriers per plane).  The next plane is loaded straight into the ring slot of the plane that leaves the window (its
 // contribution is subtracted right after the sums are published), one plane step ahead of its use.
 // Requires Z % 4 == 0 and Z <= 256 (else the one-z-per-lane kernel runs).
 constexpr int N4_WAVES = 8, N4_RPW = 2, N4_ROWS = N4_WAVES * N4_RPW, N4_YOUT = N4_ROWS - 8;
 constexpr int N4_TILE_BYTES = N4_ROWS * 5 * 64 * 16;                  // 81,920: the published x-sums
-constexpr int N4_WSAVE = N4_RPW * 5;                                  // window sums parked in LDS during the y / z phase
-constexpr int N4_LDS_BYTES = N4_TILE_BYTES + N4_WSAVE * N4_WAVES * 64 * 16;   // 155,648
+// window-sum vectors (of 10) parked in LDS during the y / z phase: 0 spills 20 B per lane, 2 fits in 256 VGPRs with none
+// (97 us at 256^3), 10 leaves 22 VGPRs unused and costs 16 more LDS operations per plane (108 us)
+constexpr int N4_WSAVE = 2;
+constexpr int N4_LDS_BYTES = N4_TILE_BYTES + N4_WSAVE * N4_WAVES * 64 * 16;   // 98,304
 typedef float f4_t __attribute__((ext_vector_type(4)));
 // y + x[lane - 1] / y + x[lane + 1] (0 beyond the wave's ends) as ONE v_add_f32_dpp.  Written out because hipcc kept the
 // shifts of this kernel as v_mov_b32_dpp + a separate add (40 extra VALU per plane step); the s_nop covers the two wait
@@ -579,8 +581,8 @@ ncc_fused4_kernel(const float* __restrict__ I, const float* __restrict__ J, doub
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f4_t* buf = reinterpret_cast<f4_t*>(smem);             // [N4_ROWS][5][64]
-    // The sliding sums (40 VGPRs) are not needed between their publication and the next plane: they wait in a private LDS
-    // area so that the y / z phase has their registers (with them resident the kernel spilled 248 B per lane).
+    // The sliding sums are not needed between their publication and the next plane: N4_WSAVE of their ten vectors wait in a
+    // private LDS area so that the y / z phase has their registers.
     f4_t* wsave = reinterpret_cast<f4_t*>(smem + N4_TILE_BYTES) + threadIdx.x;   // [N4_WSAVE][512]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int t = blockIdx.x;
