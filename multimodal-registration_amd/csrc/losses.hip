@@ -548,15 +548,15 @@ __device__ __forceinline__ float wave_shl1(float v)   // lane l <- lane l+1, lan
 //   out2 = (v2+v3)[l-1] + P + (v0+v1+v2)[l+1]      out3 = v3[l-1] + P + P[l+1]        (P = v0+v1+v2+v3)
 // = 5 plain + 8 DPP additions per field for four outputs (2 DPP per output instead of 8); whole rows also mean no z
 // halo.  The ring costs 72 VGPRs per row, so a wave holds 2 haloed rows, the tile is 16 rows -> 8 outputs and every
-// wave sums the 9-row y window of ONE output row from LDS (45 ds_read_b128, one field at a time in batches of 5 + 4:
-// more reads in flight spill; 80 KB tile, single buffer, two barriers per plane).  The next plane is loaded straight into the ring slot of the plane that leaves the window (its
+// wave sums the 9-row y window of ONE output row from LDS -- as four published row PAIRS + one single row, 25
+// ds_read_b128 instead of 45 (80 KB tile, single buffer, two barriers per plane).  The next plane is loaded straight into the ring slot of the plane that leaves the window (its
 // contribution is subtracted right after the sums are published), one plane step ahead of its use.
 // Requires Z % 4 == 0 and Z <= 256 (else the one-z-per-lane kernel runs).
 constexpr int N4_WAVES = 8, N4_RPW = 2, N4_ROWS = N4_WAVES * N4_RPW, N4_YOUT = N4_ROWS - 8;
 constexpr int N4_TILE_BYTES = N4_ROWS * 5 * 64 * 16;                  // 81,920: the published x-sums
 // window-sum vectors (of 10) parked in LDS during the y / z phase: 0 spills 20 B per lane, 2 fits in 256 VGPRs with none
 // (97 us at 256^3), 10 leaves 22 VGPRs unused and costs 16 more LDS operations per plane (108 us)
-constexpr int N4_WSAVE = 2;
+constexpr int N4_WSAVE = 3;
 constexpr int N4_LDS_BYTES = N4_TILE_BYTES + N4_WSAVE * N4_WAVES * 64 * 16;   // 98,304
 typedef float f4_t __attribute__((ext_vector_type(4)));
 // y + x[lane - 1] / y + x[lane + 1] (0 beyond the wave's ends) as ONE v_add_f32_dpp.  Written out because hipcc kept the
@@ -669,9 +669,13 @@ ncc_fused4_kernel(const float* __restrict__ I, const float* __restrict__ J, doub
             const bool full = s >= 8;                       // window complete (uniform)
             if (full) {
 #pragma unroll
-                for (int r = 0; r < N4_RPW; ++r)
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) buf[((w * N4_RPW + r) * 5 + q) * 64 + lane] = W[r][q];
+                for (int q = 0; q < 5; ++q) {
+                    // tile slot w = the SUM of this wave's two rows, slot 8 + w = the one row some window needs alone: a 9-row
+                    // window is four aligned row pairs + one single row (odd rows 1..7 from waves 0..3, even rows 8..14
+                    // from waves 4..7), so a window costs 5 reads per field instead of 9
+                    buf[(w * 5 + q) * 64 + lane] = W[0][q] + W[1][q];
+                    buf[((8 + w) * 5 + q) * 64 + lane] = (w < 4) ? W[1][q] : W[0][q];
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             // the plane that leaves the window at the next step gives up its slot now: subtract it, load plane s + 1 there
@@ -697,17 +701,16 @@ ncc_fused4_kernel(const float* __restrict__ I, const float* __restrict__ J, doub
             if (!full) continue;
             __syncthreads();
             // y window of this wave's output row (haloed rows w .. w + 8), then the centred z window from lanes l - 1, l + 1
-            // one field at a time, its nine rows in two batches (5 + 4 reads in flight): nine at once spill 164 B per lane,
-            // two fields at once 280 B
+            // window of output row w = haloed rows w .. w + 8: pairs ((w + 1) >> 1) .. + 3 and the single row w (odd w) or
+            // w + 8 (even w); one field at a time (5 reads in flight: more spill)
+            const int p0 = (w + 1) >> 1;
+            const int s1 = 8 + ((w & 1) ? (w >> 1) : (w >> 1) + 4);
             float S[4][5];
 #pragma unroll
             for (int q = 0; q < 5; ++q) {
-                f4_t v = buf[((w + 0) * 5 + q) * 64 + lane];
+                f4_t v = buf[(s1 * 5 + q) * 64 + lane];
 #pragma unroll
-                for (int k = 1; k < 5; ++k) v += buf[((w + k) * 5 + q) * 64 + lane];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k = 5; k < 9; ++k) v += buf[((w + k) * 5 + q) * 64 + lane];
+                for (int k = 0; k < 4; ++k) v += buf[((p0 + k) * 5 + q) * 64 + lane];
                 const float p01 = v.x + v.y, p012 = p01 + v.z, P = p012 + v.w, s23 = v.z + v.w, s123 = v.y + s23;
                 S[0][q] = add_shl1(v.x, add_shr1(P, P));
                 S[1][q] = add_shl1(p01, add_shr1(s123, P));
@@ -1219,7 +1222,8 @@ inline void bend_geom(int B, int X, int Y, int Z, int& nzs, int& nyg, int& nxs, 
 {
     nzs = (Z - 2 + BF_ZOUT - 1) / BF_ZOUT;
     nyg = (Y - 2 + R - 1) / R;
-    xseg = 16;
+    static const int xseg_env = [] { const char* e = getenv("MMR_BEND_XSEG"); return e ? atoi(e) : 0; }();   // A/B knob
+    xseg = xseg_env >= 4 ? xseg_env : 16;
     nxs = (X - 2 + xseg - 1) / xseg;
     nwaves = (int64_t)B * nzs * nyg * nxs;
 }
