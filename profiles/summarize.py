@@ -115,7 +115,7 @@ def round_(tag):
     # the files bench.py reads `roofline.traffic` from: dominant kernel family -> measured HBM bytes per launch
     fam = {"infer": ("conv3d_k3_mfma_bf16_bn256", "conv3d_k3_kernel<1, 2, 4, 4, 2"),
            "train": ("conv3d_k3_mfma_f32x3_bn64", "conv3d_k3_kernel<2, 8, 1, 2, 2"),
-           "ncc": ("ncc_fused_kernel", "ncc_fused_kernel")}
+           "ncc": (None, "ncc_fused")}   # family = the kernel that ran (ncc_fused4_kernel / ncc_fused_kernel)
     for wl, (family, sub) in fam.items():
         pj = os.path.join(here, f"{tag}_{wl}_pmc_traffic.json")
         if not os.path.exists(pj):
@@ -124,6 +124,8 @@ def round_(tag):
         hit = [(k, v) for k, v in d.items() if sub in k]
         if hit:
             k, v = max(hit, key=lambda kv: kv[1]["launches"])
+            if family is None:
+                family = k.replace("mmr::", "").split("(")[0]
             json.dump({family: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "kernel": k, "launches": v["launches"],
                                 "git": head, "source": f"profiles/{tag}_{wl}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
                                 "--pmc WRITE_SIZE in separate passes via tools/profile_round.sh; (2*FETCH + WRITE) KiB per "
