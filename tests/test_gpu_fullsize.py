@@ -132,3 +132,38 @@ def test_c5_ncc_and_bending_full_size(dev):
     got = float(mmr.ops.bending_energy(u.float()[None].to(dev)))
     ref = float(np.mean(4 * a * a + 2 * b * b))
     assert abs(got - ref) < 2e-3 * ref, (got, ref)  # fp32 second differences of values up to ~330
+
+
+def test_c3_thin_backward_kernels_full_size(dev):
+    """The fp32x3 thin-layer backward kernels at C3's size (160^3 x 64, 32 000 tiles over persistent workgroups): the
+    flow-head / first-layer weight gradients and the flow-head data gradient against the exact-fp32 kernels (independent
+    code paths: different tilings, MFMA shapes and reductions), plus the fused LeakyReLU mask + bias gradient."""
+    import mmr
+    ops = mmr.ops
+    S = (160, 160, 160)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn((1,) + S + (64,), generator=g).to(dev)
+    dflow = torch.randn((1,) + S + (3,), generator=g).to(dev)
+    src, trg = torch.rand((1,) + S + (1,), generator=g).to(dev), torch.rand((1,) + S + (1,), generator=g).to(dev)
+    w = (torch.randn((3, 3, 3, 64, 3), generator=g) * 0.05).to(dev)
+
+    def rel(a, b):
+        return float((a - b).abs().max() / b.abs().max())
+
+    dw3, dwe = torch.zeros((3, 3, 3, 64, 3), device=dev), torch.zeros((3, 3, 3, 64, 3), device=dev)
+    ops.conv3d_k3_wgrad(x, dflow, dw3, x3=True)
+    ops.conv3d_k3_wgrad(x, dflow, dwe, x3=False)
+    assert rel(dw3, dwe) < 2e-5
+    d03, d0e = torch.zeros((3, 3, 3, 2, 64), device=dev), torch.zeros((3, 3, 3, 2, 64), device=dev)
+    ops.conv3d_k3_cin2_wgrad(src, trg, x, d03, x3=True)
+    ops.conv3d_k3_cin2_wgrad(src, trg, x, d0e, x3=False)
+    assert rel(d03, d0e) < 2e-5
+    dx3 = ops.conv3d_k3_cout3_dgrad(dflow, w, x3=True)
+    dxe = ops.conv3d_k3_cout3_dgrad(dflow, w, x3=False)
+    assert rel(dx3, dxe) < 2e-5
+    del dxe
+    db = torch.zeros(64, device=dev)
+    fused = ops.conv3d_k3_cout3_dgrad_masked(dflow, w, x, db, x3=True)
+    ref = torch.where(x < 0, 0.2 * dx3, dx3)
+    assert torch.equal(fused, ref)
+    assert rel(db, ref.double().sum(dim=(0, 1, 2, 3)).float()) < 1e-5
