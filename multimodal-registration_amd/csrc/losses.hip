@@ -737,6 +737,24 @@ ncc_fused4_kernel(const float* __restrict__ I, const float* __restrict__ J, doub
     }
 }
 
+// x[lane + 1] + x[lane - 1] and x[lane + 1] - x[lane - 1] (0 beyond the wave's ends): one DPP move + one DPP-fused VOP2
+// instead of two moves and an add (hipcc keeps the second shift as its own v_mov_b32_dpp); the s_nop covers the two wait
+// states a DPP read needs after a VALU write of its source
+__device__ __forceinline__ float shl_plus_shr(float x)
+{
+    const float t = wave_shl1(x);
+    float d;
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(x), "v"(t));
+    return d;
+}
+__device__ __forceinline__ float shl_minus_shr(float x)
+{
+    const float t = wave_shl1(x);
+    float d;   // v_subrev: dst = src1 - dpp(src0)
+    asm("s_nop 1\n\tv_subrev_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(x), "v"(t));
+    return d;
+}
+
 struct F3 { float v[3]; };
 
 template <int BF_R>              // output rows per wave (BF_R + 2 rows loaded per plane)
@@ -798,13 +816,13 @@ bending_fused_kernel(const float* __restrict__ u, double* __restrict__ part, int
                     const float c0 = q1[j + 1].v[k];
                     const float dxx = q2[j + 1].v[k] - 2.f * c0 + q0[j + 1].v[k];
                     const float dyy = q1[j + 2].v[k] - 2.f * c0 + q1[j].v[k];
-                    const float dzz = wave_shl1(c0) - 2.f * c0 + wave_shr1(c0);
+                    const float dzz = shl_plus_shr(c0) - 2.f * c0;
                     const float dxy = (q2[j + 2].v[k] - q2[j].v[k] - q0[j + 2].v[k] + q0[j].v[k]) * 0.25f;
                     // mixed z differences: difference across x (or y) first, then ONE pair of lane shifts of it
                     const float dx = q2[j + 1].v[k] - q0[j + 1].v[k];
                     const float dy = q1[j + 2].v[k] - q1[j].v[k];
-                    const float dxz = (wave_shl1(dx) - wave_shr1(dx)) * 0.25f;
-                    const float dyz = (wave_shl1(dy) - wave_shr1(dy)) * 0.25f;
+                    const float dxz = shl_minus_shr(dx) * 0.25f;
+                    const float dyz = shl_minus_shr(dy) * 0.25f;
                     e += dxx * dxx + dyy * dyy + dzz * dzz + 2.f * (dxy * dxy + dxz * dxz + dyz * dyz);
                 }
                 if (zout && (yh0 + 1 + j) <= Y - 2) acc += e;
@@ -1244,14 +1262,17 @@ extern "C" int mmr_bending_fwd_f32(const float* flow, float* out, void* ws, int 
     if ((int64_t)Y * Z * 3 > 0x7fffffff) return MMR_EINVAL;
     int nzs, nyg, nxs, xseg;
     int64_t nwaves;
-    static const int rows = [] { const char* e = getenv("MMR_BEND_ROWS"); return (e && atoi(e) == 6) ? 6 : BF_ROWS; }();  // A/B knob
+    static const int rows = [] { const char* e = getenv("MMR_BEND_ROWS"); const int r = e ? atoi(e) : 0; return (r == 6 || r == 5) ? r : BF_ROWS; }();  // A/B knob
     bend_geom(1, X, Y, Z, nzs, nyg, nxs, xseg, nwaves, rows);  // per batch item, so that a block never straddles items
     const int64_t nblk = (nwaves + 3) / 4;
     if (nblk * B > 0x7fffffff) return MMR_EINVAL;
     const int64_t n = (int64_t)(X - 2) * (Y - 2) * (Z - 2) * 3;
     for (int b = 0; b < B; ++b) {
         double* part = (double*)ws + (int64_t)b * nblk;
-        if (rows == 6)
+        if (rows == 5)
+            hipLaunchKernelGGL(bending_fused_kernel<5>, dim3((unsigned)nblk), dim3(RED_BLOCK), 0, as_stream(stream),
+                               flow + (size_t)b * X * Y * Z * 3, part, X, Y, Z, xseg, nxs, nyg, nzs, nwaves);
+        else if (rows == 6)
             hipLaunchKernelGGL(bending_fused_kernel<6>, dim3((unsigned)nblk), dim3(RED_BLOCK), 0, as_stream(stream),
                                flow + (size_t)b * X * Y * Z * 3, part, X, Y, Z, xseg, nxs, nyg, nzs, nwaves);
         else
