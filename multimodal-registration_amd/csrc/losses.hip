@@ -764,12 +764,14 @@ bending_fused_kernel(const float* __restrict__ u, double* __restrict__ part, int
 {
     __shared__ double sh[4];
     const int lane = threadIdx.x & 63;
-    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // (an XCD-contiguous workgroup order measured no better)
     float acc = 0.f;
     if (wid < nwaves) {
+        // y row groups fastest: the four waves of a workgroup are y-neighbours of one (z strip, x segment), so the two halo
+        // rows a wave shares with the next one are served by the CU's L1 instead of crossing the fabric twice
         int64_t t = wid;
-        const int zs = (int)(t % nzs); t /= nzs;
         const int yg = (int)(t % nyg); t /= nyg;
+        const int zs = (int)(t % nzs); t /= nzs;
         const int xs = (int)(t % nxs);
         const int b = (int)(t / nxs);
         const int z = zs * BF_ZOUT + lane;                  // outputs at lanes 1..62 -> z = zs*62 + 1 .. zs*62 + 62
