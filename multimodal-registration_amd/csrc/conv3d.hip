@@ -1758,8 +1758,17 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
         // LDS) nothing else hides the HBM latency: a plane took 12 k cycles for 1.5 k cycles of MFMA.
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
         constexpr int NL = NS > 0 ? NS * (X3 ? 2 : 1) : 1;   // 16-B loads per row and plane (fp32: two per k-step)
-        u32x4_t pre[NL][2];
-        auto load_plane = [&](int xq) {
+        // TWO planes ahead: the loop is unrolled by two over two prefetch buffers (plane xp is consumed from one, which is then
+        // reloaded with plane xp + 2, while plane xp + 1 is still in flight in the other).  One plane ahead = 64 KB in flight
+        // per CU and 3.9 TB/s of loads at the ~4 us a round trip takes under this load: the kernel was bound by its bytes
+        // in flight, not by HBM bandwidth or by its halo (an XCD-contiguous tile order changes nothing).
+        // (bf16 only: the narrow fp32x3 inputs run two workgroups per CU, which already doubles the bytes in flight; two planes
+        // ahead cost them 5 %)
+        constexpr bool DEEP = !X3;
+        constexpr int AHEAD = DEEP ? 2 : 1;
+        typedef u32x4_t PreBuf[NL][2];
+        PreBuf preA, preB;
+        auto load_plane = [&](PreBuf& pre, int xq) {
             const int xc = xq < 0 ? 0 : (xq >= X ? X - 1 : xq);   // planes outside the volume are never used: any valid address
             const char* pl = in + ((size_t)b * X + xc) * Y * Z * Cin * ES;
 #pragma unroll
@@ -1769,13 +1778,16 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
                     pre[s2][j] = *reinterpret_cast<const u32x4_t*>(pl + rowoff[j] +
                                                                    (X3 ? (size_t)(s2 >> 1) * 128 + (s2 & 1) * 16 : (size_t)s2 * 64));
         };
-        if constexpr (NS > 0) load_plane(xs - 1);
-        for (int xp = xs - 1; xp <= xe; ++xp) {
+        if constexpr (NS > 0) {
+            load_plane(preA, xs - 1);
+            if constexpr (DEEP) load_plane(preB, xs);
+        }
+        auto plane_step = [&](int xp, PreBuf& pre) {
             const int buf = (pbufs == 2) ? ((xp - xs + 1) & 1) : 0;
             float* P = sP + buf * (MH_ROWS * 81);
             const bool inside = xp >= 0 && xp < X;
             if constexpr (NS > 0) {
-                if (!inside) load_plane(xp + 1);
+                if (!inside) load_plane(pre, xp + AHEAD);
             }
             if (inside) {
                 const char* plane = in + ((size_t)b * X + xp) * Y * Z * Cin * ES;
@@ -1802,7 +1814,7 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
                     for (int s2 = 0; s2 < NL; ++s2)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) allraw[s2][j] = pre[s2][j] & rowmask[j];
-                    load_plane(xp + 1);
+                    load_plane(pre, xp + AHEAD);
                 } else {
                     load_raw(0, raw0, raw1);
                 }
@@ -1892,6 +1904,14 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
             a_prev = a_cur + c1;
             a_cur = bco + c0;
             if (pbufs == 1) __syncthreads();  // single P buffer (wide fp32x3 inputs): gather done before the next plane lands
+        };
+        if constexpr (DEEP) {
+            for (int xp = xs - 1; xp <= xe; xp += 2) {
+                plane_step(xp, preA);
+                if (xp + 1 <= xe) plane_step(xp + 1, preB);
+            }
+        } else {
+            for (int xp = xs - 1; xp <= xe; ++xp) plane_step(xp, preA);
         }
         __syncthreads();  // the next tile's first plane reuses buffer 0/1
     }
