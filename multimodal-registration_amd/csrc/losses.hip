@@ -585,7 +585,14 @@ ncc_fused4_kernel(const float* __restrict__ I, const float* __restrict__ J, doub
     // private LDS area so that the y / z phase has their registers.
     f4_t* wsave = reinterpret_cast<f4_t*>(smem + N4_TILE_BYTES) + threadIdx.x;   // [N4_WSAVE][512]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one L2): every XCD takes a contiguous run of
+    // logical workgroups, so that y-neighbouring tiles, which share 8 of their 16 haloed rows, read them through one L2
     int t = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = t & 7, qd = nwg >> 3, rm = nwg & 7;
+        t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (t >> 3);
+    }
+    const int lblk = t;
     const int yt = t % nyt; t /= nyt;
     const int xs = t % nxs;
     const int b = t / nxs;
@@ -733,7 +740,7 @@ ncc_fused4_kernel(const float* __restrict__ I, const float* __restrict__ J, doub
         double r = 0.0;
 #pragma unroll
         for (int i = 0; i < N4_WAVES; ++i) r += sh[i];
-        part[blockIdx.x] = r;
+        part[lblk] = r;
     }
 }
 
