@@ -166,8 +166,8 @@ def test_dice_grad(dev):
     np.testing.assert_allclose(got, [s * s / 9 * 2.0], rtol=1e-5)
 
 
-@pytest.mark.parametrize("shape", [(20, 18, 40), (9, 33, 12)])
-def test_ncc_bending(dev, shape):
+@pytest.mark.parametrize("shape", [(20, 18, 40), (9, 33, 12), (5, 11, 256), (40, 9, 260)])   # Z = 256: every lane of the
+def test_ncc_bending(dev, shape):                                                              # four-z kernel; 260: one-z kernel
     import mmr
     from oracle import ops_np as O
     rng = np.random.default_rng(8)
