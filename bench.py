@@ -1,22 +1,31 @@
 #!/usr/bin/env python
 """Benchmark of the hot path (see DESIGN.md "Measurement").
 
-python bench.py --gpus N --steps K --warmup W [--workload infer|train|ncc]
+python bench.py --gpus N --steps K --warmup W [--workload infer|train|ncc|cascade]
 
 infer (default) = BASELINE.json configs[1]: 3d_reg.py-style inference, one VxmDense forward
   (enc/dec = 256, int_steps 5, half-res SVF) on a 160x160x192 pair, bf16 MFMA / fp32 accumulate,
   inputs resident in HBM.  A step = one pair.  N > 1 = independent replicas (single-pair inference
-  does not shard), weak scaling, no data-path collective.
+  does not shard), weak scaling, no data-path collective.  The default line ALSO carries
+  the other half of BASELINE.json's metric under "secondary": the data-parallel training step with the
+  same K / W, its own roofline, its own cpu_baseline and the per-step all-reduce time.
 train = configs[2]: SynthMorph training step at 160^3, enc/dec = 64 (config/config.json), 1 pair per GPU,
   Dice + Grad-l2, generators on device, RCCL SUM all-reduce of the flat gradient buffer + Adam.  Tensors are
   fp32; --dtype fp32x3 (default) runs the conv products as bf16 hi/lo splits (3 bf16 MFMAs, ~5e-6 relative
   error, inside north_star's 1e-4 fp32 bar), --dtype fp32 uses the exact fp32 MFMA.
 ncc   = configs[4]: local NCC (win 9) + bending energy forward on 256^3 fp32 volumes.
-Rank 0 prints ONE JSON line.
+cascade = configs[3]: two VxmDense forwards + compose + rescale + warp on one 160x160x192 pair.
+
+Launching: under torchrun (WORLD_SIZE in the environment) this process is one rank.  Started plainly with
+--gpus N > 1 it is the LAUNCHER: before anything touches the GPU it starts N fresh child processes (one rank per
+GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1), relays rank 0's JSON line and exits
+with the worst child's code.  Rank 0 prints ONE JSON line; its "dist" object says how many ranks the process group
+really had and over which backend.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,6 +41,52 @@ PEAKS = {"bf16": 2500.0, "fp32": 157.3, "f32x3": 2500.0 / 3}   # dense MFMA TFLO
 PEAK_HBM_GBS = 8000.0
 
 
+# ----------------------------------------------------------------------------------------------- launcher
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Parent of an N-rank run started WITHOUT torchrun.  Nothing here initialises HIP (torch is imported, no
+    torch.cuda call is made): the children are fresh interpreters, not re-execs of a process that owns a GPU context."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mmr_build", os.path.join(ROOT, "multimodal-registration_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    b.build()   # once, before the ranks start (they would otherwise queue on the build lock)
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MMR_BENCH_LAUNCHED="self")
+        env.setdefault("OMP_NUM_THREADS", "1")   # what torchrun does for N > 1; the cpu_baseline leg only runs at N = 1
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    deadline = time.time() + float(os.environ.get("MMR_BENCH_LAUNCH_TIMEOUT", "1500"))
+    out0, rc = b"", 0
+    try:
+        out0 = procs[0].communicate(timeout=max(deadline - time.time(), 1))[0]
+        for p in procs:
+            p.wait(timeout=max(deadline - time.time(), 1))
+            rc = rc or p.returncode
+    except subprocess.TimeoutExpired:
+        rc = 124
+    finally:
+        for p in procs:     # only the exact children started above
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+                rc = rc or 1
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------- inputs
 def synth_pair(shape, device, seed=0):
     """Smooth synthetic T1w/T2w-like pair in [0,1] (random low-res noise, trilinearly upsampled on device)."""
     import mmr
@@ -45,125 +100,250 @@ def synth_pair(shape, device, seed=0):
     return outs
 
 
-def cpu_baseline_infer(enc, dec, full_shape, mov, fix, budget_s=45.0):
+# ----------------------------------------------------------------------------------------------- CPU baselines
+def _host_mem_available_gb():
+    """Smallest of MemAvailable and the cgroup limit (a GPU box is shared: never drive it out of memory)."""
+    gb = float("inf")
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                gb = min(gb, int(ln.split()[1]) / 1e6)
+    except OSError:
+        pass
+    for p in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            v = open(p).read().strip()
+            if v.isdigit():
+                gb = min(gb, int(v) / 1e9)
+        except OSError:
+            pass
+    return gb
+
+
+def _cpu_quota():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (a GPU box hands one GPU's
+    share of the host, e.g. cpu.max = 1600000 100000 = 16 CPUs of a 256-thread machine; more threads than that are
+    only throttled)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def _cpu_threads():
+    return max(1, min(torch.get_num_threads(), _cpu_quota()))
+
+
+def _cpu_desc():
+    model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    return (f"{model or 'cpu'}; {os.cpu_count()} logical CPUs, {aff} in the affinity mask, cgroup CPU quota "
+            f"{_cpu_quota()} (threads = min(torch default, quota))")
+
+
+def cpu_baseline_infer(enc, dec, full_shape, mov, fix, nets=1, budget_s=90.0):
     """CPU restatement ('port') of the same forward on the same pair, as BASELINE.md section 3 prescribes: torch-CPU
     conv3d / max_pool3d (channels-last-3d, oneDNN) + the gather-form tail (oracle/net_torch.py, checked against
-    oracle/net_np.py in tests/test_oracle_kat.py), fp32 like the reference's TF CPU path.  All torch threads, and a
-    1-thread run mirroring --one-cpu-tf (bids_registration.py:460-472).  The sample is the largest leading crop of the
-    pair whose warm-up + 3 timed forwards fit the budget (the full pair when it does); value = crop fraction / median."""
+    oracle/net_np.py in tests/test_oracle_kat.py), fp32 like the reference's TF CPU path, on as many threads as the
+    process may use (torch's default = the physical cores, capped by the cgroup CPU quota of the box: 16 on a one-GPU
+    lease; 128 threads under a 16-CPU quota only get throttled), plus a 1-thread run mirroring --one-cpu-tf
+    (bids_registration.py:460-472).
+
+    The sample is the WHOLE 160x160x192 pair whenever one forward of it fits the time budget and the host's free
+    memory: a warm-up on the 1/8 crop builds the oneDNN primitives and gives the time estimate, then 1-3 full forwards
+    are timed (value = 1 / median).  Only when the full pair does not fit is the figure the crop's, scaled by its voxel
+    fraction, and the sample string says so.  ``nets`` = 2 for the two-step cascade (two forwards, then compose /
+    rescale / warp through the same gather ops)."""
     from oracle import net_np, net_torch
-    nthreads = torch.get_num_threads()
-    tw = net_torch.prepare_weights(net_np.init_weights(enc, dec, seed=0))
+    default_threads = torch.get_num_threads()
+    nthreads = _cpu_threads()
+    torch.set_num_threads(nthreads)
+    tws = [net_torch.prepare_weights(net_np.init_weights(enc, dec, seed=s)) for s in range(nets)]
     mov, fix = mov.detach().float().cpu(), fix.detach().float().cpu()
     nvox = float(np.prod(full_shape))
 
     def crop(shape):
         return mov[:, :shape[0], :shape[1], :shape[2]].contiguous(), fix[:, :shape[0], :shape[1], :shape[2]].contiguous()
 
+    def forward(a, b):
+        o = net_torch.vxm_dense_forward(a, b, tws[0], enc, dec, 5, 2, 2)
+        if nets == 2:   # bids_two_steps_registration.py:318-325
+            o2 = net_torch.vxm_dense_forward(o["moved"], b, tws[1], enc, dec, 5, 2, 2)
+            w = o2["preint_flow"][0] + net_torch.transform(o["preint_flow"][0], o2["preint_flow"][0])
+            full = net_torch.resize(w * 2.0, tuple(a.shape[1:4]))
+            return net_torch.transform(a[0], full)
+        return o["moved"]
+
     def run(shape, reps, warm=1):
         a, b = crop(shape)
         ts = []
         for i in range(warm + reps):
             t0 = time.perf_counter()
-            net_torch.vxm_dense_forward(a, b, tw, enc, dec, 5, 2, 2)
+            forward(a, b)
             if i >= warm:
                 ts.append(time.perf_counter() - t0)
         return float(np.median(ts)), ts
 
     def fits(shape):
         return tuple(max(16, min(int(s), int(f)) // 16 * 16) for s, f in zip(shape, full_shape))
-    # ladder: 1/64 crop as the probe (one warm-up builds the oneDNN primitives, one timed run); the 1/8 crop when the probe
-    # says a run of it stays under ~15 s (work is linear in voxels and larger crops run MORE efficiently, so x8 is an
-    # upper bound), the whole pair when even that is cheap; otherwise the probe crop itself, median of 3
-    probe_shape = fits([s // 4 for s in full_shape])
-    t_probe, _ = run(probe_shape, 1, warm=1)
+    xs = "x".join
     eighth = fits([s // 2 for s in full_shape])
-    if t_probe * 64 * 4 <= budget_s:
+    t8, _ = run(eighth, 1, warm=1)          # warm-up + one timed forward of the 1/8 crop
+    est_full = t8 * nvox / float(np.prod(eighth))
+    # fp32 activations of the full-res levels: concat 2C + out C + skip C (+ as much again for oneDNN's scratch / reorders)
+    need_gb = nvox * enc[0] * 4 * 8 / 1e9
+    mem_gb = _host_mem_available_gb()
+    if est_full <= budget_s and need_gb <= 0.6 * mem_gb:
         sample = tuple(full_shape)
-    elif t_probe * 8 <= 15.0:
-        sample = eighth
+        reps = int(min(3, max(1, budget_s // max(est_full, 1e-3))))
+        med, ts = run(sample, reps, warm=0)
+        why = f"the WHOLE {xs(map(str, sample))} pair, median of {len(ts)} forward(s) after a warm-up on the 1/8 crop"
     else:
-        sample = probe_shape
-    med, ts = run(sample, 3, warm=1 if sample != probe_shape else 0)
+        sample = eighth
+        med, ts = run(sample, 3, warm=0)
+        why = (f"the leading {xs(map(str, sample))} crop = {float(np.prod(sample)) / nvox:.5f} of the voxels, scaled by that "
+               f"fraction (the full pair was estimated at {est_full:.0f} s / {need_gb:.0f} GB against a budget of {budget_s:.0f} s / "
+               f"{0.6 * mem_gb:.0f} GB), median of {len(ts)} after a warm-up")
     frac = float(np.prod(sample)) / nvox
-    one_shape = fits((16, 16, 32))
+    one_shape = fits((32, 32, 48))
     torch.set_num_threads(1)
     try:
         med1, ts1 = run(one_shape, 3, warm=1)
     finally:
-        torch.set_num_threads(nthreads)
+        torch.set_num_threads(default_threads)
     frac1 = float(np.prod(one_shape)) / nvox
-    xs = "x".join
+    what = "VxmDense forward" if nets == 1 else "two-step cascade (2 x VxmDense forward + compose + rescale + warp)"
     return {"value": frac / med, "unit": "pairs/s", "cores": nthreads, "kind": "port",
-            "ms_per_pair_equivalent": med / frac * 1e3, "runs_s": [round(t, 3) for t in ts],
-            "sample": f"VxmDense forward (enc/dec={enc[0]}, fp32) on the leading {xs(map(str, sample))} crop of the same pair = "
-                      f"{frac:.5f} of the {xs(map(str, full_shape))} voxels; median of {len(ts)} after 1 warm-up = {med:.2f} s; "
-                      f"value = crop fraction / median; torch-CPU conv3d/max_pool3d channels-last (oneDNN) + gather-form "
-                      f"resize/VecInt/warp (oracle/net_torch.py), {nthreads} threads; host has {os.cpu_count()} logical CPUs",
+            "ms_per_pair": med / frac * 1e3, "runs_s": [round(t, 3) for t in ts],
+            "sample": f"{what} (enc/dec={enc[0]}, fp32) on {why}; torch-CPU conv3d/max_pool3d channels-last (oneDNN) + "
+                      f"gather-form resize/VecInt/warp (oracle/net_torch.py), {nthreads} threads; host: {_cpu_desc()}",
             "one_thread": {"value": frac1 / med1, "unit": "pairs/s", "cores": 1, "runs_s": [round(t, 3) for t in ts1],
-                           "sample": f"same graph, torch.set_num_threads(1) (the reference's --one-cpu-tf mode), "
-                                     f"{xs(map(str, one_shape))} crop = {frac1:.6f} of the voxels, median of 3 = {med1:.2f} s"}}
+                           "sample": f"same graph, torch.set_num_threads(1) (the reference's --one-cpu-tf mode), leading "
+                                     f"{xs(map(str, one_shape))} crop = {frac1:.6f} of the voxels scaled by that fraction, "
+                                     f"median of 3 after a warm-up = {med1:.2f} s"}}
 
 
-def cpu_baseline_train(enc, dec, full_shape, L):
-    """Oracle training step ('port'): torch-CPU float64 autograd of the restated graph on a small crop."""
-    from oracle import grad_torch as G
-    from oracle import net_np
-    sample = (16, 16, 32)
-    rng = np.random.default_rng(0)
-    ws = [torch.from_numpy(w).double().requires_grad_(True) for w in net_np.init_weights(enc, dec, seed=0, flow_std=1e-2)]
-    src = torch.from_numpy(rng.random((1,) + sample + (1,)))
-    trg = torch.from_numpy(rng.random((1,) + sample + (1,)))
-    e = torch.eye(L, dtype=torch.float64)
-    o1 = e[torch.from_numpy(rng.integers(0, L, (1,) + sample))]
-    o2 = e[torch.from_numpy(rng.integers(0, L, (1,) + sample))]
-    t0 = time.perf_counter()
-    total = G.synthmorph_loss(src, trg, o1, o2, ws, enc, dec, 5, 1.0)[0]
-    total.backward()
-    dt = time.perf_counter() - t0
-    frac = float(np.prod(sample)) / float(np.prod(full_shape))
-    return {"value": frac / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"one fwd+bwd of the restated SynthMorph step (oracle/grad_torch.py, torch-CPU float64 autograd, {torch.get_num_threads()} threads, "
-                      f"enc/dec={enc[0]}, no generator, no Adam) on a {sample[0]}x{sample[1]}x{sample[2]} pair = {frac:.6f} of "
-                      f"the voxels, {dt:.1f} s wall; value = fraction / wall"}
+def cpu_baseline_train(enc, dec, full_shape, L, label_map, reg_param=1.0, lr=1e-4):
+    """CPU restatement ('port') of the WHOLE training step -- both generators, forward, backward, Adam -- in fp32 on
+    torch-CPU (oracle/train_torch.py: oneDNN conv3d fwd/bwd through autograd, NumPy generator stages), on the leading
+    64^3 block of the same label map (BASELINE configs[0]'s size), median of 3 steps after a warm-up; the whole 160^3
+    step is timed once as well when the estimate says it fits."""
+    from oracle import train_torch
+    default_threads = torch.get_num_threads()
+    nthreads = _cpu_threads()
+    torch.set_num_threads(nthreads)
+    nvox = float(np.prod(full_shape))
+    lab = np.asarray(label_map)
+
+    def run(shape, reps, warm):
+        st = train_torch.CpuStep(lab[:shape[0], :shape[1], :shape[2]], L, enc, dec, reg_param=reg_param, lr=lr, seed=0)
+        ts = []
+        for i in range(warm + reps):
+            t0 = time.perf_counter()
+            st.step()
+            if i >= warm:
+                ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), ts
+    small = tuple(min(64, s) for s in full_shape)
+    med, ts = run(small, 3, 1)
+    frac = float(np.prod(small)) / nvox
+    res = {"value": frac / med, "unit": "pairs/s", "cores": nthreads, "kind": "port", "runs_s": [round(t, 3) for t in ts],
+           "sample": f"whole SynthMorph step (2 x labels_to_image + fwd + bwd + Adam, fp32, enc/dec={enc[0]}, {L} labels) on the "
+                     f"leading {small[0]}x{small[1]}x{small[2]} block of the same label map = {frac:.4f} of the voxels, scaled "
+                     f"by that fraction; median of 3 steps after a warm-up = {med:.2f} s; torch-CPU autograd over oneDNN "
+                     f"conv3d + gather-form warp/VecInt/resize, NumPy generator (oracle/train_torch.py), {nthreads} threads; "
+                     f"host: {_cpu_desc()}"}
+    est = med / frac
+    need_gb = nvox * (enc[0] * 4 * 40 + L * 4 * 30) / 1e9
+    if small != tuple(full_shape) and est <= 40.0 and need_gb <= 0.5 * _host_mem_available_gb():
+        full_med, full_ts = run(tuple(full_shape), 1, 0)
+        res["full_size"] = {"value": 1.0 / full_med, "unit": "pairs/s", "runs_s": [round(t, 3) for t in full_ts],
+                            "sample": f"one whole step at {full_shape[0]}x{full_shape[1]}x{full_shape[2]} (no warm-up at this size)"}
+    torch.set_num_threads(default_threads)
+    return res
 
 
-def roofline_from_profile(prof, steps, dtype, traffic_file):
+def cpu_baseline_ncc(I, J, flow):
+    """NumPy float64 restatement (oracle/ops_np.py) of NCC(9) + bending energy on the leading 128^3 block."""
+    from oracle import ops_np
+    s = tuple(min(128, d) for d in I.shape[1:4])
+    a = I[:, :s[0], :s[1], :s[2]].cpu().numpy()
+    b = J[:, :s[0], :s[1], :s[2]].cpu().numpy()
+    f = flow[:, :s[0], :s[1], :s[2]].cpu().numpy()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ops_np.ncc_loss(a, b, 9)
+        ops_np.bending_energy(f)
+        ts.append(time.perf_counter() - t0)
+    med = float(np.median(ts))
+    frac = float(np.prod(s)) / float(np.prod(I.shape[1:4]))
+    return {"value": frac / med, "unit": "pairs/s", "cores": 1, "kind": "port", "runs_s": [round(t, 3) for t in ts],
+            "sample": f"NCC(9) + bending energy, NumPy float64 (oracle/ops_np.py, separable box sums), leading "
+                      f"{s[0]}x{s[1]}x{s[2]} block = {frac:.4f} of the voxels scaled by that fraction, median of 3 = {med:.2f} s; "
+                      f"host: {_cpu_desc()}"}
+
+
+# ----------------------------------------------------------------------------------------------- roofline
+def roofline_from_profile(prof, steps, traffic_file):
+    """Per-family sums of HIP-event times (events on the stream the kernels run on) -> roofline of the dominant family,
+    ms per step of every family, and the achieved rate of the others.  Families "hbm:*" carry algorithmic BYTES,
+    "comm:*" carry message bytes and never count as the dominant kernel, the rest carry algorithmic flops."""
     fam = {}
     for f, tag, e0, e1, fl in prof:
         a = fam.setdefault(f, [0.0, 0.0, 0])
         a[0] += e0.elapsed_time(e1)
         a[1] += fl
         a[2] += 1
-    if not fam:
-        return None, {}
-    dom = max(fam, key=lambda k: fam[k][0])
-    ms, fl, n = fam[dom]
     fam_ms = {k: round(v[0] / steps, 4) for k, v in fam.items()}
-    if dom.startswith("hbm:"):   # HBM-bound family: the recorded work is ALGORITHMIC BYTES per launch
+    kern = {k: v for k, v in fam.items() if not k.startswith("comm:")}
+    if not kern:
+        return None, fam_ms, fam
+    dom = max(kern, key=lambda k: kern[k][0])
+    ms, fl, n = kern[dom]
+
+    def peak_of(name):
+        return PEAKS["bf16" if "bf16" in name else ("f32x3" if ("f32x3" in name or "f32x1" in name) else "fp32")]
+    if dom.startswith("hbm:"):
         gbs = fl / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                 "traffic": None, "kernel": dom[4:], "launches_per_step": n // max(steps, 1), "avg_launch_ms": ms / max(n, 1),
                 "algorithmic_bytes_per_launch": fl / max(n, 1),
-                "other_kernels_GBps": {k[4:]: round(v[1] / (v[0] * 1e-3) / 1e9, 1) for k, v in fam.items()
+                "other_kernels_GBps": {k[4:]: round(v[1] / (v[0] * 1e-3) / 1e9, 1) for k, v in kern.items()
                                        if k != dom and k.startswith("hbm:") and v[0] > 0}}
-        return roof, fam_ms
-    peak = PEAKS["bf16" if "bf16" in dom else ("f32x3" if "f32x3" in dom else "fp32")]
-    achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    traffic = None
+        name = dom[4:]
+    else:
+        peak = peak_of(dom)
+        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "traffic": None, "kernel": dom, "launches_per_step": n // max(steps, 1), "avg_launch_ms": ms / max(n, 1),
+                "algorithmic_tflop_per_step": fl / max(steps, 1) / 1e12,
+                "other_mfma_kernels": {k: {"TFLOPs": round(v[1] / (v[0] * 1e-3) / 1e12, 1),
+                                           "frac": round(v[1] / (v[0] * 1e-3) / 1e12 / peak_of(k), 3),
+                                           "ms_per_step": round(v[0] / steps, 3)}
+                                       for k, v in kern.items() if k != dom and not k.startswith("hbm:") and v[0] > 0}}
+        name = dom
     tpath = os.path.join(ROOT, "profiles", traffic_file)
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+            roof["traffic"] = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
         except Exception:
-            traffic = None
-    roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "traffic": traffic, "kernel": dom, "launches_per_step": n // max(steps, 1), "avg_launch_ms": ms / max(n, 1),
-            "algorithmic_tflop_per_step": fl / max(steps, 1) / 1e12}
-    fam_ms = {k: round(v[0] / steps, 3) for k, v in fam.items()}
-    return roof, fam_ms
+            roof["traffic"] = None
+    return roof, fam_ms, fam
 
 
+# ----------------------------------------------------------------------------------------------- one rank
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,12 +355,23 @@ def main():
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp32", "fp32x3"])
     ap.add_argument("--bwd", default=None, choices=["bf16"], help="train: opt-in bf16-product backward (not the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="infer: skip the short training leg reported under \"secondary\"")
+    ap.add_argument("--no-secondary", action="store_true", help="infer: skip the training leg reported under \"secondary\"")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))      # launcher: no GPU call has been made in this process
+
+    # stdout carries ONE JSON line and nothing else: libraries that write to fd 1 (gloo's "[Gloo] Rank 0 is connected ..."
+    # banner, RCCL / MIOpen notices) are sent to stderr, the JSON line goes out through a private copy of the original fd
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: reporting the {world} rank(s) that exist", file=sys.stderr)
     # MMR_BENCH_BACKEND=gloo: rehearsal of the N > 1 flow on a one-GPU box (ranks share the card, the gradient
     # exchange goes through the host); the measured configuration is always nccl = RCCL, one rank per GPU.
     backend = os.environ.get("MMR_BENCH_BACKEND", "nccl")
@@ -190,18 +381,16 @@ def main():
     # MMR_FORCE_DIST=1: create the (RCCL) process group even for one rank so that a 1-GPU box runs the same collective
     # code path as the driver's N > 1 launches (tests/test_gpu_rccl.py)
     forced = os.environ.get("MMR_FORCE_DIST", "0") == "1"
-    if world > 1 or forced:
+    use_dist = world > 1 or forced
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1 and "MASTER_PORT" not in os.environ:
-            import socket
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ["MASTER_PORT"] = str(_free_port())
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    use_dist = world > 1 or forced
+    launched = os.environ.get("MMR_BENCH_LAUNCHED") or ("torchrun" if "WORLD_SIZE" in os.environ else "single process")
 
     import mmr
 
@@ -226,7 +415,6 @@ def main():
                         f"enc/dec={feats}, int_steps=5, svf/int_res=2, inputs resident in HBM, 1 pair/step")
             par = f"replicas x{world} (single-pair inference does not shard)"
             cpu_fn = lambda: cpu_baseline_infer(enc, dec, shape, mov, fix)
-            metric, unit, pairs_per_step = "volume-pairs/sec", "pairs/s", 1
         elif wl == "cascade":
             # BASELINE configs[3]: two-step cascade of bids_two_steps_registration.py:311-325,484-499 on one pair --
             # model 1 on (moving, fixed), model 2 on (moved_1, fixed), compose the two half-res fields, rescale x2, warp
@@ -249,7 +437,7 @@ def main():
             workload = (f"bids_two_steps_registration.py cascade (BASELINE configs[3]): 2 x VxmDense {shape[0]}x{shape[1]}x{shape[2]}, "
                         f"enc/dec={feats}, compose + rescale + warp, inputs resident in HBM, 1 pair/step")
             par = f"replicas x{world}"
-            cpu_fn = None
+            cpu_fn = lambda: cpu_baseline_infer(enc, dec, shape, mov, fix, nets=2, budget_s=0.0)   # 1/8 crop: two nets
         elif wl == "train":
             from mmr import synth, training
             shape = tuple(shape_arg or (160, 160, 160))
@@ -276,8 +464,8 @@ def main():
                         f"Grad-l2(reg 1), same_subj pairs, generators + fwd + bwd + all-reduce + Adam, 1 pair per GPU, label maps resident in HBM"
                         + (" [OPT-IN bf16-product backward]" if args.bwd else ""))
             par = f"dp{world} (batch sharded by rank, one SUM all-reduce of {model._flat.numel() * 4 / 1e6:.1f} MB over RCCL)"
-            cpu_fn = lambda: cpu_baseline_train(enc, dec, shape, L)
-            metric, unit, pairs_per_step = "volume-pairs/sec", "pairs/s", 1
+            cpu_fn = lambda: cpu_baseline_train(enc, dec, shape, L, maps[0])
+            extra["allreduce_bytes"] = model._flat.numel() * 4
         else:  # ncc
             shape = tuple(shape_arg or (256, 256, 256))
             dtype = "fp32"
@@ -290,10 +478,9 @@ def main():
                 return mmr.ops.ncc_loss(I, J, 9) + mmr.ops.bending_energy(flow)
             workload = f"local NCC(win 9) + bending energy forward on {shape[0]}^3 fp32 (BASELINE configs[4])"
             par = f"replicas x{world}"
-            cpu_fn = None
-            metric, unit, pairs_per_step = "volume-pairs/sec", "pairs/s", 1
+            cpu_fn = lambda: cpu_baseline_ncc(I, J, flow)
             extra["algorithmic_bytes_per_step"] = int(np.prod(shape)) * 4 * 5
-        return dict(step=step, workload=workload, par=par, cpu_fn=cpu_fn, dtype=dtype, extra=extra)
+        return dict(step=step, workload=workload, par=par, cpu_fn=cpu_fn, dtype=dtype, extra=extra, wl=wl)
 
     def timed(step, warmup, steps):
         for _ in range(warmup):
@@ -314,73 +501,79 @@ def main():
         assert torch.isfinite(last).all()
         return dt, prof
 
-    w = setup(args.workload, args.dtype, args.features, args.shape)
-    dtype, extra, workload, par, cpu_fn = w["dtype"], w["extra"], w["workload"], w["par"], w["cpu_fn"]
-    metric, unit, pairs_per_step = "volume-pairs/sec", "pairs/s", 1
-    dt, prof = timed(w["step"], args.warmup, args.steps)
+    def dist_info(fam, steps):
+        d = {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
+             "backend": dist.get_backend() if dist.is_initialized() else None, "launched_by": launched}
+        ar = fam.get("comm:allreduce_grads") if fam else None
+        if ar:
+            d["allreduce_ms_per_step"] = round(ar[0] / max(steps, 1), 4)
+            d["allreduce_bytes"] = int(ar[1] / max(ar[2], 1))
+        return d
 
-    fp32_grade = None
-    if args.workload == "infer" and dtype == "bf16" and not args.no_secondary:
+    def measure(w, steps, warmup):
+        """One workload -> the fields of a bench line (rank 0 fills cpu_baseline afterwards)."""
+        dt, prof = timed(w["step"], warmup, steps)
+        res = {"metric": "volume-pairs/sec", "value": world * steps / dt, "unit": "pairs/s", "n_gpus": world,
+               "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": w["dtype"], "data": "synthetic",
+               "config": {"workload": w["workload"], "parallelism": w["par"]}}
+        roof, fam_ms, fam = roofline_from_profile(prof, steps, f"traffic_{w['wl']}.json")
+        if w["wl"] == "ncc" and roof:
+            roof["whole_step_GBps"] = w["extra"]["algorithmic_bytes_per_step"] / (dt / steps) / 1e9   # incl. finalize launches
+        if roof:
+            res["roofline"] = roof
+        if fam_ms:
+            res["kernel_family_ms_per_step"] = fam_ms
+        res["dist"] = dist_info(fam, steps)
+        return res
+
+    w = setup(args.workload, args.dtype, args.features, args.shape)
+    res = measure(w, args.steps, args.warmup)
+    if forced and world == 1:
+        res["config"]["collectives"] = "rccl (forced single-rank group)" if backend == "nccl" else backend + " (forced)"
+    cpu_fns = [("cpu_baseline", w["cpu_fn"], res)]
+
+    extras = args.workload == "infer" and not args.no_secondary
+    if extras and w["dtype"] == "bf16":
         # the same workload at the drop-in API's default arithmetic (fp32x3: fp32 tensors, bf16 hi/lo-split products,
         # the 1e-4-grade path of north_star) -- reported beside the bf16 headline, never part of `value`
         try:
             w3 = setup("infer", "fp32x3", args.features, args.shape)
             k3 = max(2, min(args.steps, 3))
             dt3, _ = timed(w3["step"], 1, k3)
-            fp32_grade = {"dtype": "fp32x3", "ms_per_step": dt3 / k3 * 1e3, "value": world * k3 / dt3, "unit": "pairs/s",
-                          "steps": k3, "warmup": 1}
+            res["same_workload_fp32x3"] = {"dtype": "fp32x3", "ms_per_step": dt3 / k3 * 1e3, "value": world * k3 / dt3,
+                                           "unit": "pairs/s", "steps": k3, "warmup": 1}
             del w3
-            torch.cuda.empty_cache()
         except Exception as e:
-            fp32_grade = {"error": f"{type(e).__name__}: {e}"}
-
-    secondary = None
-    if args.workload == "infer" and not args.no_secondary:
-        # the other half of BASELINE.json's metric (configs[2]): a short run of the data-parallel training step, so one
-        # default invocation per N records both; it is outside the timed region above and never enters `value`.
+            res["same_workload_fp32x3"] = {"error": f"{type(e).__name__}: {e}"}
+    if extras:
+        # the other half of BASELINE.json's metric (configs[2]): the data-parallel training step with the SAME K / W,
+        # its own roofline / dist / cpu_baseline; outside the timed region above, never part of `value`.
+        w_keep_cpu = w["cpu_fn"]
         del w
         torch.cuda.empty_cache()
         try:
             w2 = setup("train", None, None, None)
-            k2 = max(2, min(args.steps, 4))
-            dt2, _ = timed(w2["step"], 1, k2)
-            secondary = {"metric": "volume-pairs/sec (160^3 SynthMorph training step)", "value": world * k2 / dt2,
-                         "unit": "pairs/s", "n_gpus": world, "steps": k2, "warmup": 1, "ms_per_step": dt2 / k2 * 1e3,
-                         "dtype": w2["dtype"], "scaling": "weak",
-                         "config": {"workload": w2["workload"], "parallelism": w2["par"]}}
-            del w2
+            sec = measure(w2, args.steps, args.warmup)
+            sec["metric"] = "volume-pairs/sec (160^3 SynthMorph training step)"
+            res["secondary"] = sec
+            cpu_fns.append(("cpu_baseline", w2["cpu_fn"], sec))
         except Exception as e:  # the headline line above must survive a failure of the extra leg
-            secondary = {"error": f"{type(e).__name__}: {e}"}
+            res["secondary"] = {"error": f"{type(e).__name__}: {e}"}
+        cpu_fns[0] = ("cpu_baseline", w_keep_cpu, res)
 
     if rank == 0:
-        res = {"metric": metric, "value": world * pairs_per_step * args.steps / dt, "unit": unit, "n_gpus": world,
-               "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-               "config": {"workload": workload, "parallelism": par}}
-        if forced and world == 1:
-            res["config"]["collectives"] = "rccl (forced single-rank group)" if backend == "nccl" else backend + " (forced)"
-        roof, fam_ms = roofline_from_profile(prof, args.steps, dtype, f"traffic_{args.workload}.json")
-        if args.workload == "ncc" and roof:
-            gbs = extra["algorithmic_bytes_per_step"] / (dt / args.steps) / 1e9
-            roof["whole_step_GBps"] = gbs   # NCC + bending + finalize launches + the torch add, wall clock
-            tf = os.path.join(ROOT, "profiles", "traffic_ncc.json")
-            if os.path.exists(tf):
-                try:
-                    roof["traffic"] = json.load(open(tf)).get(roof["kernel"], {}).get("hbm_bytes_per_launch")
-                except Exception:
-                    pass
-        if roof:
-            res["roofline"] = roof
-        if fam_ms:
-            res["kernel_family_ms_per_step"] = fam_ms
-        if fp32_grade:
-            res["same_workload_fp32x3"] = fp32_grade
-        if secondary:
-            res["secondary"] = secondary
-        if world == 1 and not args.no_cpu_baseline and cpu_fn is not None:
-            res["cpu_baseline"] = cpu_fn()
-        print(json.dumps(res))
+        if world == 1 and not args.no_cpu_baseline:
+            torch.cuda.synchronize()
+            for key, fn, target in cpu_fns:
+                if fn is not None:
+                    try:
+                        target[key] = fn()
+                    except Exception as e:
+                        target[key] = {"error": f"{type(e).__name__}: {e}"}
+        print(json.dumps(res), file=json_out, flush=True)
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -2,26 +2,29 @@
 // implicit GEMM on the gfx950 matrix cores (reference call sites:
 // train_synthmorph.py:296, 3d_reg.py:305; semantics SURVEY.md Appendix A1).
 //
-//   M = output voxels (a 4x8x8 tile = 256 rows per workgroup)
-//   N = Cout tile (BN = 32*WN*NT)
+//   M = output voxels (a 4x8x8 or 8x8x8 tile = 256 / 512 rows per workgroup)
+//   N = Cout tile (BN = 32*WN*NT: 256 / 128 / 64 / 32)
 //   K = 27 taps x Cin, walked as  slice (128 B of channels) -> tap -> k-step
 //
 // Data movement per workgroup (512 threads = 8 waves, 1 workgroup / CU):
-//   * A: the haloed input tile (6x10x10 voxels x 128 B of channels) is staged
-//     ONCE per channel slice into LDS (rows padded to 144 B so that b128
-//     fragment reads of consecutive voxels spread over the banks); all 27 taps
-//     read it with a constant per-tap address offset -> every input byte is
-//     fetched from L2/HBM 2.3x (halo) instead of 27x.  The loader folds
-//     UpSampling3D(2) (nearest) and the skip concatenation, so neither tensor
-//     is ever materialised.
+//   * A: the haloed input tile ((TXT+2)x10x10 voxels x 128 B of channels) is staged ONCE per channel slice into
+//     LDS -- bf16 / exact fp32 by LDS-DMA (global_load_lds_dwordx4, swizzle applied to the SOURCE chunk, out-of-
+//     volume rows from a zero page), fp32x3 through registers because the hi/lo split happens on the way -- as
+//     unpadded 128-B rows whose 16-B chunks are XOR-swizzled on the halo coordinates (swz / swz16: conflict-free
+//     ds_read_b128 for every tap); all 27 taps read it with a constant per-tap address offset -> every input
+//     byte is fetched from L2/HBM 2.3x (halo) instead of 27x.  The loader folds UpSampling3D(2) (nearest) and the
+//     skip concatenation, so neither tensor is ever materialised.
 //   * B: weights are pre-packed (mmr_conv3d_k3_pack) into the exact LDS image
-//     [tile][slice][tap][16B-chunk][cout][16 B]; each tap's BN x 128 B block is
-//     streamed with global_load_lds (LDS-DMA, 16 B/lane) into a double buffer
-//     while the previous tap computes.
-//   * MFMA: bf16 -> v_mfma_f32_32x32x16_bf16 (fp32 accumulate);
-//           fp32 -> v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain).
-//     Both element types share the byte-level layout (a 16 B chunk = 8 bf16 or
-//     4 fp32 consecutive input channels), so one kernel template serves both.
+//     [tile][slice][tap][16B-chunk][cout][16 B]; each tap's BN x 128 B block is streamed by LDS-DMA into a double
+//     buffer while the previous tap computes (BN = 256 bf16: issued by waves 0-3 from two points INSIDE their
+//     MFMA stream, see MIDDMA).
+//   * MFMA: bf16 / fp32x3 -> v_mfma_f32_16x16x32_bf16 with the product formed transposed (weights as the A
+//     operand) so that a lane owns 16 consecutive couts of one voxel; fp32 -> v_mfma_f32_32x32x2_f32 (exact fp32
+//     FMA chain); BN = 32 -> v_mfma_f32_32x32x16_bf16.  All element types share the byte-level layout (a 16-B
+//     chunk = 8 bf16, 4 fp32, or 8 hi / 8 lo halves), so one kernel template serves them.
+// Variants that were measured and rejected (XCD-aware tile order, split / top-of-tap weight-DMA placements, two
+// taps per barrier, s_setprio switching, fragment reuse across dz, ...) are recorded in DESIGN.md 2.2 with their
+// numbers and live in the git history only.
 #include "common.hpp"
 
 #include <stdlib.h>
@@ -39,7 +42,7 @@ constexpr int ROWB = 128;                             // 128 B of channels, XOR-
 constexpr int A_BYTES = HROWS * ROWB;                 // 86400
 constexpr int CONV_THREADS = 512;
 
-// 16 zero bytes that out-of-volume halo rows are DMA'd from (VAR bit 8)
+// 16 zero bytes that out-of-volume halo rows are DMA'd from (CV_DMA_A)
 __device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
 struct ConvParams {
@@ -74,10 +77,19 @@ struct ConvParams {
 
 template <int N> struct IntTag { static constexpr int value = N; };
 
-// Diagnostic build only (VAR bit 10, MMR_CONV_VARIANT=1440): where a tap's cycles go.  Per wave slot w (0..7) the sums over
-// all workgroups of: [0] tap top -> weight DMA issued, [1] -> last MFMA issued (fragment reads + MFMAs), [2] -> own DMA
-// landed (vmcnt 0), [3] -> barrier passed, [4] A restage (per slice), [5] number of taps.  s_memtime ticks.  Read the
-// SHARES, never the run time of this build (cdna_hip_programming.md section 7, in-kernel stamps).
+// Variant bits of conv3d_k3_kernel's VAR parameter (the per-tile defaults are chosen in dispatch_conv)
+constexpr int CV_M16 = 1 << 5;      // 16x16x32 MFMA with the transposed product (every dtype but exact fp32, N tiles >= 64)
+constexpr int CV_PIPE = 1 << 7;     // fragment schedule of a tap written out with sched_group_barrier
+constexpr int CV_DMA_A = 1 << 8;    // bf16 / exact fp32: the haloed A tile goes global -> LDS by DMA
+constexpr int CV_STAMP = 1 << 10;   // cycle stamps (only with -DMMR_DIAG; never the measured build)
+constexpr int CV_BATCHA = 1 << 12;  // fp32x3 / x1: all staging loads of a slice issued branch-free, masked when stored
+constexpr int CV_PRIO_Y = 1 << 15;  // static s_setprio 1 for waves 4-7
+
+#ifdef MMR_DIAG
+// Diagnostic build only (CV_STAMP): where a tap's cycles go.  Per wave slot w (0..7) the sums over all workgroups of:
+// [0] tap top -> weight DMA issued, [1] -> last MFMA issued (fragment reads + MFMAs), [2] -> own DMA landed (vmcnt 0),
+// [3] -> barrier passed, [4] A restage (per slice), [5] number of taps.  s_memtime ticks.  Read the SHARES, never the
+// run time of this build (cdna_hip_programming.md section 7, in-kernel stamps).
 __device__ unsigned long long g_conv_stamp[8][8];
 __device__ __forceinline__ unsigned long long stamp_now()
 {
@@ -87,6 +99,10 @@ __device__ __forceinline__ unsigned long long stamp_now()
     __builtin_amdgcn_sched_barrier(0);
     return t;
 }
+#define MMR_STAMP(k) do { if constexpr (STAMP) { const unsigned long long t_ = stamp_now(); st_acc[k] += t_ - st_t; st_t = t_; } } while (0)
+#else
+#define MMR_STAMP(k) do { } while (0)
+#endif
 
 template <int DT> struct Elt;
 template <> struct Elt<MMR_DT_BF16> { static constexpr int size = 2; static constexpr int kc = 64; };
@@ -159,9 +175,6 @@ __device__ __forceinline__ int row_perm(int r)
     return r + d;
 }
 
-// VAR bit 5: 16x16x32 MFMA with the transposed product (default for N tiles >= 64); bit 6: XCD-aware tile order.
-// (Retired after measurement, see DESIGN.md 2.2: fragment double-buffering, A-slice register prefetch -- together
-// they exceed 256 VGPRs at the 128x64 wave tile --, dz-shifted fragment reuse, cross-barrier A prefetch.)
 template <int DT, int WM, int WN, int MT, int NT, int VAR>
 __global__ void __launch_bounds__(CONV_THREADS, 2)
 conv3d_k3_kernel(const ConvParams p)
@@ -172,45 +185,25 @@ conv3d_k3_kernel(const ConvParams p)
     constexpr int HXT = TXT + 2;
     constexpr int HROWS_T = HXT * HY * HZ;
     constexpr int A_BYTES_T = HROWS_T * ROWB;
-    // VAR bit 5: v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (bf16 only): same bytes per flop, the chip holds
-    // a higher clock on this shape (MI355X_MICROARCH.md, DVFS give-back item 7)
-    constexpr bool M16 = ((VAR >> 5) & 1) && (DT == MMR_DT_BF16 || DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1);
+    // CV_M16: v_mfma_f32_16x16x32_bf16 instead of 32x32x16: same bytes per flop, the chip holds a higher clock on
+    // this shape (MI355X_MICROARCH.md, DVFS give-back item 7)
+    constexpr bool M16 = ((VAR & CV_M16) != 0) && (DT == MMR_DT_BF16 || DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1);
     constexpr bool LO = (DT == MMR_DT_F32X3);  // lo halves staged and multiplied
-    constexpr bool PIPE = M16 && (DT == MMR_DT_BF16) && MT == 4 && ((VAR >> 7) & 1);  // VAR bit 7: explicit fragment pipeline
-    constexpr bool PIPE3 = M16 && (DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) && ((VAR >> 7) & 1);
-    // VAR bit 9: the weight DMA of the next tap is issued from INSIDE the MFMA stream instead of at the top of the tap,
-    // and at different points for the two waves of a SIMD (waves w and w + 4 share one): while one wave spends its
-    // issue slots on the four global_load_lds, its partner keeps the matrix pipe fed.  Issued at the top of the tap by
-    // both, the DMA (and the fragment round trip behind it) left the pipe idle right after every barrier.
-    constexpr bool MIDDMA = PIPE && ((VAR >> 9) & 1);
-    constexpr bool STAMP = ((VAR >> 10) & 1) != 0;
-    // VAR bit 11: split placement of the next tap's weight DMA.  The cycle stamps (tools/conv_stamps.py) show that the
-    // older half of the workgroup (waves 0-3; wave w shares a SIMD with wave w + 4 and wins the issue arbitration by age)
-    // finishes its 64 MFMAs ~700 clk before the younger half and then idles at the barrier, while at the top of the tap
-    // BOTH halves spend 220-340 clk issuing their four global_load_lds with the matrix pipe empty.  So waves 0-3 issue
-    // their share AFTER their MFMAs (inside the time they would wait at the barrier anyway) and start the tap's
-    // fragment reads at once; waves 4-7 keep issuing at the top, now under the older waves' MFMAs.
-    constexpr bool SPLITDMA = (PIPE || PIPE3) && !MIDDMA && ((VAR >> 11) & 1);
-    constexpr bool BATCHA = (DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) && ((VAR >> 12) & 1);
-    // VAR bit 13 (with bit 11): waves 0-3 issue the weight DMA of BOTH halves after their MFMAs (their own pieces and the
-    // pieces of wave w + 4), waves 4-7 issue none and start every tap with their fragment reads
-    constexpr bool ALLOLD = SPLITDMA && ((VAR >> 13) & 1);
-    // VAR bits 9 + 13: the two mid-stream issue points of MIDDMA, both used by waves 0-3 only (their own pieces at the
-    // first, the pieces of wave w + 4 at the second); waves 4-7 never issue
-    constexpr bool MIDOLD = MIDDMA && ((VAR >> 13) & 1);
-    // VAR bit 14 (64-column tile only: four 8-KB weight buffers fit beside the A tile): TWO taps per barrier interval.  The
-    // stamps of the fp32x3 training conv show ~390 clk per tap of 2 380 at the top-of-tap DMA issue, the vmcnt(0) and the
-    // barrier, against 48 MFMAs per wave: pairs (0,1) .. (24,25), then tap 26 alone in front of the A restage.
-    constexpr bool PAIR = ((VAR >> 14) & 1) != 0;
-    // VAR bit 15: static priority for the younger half of the workgroup (waves 4-7: s_setprio 1 once, in front of the loop).
-    // VAR bit 16 (with 15): the older half starts every tap at priority 2 and drops to 0 after half of its MFMAs, so that
-    // the matrix pipe goes to the older wave of a SIMD first and to the younger one second and both reach the barrier
-    // together (by age alone the older wave finishes ~700 clk early and the younger one then runs alone at 22 instead of
-    // 16 clk per MFMA).
-    constexpr bool PRIO_Y = ((VAR >> 15) & 1) != 0;
-    constexpr bool PRIO_SW = PRIO_Y && ((VAR >> 16) & 1) != 0;
-    constexpr bool PRIO_EARLY = ((VAR >> 17) & 1) != 0;   // main conv: switch at the first DMA issue point instead of the second
+    // CV_PIPE, bf16 128x64 wave tile: explicit fragment pipeline, and the weight DMA of the next tap is issued from
+    // INSIDE the MFMA stream by waves 0-3 only (wave w shares a SIMD with wave w + 4 and wins the issue arbitration by
+    // age): their own pieces after MFMA group 4 of 16, the pieces of wave w + 4 after group 10; waves 4-7 never issue.
+    // Issued at the top of the tap by everyone, the DMA (and the fragment round trip behind it) left the matrix pipe
+    // idle for 220-340 clk right after every barrier (cycle stamps).
+    constexpr bool MIDDMA = M16 && (DT == MMR_DT_BF16) && MT == 4 && ((VAR & CV_PIPE) != 0);
+    constexpr bool PIPE3 = M16 && (DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) && ((VAR & CV_PIPE) != 0);
+    constexpr bool BATCHA = (DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) && ((VAR & CV_BATCHA) != 0);
+    // static priority for the younger half of the workgroup (-1 % on the 64-column fp32x3 tile, +14 % on the 256-column
+    // bf16 tile whose DMA issue needs waves 0-3 to be the arbitration winners)
+    constexpr bool PRIO_Y = (VAR & CV_PRIO_Y) != 0;
+#ifdef MMR_DIAG
+    constexpr bool STAMP = (VAR & CV_STAMP) != 0;
     unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = 0;
+#endif
     static_assert(WM * WN == 8, "8 waves");
     static_assert(TXT == 4 || TXT == 8, "M tile");
     constexpr int BN = WN * NT * 32;
@@ -218,7 +211,6 @@ conv3d_k3_kernel(const ConvParams p)
     constexpr int KC = Elt<DT>::kc;
     constexpr int B_BYTES = BN * 128;
     constexpr int B_ITERS = B_BYTES / (CONV_THREADS * 16);
-    static_assert(!PAIR || (A_BYTES_T + 4 * B_BYTES <= 160 * 1024 && !MIDDMA && !SPLITDMA), "PAIR: LDS budget / DMA placement");
     constexpr int A_ITERS = (((DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) ? HROWS_T * 4 : HROWS_T * 8) + CONV_THREADS - 1) / CONV_THREADS;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -231,15 +223,7 @@ conv3d_k3_kernel(const ConvParams p)
     const int wm = wave / WN, wn = wave % WN;
     const int h = lane >> 5;
 
-    // Optional XCD-aware tile order (VAR bit 6): blocks are dealt round-robin over the 8 XCDs (b and b+8 share
-    // one); giving every XCD a contiguous run of spatial tiles lets neighbours share halo rows in one L2.
-    // Measured on C2: 1 % SLOWER than the plain order (all XCDs then stream the same weights and halo
-    // neighbourhood at the same time through the Infinity Cache), so it is off by default.
     int bid = blockIdx.x;
-    if constexpr (((VAR >> 6) & 1) != 0) {
-        const int nwg = gridDim.x, xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
-        bid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-    }
     const int tzi = bid % p.ntz; bid /= p.ntz;
     const int tyi = bid % p.nty; bid /= p.nty;
     const int txi = bid % p.ntx;
@@ -322,7 +306,7 @@ conv3d_k3_kernel(const ConvParams p)
         }
         return val;
     };
-    // VAR bit 12 (fp32x3 / x1): the same items, but every lane loads from a clamped, always-valid address and returns the
+    // CV_BATCHA (fp32x3 / x1): the same items, but every lane loads from a clamped, always-valid address and returns the
     // in-bounds flag separately, so that all loads of a slice can be issued back to back and masked when they are stored.
     // `if (in bounds) load` compiles to a branch + wait per item: the 8 items of a slice were 8 dependent round trips
     // (6.7 k cycles per slice on the stamps of tools/conv_stamps.py train).
@@ -388,7 +372,7 @@ conv3d_k3_kernel(const ConvParams p)
         const unsigned t16 = (unsigned)((ws_ << 6) | lane) * 16u;
 #pragma unroll
         for (int it = 0; it < B_ITERS; ++it) {
-            if constexpr (MIDDMA || SPLITDMA) glds16_s(wt + it * CONV_THREADS * 16, wv < 0 ? tid16 : t16, dst + it * CONV_THREADS * 16);
+            if constexpr (MIDDMA) glds16_s(wt + it * CONV_THREADS * 16, wv < 0 ? tid16 : t16, dst + it * CONV_THREADS * 16);
             else glds16(wt + (it * CONV_THREADS + tid) * 16, dst + it * CONV_THREADS * 16);
         }
         if (B_BYTES < CONV_THREADS * 16) {
@@ -396,10 +380,10 @@ conv3d_k3_kernel(const ConvParams p)
         }
     };
 
-    // VAR bit 8 (bf16 / exact fp32, no conversion on the way): the haloed A tile goes global -> LDS by DMA as well.
+    // CV_DMA_A (bf16 / exact fp32, no conversion on the way): the haloed A tile goes global -> LDS by DMA as well.
     // Lane i of an instruction lands at base + 16 i, i.e. at (row, chunk position) = (i >> 3, i & 7) of the swizzled
     // tile, so the swizzle is applied to the SOURCE chunk; out-of-volume rows read a zero page.
-    constexpr bool DMA_A = !X3 && ((VAR >> 8) & 1);
+    constexpr bool DMA_A = !X3 && ((VAR & CV_DMA_A) != 0);
     const unsigned sA_lds = lds_addr(sA);
     auto dma_stage_a = [&](int s) {
         const int ch0 = s * KC;
@@ -432,9 +416,6 @@ conv3d_k3_kernel(const ConvParams p)
     const int g1 = p.kpart ? min(g0 + p.gsplit, G) : G;
     int cur = 0, tap = g0 % 27, s = g0 / 27;
     issue_b(g0, 0);
-    if constexpr (PAIR) {
-        if (tap < 26 && g0 + 1 < g1) issue_b(g0 + 1, 1);
-    }
     // a macro, not a lambda: wrapped in one more closure, hipcc no longer scalarises the by-value kernel argument
     // struct and every instantiation reads ConvParams from scratch (288 B/lane; the bn64 convs ran 1.8x slower)
     // named scalars, not an array: an indexed array of structs stays in scratch here even when unrolled
@@ -487,36 +468,20 @@ conv3d_k3_kernel(const ConvParams p)
         if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     }
 
-    for (int g = g0; g < g1;) {
-        int ntap = 1;                                  // taps of this barrier interval
-        if constexpr (PAIR) ntap = (tap < 26 && g + 1 < g1) ? 2 : 1;
-        const int gn = g + ntap;                       // first tap of the next interval
-        const bool more = gn < g1;
-        if constexpr (PRIO_SW) {
-            if (wave < 4) __builtin_amdgcn_s_setprio(2);
-        }
+    for (int g = g0; g < g1; ++g) {
+        const bool more = g + 1 < g1;
+#ifdef MMR_DIAG
         if constexpr (STAMP) st_t = stamp_now();
-        if constexpr (ALLOLD) {
-        } else if constexpr (SPLITDMA) {
-            if (more && wave >= 4) issue_b(g + 1, cur ^ 1);
-        } else if constexpr (PAIR) {
-            if (more) {
-                const int tapn = (tap + ntap == 27) ? 0 : tap + ntap;
-                issue_b(gn, (cur ^ 1) * 2);
-                if (tapn < 26 && gn + 1 < g1) issue_b(gn + 1, (cur ^ 1) * 2 + 1);
-            }
-        } else if constexpr (!MIDDMA) {
+#endif
+        if constexpr (!MIDDMA) {
             if (more) issue_b(g + 1, cur ^ 1);
         }
-        if constexpr (STAMP) { const unsigned long long t = stamp_now(); st_acc[0] += t - st_t; st_t = t; }
-#pragma unroll 1
-        for (int jt = 0; jt < ntap; ++jt) {
-        const int tpj = tap + jt;
-        const int dx = tpj / 9, dy = (tpj / 3) % 3, dz = tpj % 3;
+        MMR_STAMP(0);
+        const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
         const int tapoff = (dx * (HY * HZ) + dy * HZ + dz) * ROWB;
         const int sw = (swz(vyl + dy, vz + dz) ^ h) << 4;
         const char* bA = sA + tapoff;
-        const char* bB = sB + (PAIR ? cur * 2 + jt : cur) * B_BYTES;
+        const char* bB = sB + cur * B_BYTES;
         if constexpr (M16) {
             const int sw16 = swz16((r16 & 7) + dz);
             if constexpr (X3 && PIPE3) {

@@ -272,7 +272,8 @@ class SynthMorphTrainer:
     def train_step(self, src_labels, trg_labels, draws_1=None, draws_2=None):
         out = self.forward_backward(src_labels, trg_labels, draws_1, draws_2, train=True)
         if self.world > 1 or parallel.forced():
-            parallel.allreduce_sum_(self.gflat, self.pg)  # one 5.8 MB (64f) message
+            with ops._Timed("comm:allreduce_grads", (self.world,), float(self.gflat.numel() * 4)):
+                parallel.allreduce_sum_(self.gflat, self.pg)  # one 5.8 MB (64f) message
         self.opt.apply(self.model._flat, self.gflat, grad_scale=1.0 / self.world)
         self.model.invalidate_packed()
         return out

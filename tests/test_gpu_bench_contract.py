@@ -13,8 +13,12 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
         "dtype", "data", "config"}
 
 
-def _run(*args):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600)
+def _run(*args, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900, env=e)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout
@@ -30,6 +34,34 @@ def test_infer_line_small():
     assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert d["dist"]["world_size"] == 1 and d["dist"]["backend"] is None
+
+
+def test_default_line_carries_both_halves_of_the_metric():
+    """The line the driver records: primary = inference, secondary = the training step with the SAME steps / warm-up,
+    each with its own roofline and cpu_baseline."""
+    d = _run("--shape", "32", "32", "32", "--features", "32", "--steps", "2", "--warmup", "1")
+    sec = d["secondary"]
+    assert "error" not in sec, sec
+    assert sec["steps"] == d["steps"] == 2 and sec["warmup"] == d["warmup"] == 1 and sec["dtype"] == "fp32x3"
+    for leg in (d, sec):
+        assert leg["roofline"]["frac"] > 0 and leg["cpu_baseline"]["value"] > 0 and leg["cpu_baseline"]["kind"] == "port"
+    assert "whole SynthMorph step" in sec["cpu_baseline"]["sample"]
+
+
+def test_gpus_2_starts_two_ranks():
+    """`python bench.py --gpus 2` without torchrun: the launcher starts two fresh rank processes (before touching the GPU)
+    and the line reports the group they formed.  On this one-GPU box the ranks share the card and exchange gradients over
+    gloo (MMR_BENCH_BACKEND); the driver's 8-GPU run takes the same path with nccl = RCCL."""
+    d = _run("--gpus", "2", "--workload", "train", "--shape", "32", "32", "32", "--features", "32", "--steps", "2", "--warmup", "1",
+             env={"MMR_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["dist"] == {**d["dist"], "world_size": 2, "backend": "gloo", "launched_by": "self"}
+    assert d["dist"]["allreduce_ms_per_step"] > 0 and d["dist"]["allreduce_bytes"] > 0 and "dp2" in d["config"]["parallelism"]
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    d = _run("--gpus", "2", "--shape", "32", "32", "32", "--features", "32", "--steps", "2", "--warmup", "1",
+             env={"MMR_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["dist"]["world_size"] == 2 and d["secondary"]["n_gpus"] == 2
+    assert d["secondary"]["dist"]["allreduce_ms_per_step"] > 0 and "cpu_baseline" not in d
 
 
 def test_train_and_ncc_lines_small():

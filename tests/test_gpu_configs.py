@@ -75,6 +75,42 @@ def test_c4_two_step_cascade_matches_oracle(dev):
     assert tr.shape == (1,) + shape + (1,)
 
 
+def test_c4_cascade_bf16_256_features_matches_bf16_oracle(dev):
+    """The BENCHMARKED cascade arithmetic (bench.py --workload cascade: bf16, enc/dec = 256) on 32x32x48 against the
+    oracle that rounds conv inputs / weights to bf16 at the same points (bids_two_steps_registration.py:318-325):
+    stage 2 sees stage 1's moved image, the two half-res fields are composed, rescaled x2 and applied."""
+    import mmr
+    from oracle import net_np
+    from oracle import ops_np as O
+    shape, enc, dec = (32, 32, 48), [256] * 4, [256] * 6
+    rng = np.random.default_rng(4)
+    import scipy.ndimage as ndi
+    n = lambda v: ((v - v.min()) / (v.max() - v.min())).astype(np.float32)[None, ..., None]
+    mov, fix = n(ndi.gaussian_filter(rng.random(shape), 2.0)), n(ndi.gaussian_filter(rng.random(shape), 2.0))
+    w1 = net_np.init_weights(enc, dec, seed=1, flow_std=1e-2)
+    w2 = net_np.init_weights(enc, dec, seed=2, flow_std=1e-2)
+    kw = dict(nb_unet_features=(enc, dec), int_steps=5, int_resolution=2, svf_resolution=2, compute_dtype="bf16")
+    m1, m2 = mmr.networks.VxmDense(shape, **kw), mmr.networks.VxmDense(shape, **kw)
+    m1.set_weights(w1)
+    m2.set_weights(w2)
+    moved1, warp1 = m1.predict([mov, fix])
+    moved, warp2 = m2.predict([moved1, fix])
+    warp = mmr.utils.compose([warp1[0], warp2[0]])
+    final = mmr.networks.Transform(shape, interp_method="linear", rescale=2, nb_feats=1).predict([mov, warp[None]])
+    r1 = net_np.vxm_dense_forward(mov, fix, w1, enc, dec, 5, 2, 2, quant=net_np.bf16_round)
+    r2 = net_np.vxm_dense_forward(r1["moved"], fix, w2, enc, dec, 5, 2, 2, quant=net_np.bf16_round)
+    ref_warp = O.compose(r1["preint_flow"][0], r2["preint_flow"][0])
+    ref_final = O.transform(mov[0], O.rescale_dense_transform(ref_warp, 2), "linear")[None]
+    assert np.abs(ref_warp).max() > 0.25, "composed field too small to be meaningful"
+    errs = {"moved_1": np.abs(moved1 - r1["moved"]).max() / np.abs(r1["moved"]).max(),
+            "moved_2": np.abs(moved - r2["moved"]).max() / np.abs(r2["moved"]).max(),
+            "composed_warp": np.abs(warp - ref_warp).max() / np.abs(ref_warp).max(),
+            "final": np.abs(final - ref_final).max() / np.abs(ref_final).max()}
+    print("C4 cascade bf16 / 256 features: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    for k, v in errs.items():
+        assert v < 3e-2, f"{k}: {v:.3e}"
+
+
 def test_pair_registration_flow_files(dev, tmp_path):
     """3d_reg.py / bids_registration.py flow end to end on synthetic NIfTI files: whole volume and sub-volumes,
     one model and the two-step cascade; outputs written like the reference (moved image + RAI warp, intent 1007)."""

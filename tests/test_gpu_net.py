@@ -129,3 +129,35 @@ def test_vxmdense_256_features_matches_oracle(dev, dtype, tol):
     print(f"256-feature whole-net parity [{dtype}]: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
     for name, err in errs.items():
         assert err < tol, f"{name}: rel-to-scale err {err:.3e} >= {tol}"
+
+
+def test_vxmdense_256_features_80x80x96_matches_torch_oracle(dev):
+    """Whole-network parity where the benchmark's launch geometry starts: 80x80x96 (an eighth of BASELINE configs[1]'s
+    voxels), enc/dec = 256 -- 2 400 workgroups per full-res conv launch, no split-K at full resolution, split-K only at
+    the two coarsest levels, an x-segmented flow head -- in the API's default arithmetic (fp32x3) against
+    oracle/net_torch.vxm_dense_forward (torch-CPU fp32; itself checked against oracle/net_np.py on CPU).  north_star's
+    1e-4 on every output."""
+    import mmr
+    from oracle import net_np, net_torch
+    shape, enc, dec = (80, 80, 96), [256] * 4, [256] * 6
+    rng = np.random.default_rng(21)
+    mov, fix = _pair(rng, shape)
+    weights = net_np.init_weights(enc, dec, seed=7, flow_std=1e-2)
+    for i in range(1, len(weights), 2):
+        weights[i] = (rng.standard_normal(weights[i].shape) * 0.05).astype(np.float32)
+    model = mmr.networks.VxmDense(shape, nb_unet_features=(enc, dec), int_steps=5, int_resolution=2,
+                                  svf_resolution=2, compute_dtype="fp32x3")
+    model.set_weights(weights)
+    moved, preint = model.predict([mov, fix])
+    pos = model.references.pos_flow.cpu().numpy()
+    ref = net_torch.vxm_dense_forward(torch.from_numpy(mov), torch.from_numpy(fix), net_torch.prepare_weights(weights),
+                                      enc, dec, 5, 2, 2)
+    ref = {k: v.numpy() for k, v in ref.items()}
+    assert np.abs(ref["pos_flow"]).max() > 0.5, "test flow too small to be meaningful"
+    errs = {}
+    for name, got, exp in (("preint_flow", preint, ref["preint_flow"]), ("pos_flow", pos, ref["pos_flow"]),
+                           ("moved", moved, ref["moved"])):
+        errs[name] = np.abs(got - exp).max() / np.abs(exp).max()
+    print("80x80x96 / 256-feature whole-net parity [fp32x3]: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    for name, err in errs.items():
+        assert err < 1e-4, f"{name}: rel-to-scale err {err:.3e} >= 1e-4"

@@ -174,13 +174,13 @@ def test_ncc_bending(dev, shape):                                               
     I = rng.random((2,) + shape + (1,)).astype(np.float32)
     J = rng.random((2,) + shape + (1,)).astype(np.float32)
     got = _np(mmr.losses.NCC(win=9).loss(I, J))
-    np.testing.assert_allclose(got, O.ncc_loss(I, J, 9), rtol=2e-4)
+    np.testing.assert_allclose(got, O.ncc_loss(I, J, 9), rtol=1e-5)   # measured <= 1e-7 (tools/ncc_error_probe.py)
     same = _np(mmr.losses.NCC(win=9).loss(I, I))
-    np.testing.assert_allclose(same, O.ncc_loss(I, I, 9), rtol=2e-4)
+    np.testing.assert_allclose(same, O.ncc_loss(I, I, 9), rtol=1e-5)
     assert np.all(same < -0.99)
     # affine intensity change: invariant away from the zero-padded border only, so compare with the oracle
     J2 = (2.0 * I + 0.5).astype(np.float32)
-    np.testing.assert_allclose(_np(mmr.losses.NCC().loss(I, J2)), O.ncc_loss(I, J2, 9), rtol=2e-4)
+    np.testing.assert_allclose(_np(mmr.losses.NCC().loss(I, J2)), O.ncc_loss(I, J2, 9), rtol=1e-5)
     flow = _rand_flow(rng, (2,) + shape, 2.0)
     np.testing.assert_allclose(_np(mmr.losses.BendingEnergy().loss(None, flow)), O.bending_energy(flow), rtol=1e-5)
     lin = np.zeros((1,) + shape + (3,), np.float32)

@@ -280,7 +280,8 @@ def test_adam_matches_keras_formula(dev):
 
 _ARCHS = [([32, 32], [32, 32, 32]),               # 32-wide: 32x32 MFMA kernels (BN = 32)
           ([64, 64], [64, 64, 64]),               # 64-wide: 16x16x32 kernels with the transposed epilogue
-          ([32, 64, 64], [64, 64, 32, 32, 32])]   # three levels, mixed widths
+          ([32, 64, 64], [64, 64, 32, 32, 32]),   # three levels, mixed widths
+          ([64] * 4, [64] * 6)]                   # BASELINE configs[2] exactly: config/config.json:44-45 (4 levels, 64 wide)
 
 
 @pytest.mark.parametrize("cdt,kinks,tol", [("fp32", False, 2e-4), ("fp32", True, 1e-4), ("fp32x3", True, 1e-4)])
@@ -537,12 +538,12 @@ def test_ncc_and_bending_backward(dev, shape):
     assert np.allclose(loss.detach().numpy(), O.ncc_loss(I, J, 9), rtol=1e-9)  # the torch restatement IS the oracle formula
     (loss * torch.from_numpy(gout).double()).sum().backward()
     dI, dJ = mmr.ops.ncc_loss_bwd(_t(I, dev), _t(J, dev), _t(gout, dev))
-    assert _rel(dI, It.grad) < 2e-4 and _rel(dJ, Jt.grad) < 2e-4
+    assert _rel(dI, It.grad) < 2e-5 and _rel(dJ, Jt.grad) < 2e-5   # measured <= 5e-6 (tools/ncc_error_probe.py)
     only_j = mmr.losses.NCC(9).grad(_t(I, dev), _t(J, dev))
     Jt.grad = None
     It.grad = None
     G.ncc_loss(It, Jt).sum().backward()
-    assert _rel(only_j, Jt.grad) < 2e-4
+    assert _rel(only_j, Jt.grad) < 2e-5
 
     u = (rng.standard_normal((B,) + shape + (3,)) * 2).astype(np.float32)
     ut = torch.from_numpy(u).double().requires_grad_(True)

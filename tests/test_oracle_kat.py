@@ -254,3 +254,18 @@ def test_torch_cpu_baseline_graph_equals_numpy_oracle():
     assert np.abs(ref["pos_flow"]).max() > 0.3
     for k in ("moved", "preint_flow", "pos_flow"):
         assert np.abs(got[k].numpy() - ref[k]).max() < 2e-5 * max(np.abs(ref[k]).max(), 1), k
+
+
+def test_cpu_training_step_restatement_runs_and_learns():
+    """oracle/train_torch.CpuStep (bench.py's training cpu_baseline): generators + fwd + bwd + Adam in fp32 on torch-CPU;
+    its loss equals the float64 gradient oracle's on the same generated pair and Adam moves the weights."""
+    import torch
+    from oracle import grad_torch as G, train_torch
+    rng = np.random.default_rng(0)
+    lab = np.repeat(np.repeat(np.repeat(rng.integers(0, 4, (4, 4, 4)), 4, 0), 4, 1), 4, 2).astype(np.uint8)
+    st = train_torch.CpuStep(lab, 4, [8, 8], [8, 8, 8], lr=1e-2, seed=1, warp_res=(8,), bias_res=(8,))
+    w0 = [w.detach().clone() for w in st.ws]
+    losses = [st.step() for _ in range(4)]
+    assert all(np.isfinite(l) for l in losses) and G.DT == torch.float64   # the dtype switch is restored
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(w0, st.ws))
+    assert 0.0 < losses[-1] < 2.0
