@@ -10,6 +10,7 @@ from ctypes import c_float, c_int, c_int64, c_uint8, c_uint32, c_uint64, c_void_
 from . import build as _build
 
 _LIB = None
+ABI_VERSION = 100   # mmr_version() of csrc/api.hip
 
 P = c_void_p
 I = c_int
@@ -118,7 +119,11 @@ def load():
     if _LIB is not None:
         return _LIB
     path = lib_path()
-    if not os.environ.get("MMR_LIB") and _build.needs_build():
+    try:
+        stale = not os.environ.get("MMR_LIB") and _build.needs_build()
+    except OSError as e:
+        raise MmrError(f"cannot check {path} against its sources: {e}") from e
+    if stale:
         have_hipcc = os.path.exists(_build.hipcc_path())
         if not os.path.exists(path) or have_hipcc:
             try:
@@ -135,6 +140,8 @@ def load():
             raise MmrError(f"{path} does not export {name}; rebuild with __graft_entry__.build()") from e
         fn.restype = res
         fn.argtypes = args
+    if os.environ.get("MMR_LIB") and lib.mmr_version() != ABI_VERSION:   # a hand-picked library skips the source-hash check
+        raise MmrError(f"{path} reports ABI version {lib.mmr_version()}, this binding expects {ABI_VERSION}")
     _LIB = lib
     return lib
 

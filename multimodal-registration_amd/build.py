@@ -26,9 +26,13 @@ def sources():
 
 
 def source_hash():
+    """Content hash of everything the library is built from.  include/mmr.h lives at the repo root; a relocated package
+    without it still hashes (and loads) its own sources."""
     h = hashlib.sha256(" ".join(FLAGS).encode())
     deps = sources() + [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "..", "..", "include", "mmr.h")]
     for d in deps:
+        if not os.path.exists(d):
+            continue
         with open(d, "rb") as f:
             h.update(os.path.basename(d).encode() + b"\0" + f.read())
     return h.hexdigest()
@@ -81,5 +85,35 @@ def build(force=False, verbose=False):
     return LIB
 
 
+DIAG_LIB = os.path.join(CSRC, "libmmr_hip_diag.so")
+
+
+def build_diag(verbose=False):
+    """Diagnostic twin of the library (-DMMR_DIAG): adds the cycle-stamped instantiations of the conv / wgrad kernels and
+    the mmr_debug_* exports that tools/conv_stamps.py and tools/wgrad_stamps.py read.  Never the measured or shipped
+    build; load it with MMR_LIB=<path>."""
+    hipcc = hipcc_path()
+    tmp = tempfile.mkdtemp(prefix=".build-", dir=CSRC)
+    try:
+        objs, procs = [], []
+        for s in sources():
+            o = os.path.join(tmp, os.path.basename(s)[:-4] + ".o")
+            objs.append(o)
+            cmd = [hipcc] + FLAGS + ["-DMMR_DIAG", "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd)))
+        failed = [cmd for cmd, p in procs if p.wait() != 0]
+        if failed:
+            raise RuntimeError("hipcc failed: " + " ".join(failed[0]))
+        out = os.path.join(tmp, "libmmr_hip_diag.so")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
+        os.replace(out, DIAG_LIB)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return DIAG_LIB
+
+
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build_diag(verbose=True) if "--diag" in sys.argv else build(force=True, verbose=True))

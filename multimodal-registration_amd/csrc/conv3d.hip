@@ -86,6 +86,7 @@ constexpr int CV_BATCHA = 1 << 12;  // fp32x3 / x1: all staging loads of a slice
 constexpr int CV_PRIO_Y = 1 << 15;  // static s_setprio 1 for waves 4-7
 
 #ifdef MMR_DIAG
+int g_diag_stamps = 0;   // host switch of the stamped instantiations (conv and wgrad), set by mmr_debug_set_stamps
 // Diagnostic build only (CV_STAMP): where a tap's cycles go.  Per wave slot w (0..7) the sums over all workgroups of:
 // [0] tap top -> weight DMA issued, [1] -> last MFMA issued (fragment reads + MFMAs), [2] -> own DMA landed (vmcnt 0),
 // [3] -> barrier passed, [4] A restage (per slice), [5] number of taps.  s_memtime ticks.  Read the SHARES, never the
@@ -516,56 +517,13 @@ conv3d_k3_kernel(const ConvParams p)
                     for (int ni = 0; ni < 4; ++ni)
                         acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             __builtin_bit_cast(bf16x8, bh16[ni]), __builtin_bit_cast(bf16x8, ah16[mi]), acc16[mi][ni], 0, 0, 0);
-                    if constexpr (PRIO_SW) {
-                        if (mi == MT - 1) {   // half of this tap's MFMAs issued: the partner wave goes first from here on
-                            constexpr int NA1 = LO ? 2 : 1, NM1 = LO ? 12 : 4;
-                            __builtin_amdgcn_sched_group_barrier(0x100, 4 * NA1 + 2 * NA1, 0);
-                            if constexpr (MT == 4) {
-                                __builtin_amdgcn_sched_group_barrier(0x008, NM1, 0); __builtin_amdgcn_sched_group_barrier(0x100, NA1, 0);
-                                __builtin_amdgcn_sched_group_barrier(0x008, NM1, 0); __builtin_amdgcn_sched_group_barrier(0x100, NA1, 0);
-                            }
-                            __builtin_amdgcn_sched_group_barrier(0x008, NM1, 0); __builtin_amdgcn_sched_group_barrier(0x100, NA1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x008, NM1, 0); __builtin_amdgcn_sched_group_barrier(0x100, NA1, 0);
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (wave < 4) __builtin_amdgcn_s_setprio(0);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
                 }
                 constexpr int NA = LO ? 2 : 1, NM = LO ? 12 : 4;
 #define MMR_GRP3(rd) __builtin_amdgcn_sched_group_barrier(0x008, NM, 0); if (rd) __builtin_amdgcn_sched_group_barrier(0x100, NA, 0)
-                if constexpr (!PRIO_SW) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 4 * NA + 2 * NA, 0);
-                    if constexpr (MT == 4) { MMR_GRP3(1); MMR_GRP3(1); MMR_GRP3(1); MMR_GRP3(1); }
-                    MMR_GRP3(1); MMR_GRP3(1); MMR_GRP3(0); MMR_GRP3(0);
-                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 4 * NA + 2 * NA, 0);
+                if constexpr (MT == 4) { MMR_GRP3(1); MMR_GRP3(1); MMR_GRP3(1); MMR_GRP3(1); }
+                MMR_GRP3(1); MMR_GRP3(1); MMR_GRP3(0); MMR_GRP3(0);
 #undef MMR_GRP3
-            } else if constexpr (X3) {
-                // one 32-channel k-step per tap: chunks 0..3 = hi, 4..7 = lo
-                uint4 ah16[2 * MT], al16[2 * MT], bh16[2 * NT], bl16[2 * NT];
-#pragma unroll
-                for (int mi = 0; mi < 2 * MT; ++mi) {
-                    ah16[mi] = *reinterpret_cast<const uint4*>(bA + a16_off[mi] + ((q16 ^ sw16) << 4));
-                    if constexpr (LO) al16[mi] = *reinterpret_cast<const uint4*>(bA + a16_off[mi] + (((4 + q16) ^ sw16) << 4));
-                }
-#pragma unroll
-                for (int ni = 0; ni < 2 * NT; ++ni) {
-                    bh16[ni] = *reinterpret_cast<const uint4*>(bB + b16_off[ni]);
-                    if constexpr (LO) bl16[ni] = *reinterpret_cast<const uint4*>(bB + b16_off[ni] + 4 * BN * 16);
-                }
-#pragma unroll
-                for (int mi = 0; mi < 2 * MT; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2 * NT; ++ni) {
-                        if constexpr (LO) {
-                            acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8, bh16[ni]), __builtin_bit_cast(bf16x8, al16[mi]), acc16[mi][ni], 0, 0, 0);
-                            acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8, bl16[ni]), __builtin_bit_cast(bf16x8, ah16[mi]), acc16[mi][ni], 0, 0, 0);
-                        }
-                        acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, bh16[ni]), __builtin_bit_cast(bf16x8, ah16[mi]), acc16[mi][ni], 0, 0, 0);
-                    }
             } else if constexpr (MIDDMA) {
                 static_assert(MT == 4 && NT == 2, "pipelined schedule is written for the 128x64 wave tile");
                 uint4 fa[2][8], fb[2][4];
@@ -586,7 +544,7 @@ conv3d_k3_kernel(const ConvParams p)
                 };
                 // One code path, three scheduling regions cut by the two DMA issue points (the asm is a scheduling barrier):
                 // MFMA groups 0..3 | first issue point | groups 4..9 | second issue point | groups 10..15.  Reads
-                // keep the PIPE order (7 up front, then the per-group counts below), split where the regions are cut.
+                // go 7 up front, then per group of 4 MFMAs the counts below, split where the regions are cut.
 #pragma unroll
                 for (int i = 0; i < 12; ++i) rd(i);
 #pragma unroll
@@ -597,9 +555,6 @@ conv3d_k3_kernel(const ConvParams p)
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 if (more && wave < 4) issue_b(g + 1, cur ^ 1);
-                if constexpr (PRIO_SW && PRIO_EARLY) {
-                    if (wave < 4) __builtin_amdgcn_s_setprio(0);   // 16 of 64 MFMAs issued: the partner wave goes first from here on
-                }
 #pragma unroll
                 for (int i = 12; i < 21; ++i) rd(i);
 #pragma unroll
@@ -610,16 +565,7 @@ conv3d_k3_kernel(const ConvParams p)
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if constexpr (MIDOLD) {
-                    if (more && wave < 4) issue_b(g + 1, cur ^ 1, wave + 4);
-                } else {
-                    if (more && wave >= 4) issue_b(g + 1, cur ^ 1);
-                }
-                if constexpr (PRIO_SW && !PRIO_EARLY) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (wave < 4) __builtin_amdgcn_s_setprio(0);   // 40 of 64 MFMAs issued
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                if (more && wave < 4) issue_b(g + 1, cur ^ 1, wave + 4);
 #pragma unroll
                 for (int i = 21; i < 24; ++i) rd(i);
 #pragma unroll
@@ -630,41 +576,6 @@ conv3d_k3_kernel(const ConvParams p)
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            } else if constexpr (PIPE) {
-                // Explicit fragment pipeline over the whole tap (24 reads, 64 MFMAs in one scheduling region): the B
-                // fragments of the second k-step and A fragments two groups ahead are in flight while the matrix
-                // cores work, so that only the tap boundary (barrier) still exposes a full LDS round trip.
-                static_assert(MT == 4 && NT == 2, "pipelined schedule is written for the 128x64 wave tile");
-                uint4 fa[2][8], fb[2][4];
-                const char* pa0 = bA + a16_off[0] + ((q16 ^ sw16) << 4);
-                const char* pa1 = bA + a16_off[0] + (((4 + q16) ^ sw16) << 4);
-                const char* pb = bB + b16_off[0];
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) fb[0][ni] = *reinterpret_cast<const uint4*>(pb + ni * 256);
-#pragma unroll
-                for (int mi = 0; mi < 8; ++mi)
-                    fa[0][mi] = *reinterpret_cast<const uint4*>(pa0 + (((mi >> 2) * HY + ((mi >> 1) & 1) * 4 + 2 * (mi & 1)) * HZ) * ROWB);
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) fb[1][ni] = *reinterpret_cast<const uint4*>(pb + ni * 256 + 4 * BN * 16);
-#pragma unroll
-                for (int mi = 0; mi < 8; ++mi)
-                    fa[1][mi] = *reinterpret_cast<const uint4*>(pa1 + (((mi >> 2) * HY + ((mi >> 1) & 1) * 4 + 2 * (mi & 1)) * HZ) * ROWB);
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < 4; ++ni)
-                            acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8, fb[ks][ni]), __builtin_bit_cast(bf16x8, fa[ks][mi]), acc16[mi][ni], 0, 0, 0);
-                // order: 7 reads up front (B of k-step 0, A tiles 0-2), then per group of 4 MFMAs the reads listed
-#define MMR_GRP(nrd) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); if (nrd) __builtin_amdgcn_sched_group_barrier(0x100, nrd, 0)
-                // 7 reads up front (B of k-step 0, A tiles 0-2), then per group of 4 MFMAs the reads listed (A three
-                // groups ahead measured the same as two)
-                __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
-                MMR_GRP(1); MMR_GRP(1); MMR_GRP(1); MMR_GRP(2); MMR_GRP(2); MMR_GRP(2); MMR_GRP(2); MMR_GRP(1);
-                MMR_GRP(1); MMR_GRP(1); MMR_GRP(1); MMR_GRP(1); MMR_GRP(1); MMR_GRP(0); MMR_GRP(0); MMR_GRP(0);
-#undef MMR_GRP
             } else {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -739,25 +650,20 @@ conv3d_k3_kernel(const ConvParams p)
             }
         }
         }
-        }   // jt
-        if constexpr (SPLITDMA) {
-            if (more && wave < 4) {
-                issue_b(g + 1, cur ^ 1);
-                if constexpr (ALLOLD) issue_b(g + 1, cur ^ 1, wave + 4);
-            }
-        }
-        if constexpr (STAMP) { const unsigned long long t = stamp_now(); st_acc[1] += t - st_t; st_t = t; }
+        MMR_STAMP(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA of tap g+1 has landed (this wave's share)
-        if constexpr (STAMP) { const unsigned long long t = stamp_now(); st_acc[2] += t - st_t; st_t = t; }
+        MMR_STAMP(2);
         __syncthreads();                                  // ... everyone's has; buffer `cur` is free
-        if constexpr (STAMP) { const unsigned long long t = stamp_now(); st_acc[3] += t - st_t; st_t = t; st_acc[5] += ntap; }
+        MMR_STAMP(3);
+#ifdef MMR_DIAG
+        if constexpr (STAMP) st_acc[5] += 1;
+#endif
         cur ^= 1;
-        tap += ntap;
-        g = gn;
+        ++tap;
         if (tap == 27) {
             tap = 0;
             ++s;
-            if (s < nslices && g < g1) {  // every wave is past its last read of sA: install the next slice
+            if (s < nslices && more) {  // every wave is past its last read of sA: install the next slice
                 if constexpr (DMA_A) {
                     dma_stage_a(s);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -765,16 +671,18 @@ conv3d_k3_kernel(const ConvParams p)
                     MMR_STAGE_A_REGS(s);
                 }
                 __syncthreads();
-                if constexpr (STAMP) { const unsigned long long t = stamp_now(); st_acc[4] += t - st_t; }
+                MMR_STAMP(4);
             }
         }
     }
+#ifdef MMR_DIAG
     if constexpr (STAMP) {
         if (lane == 0) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) atomicAdd(&g_conv_stamp[wave][k], st_acc[k]);
         }
     }
+#endif
 
     // ---- split-K: raw fp32 partial tile, finalised by conv_ksplit_finalize_kernel ----
     if (p.kpart) {
@@ -1072,7 +980,7 @@ int launch_conv(const ConvParams& p, int ntiles_n, hipStream_t st, int64_t* nblk
 {
     constexpr int BN = WN * NT * 32;
     constexpr int TXT = WM * MT * 32 / (TY * TZ);
-    constexpr int LDS = (TXT + 2) * HY * HZ * ROWB + ((((VAR >> 14) & 1) != 0) ? 4 : 2) * BN * 128;
+    constexpr int LDS = (TXT + 2) * HY * HZ * ROWB + 2 * BN * 128;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     auto kern = conv3d_k3_kernel<DT, WM, WN, MT, NT, VAR>;
@@ -1109,73 +1017,35 @@ int dispatch_conv(const ConvParams& p, hipStream_t st, int64_t* nblk_out = nullp
 {
     const int BN = conv_bn(p.Cout);
     const int nt = (p.Cout + BN - 1) / BN;
-    // MMR_CONV_VARIANT=96: XCD-aware tile order for the 256-wide tile (A/B runs; measured 1 % slower).  The earlier
-    // 32x32x16 / fragment-double-buffer / A-prefetch / timing-only variants and the 4x8x8 narrow tiles were retired
-    // once measured; for exact fp32 the same instantiations run the 32x32x2 f32 path.
-    static int var = -1;
-    if (var < 0) {
-        const char* e = getenv("MMR_CONV_VARIANT");
-        var = e ? atoi(e) : 0;   // 0 = the per-tile defaults below
-    }
+    // Per-tile defaults, each measured against its alternatives on one box, back to back:
+    //  BN 256 bf16: explicit fragment pipeline + A tile by LDS-DMA + weight DMA from inside waves 0-3's MFMA stream
+    //         (ms per C2 pair: all waves at the top of the tap 44.2 | waves 4-7 at the top, 0-3 after their MFMAs 43.7 |
+    //         waves 0-3 issue everything after their MFMAs 43.2 | this 42.1-42.7);
+    //  BN 256 fp32 tensors: + batched branch-free A staging (-1.5 % on the 256 -> 256 layer of C2);
+    //  BN 128: 8x8x8-voxel tiles; bf16: compiler-scheduled fragments (neither the pipeline nor the DMA staging fit 256
+    //         VGPRs at this tile); others: pipeline + DMA / batched staging (-2.3 % on the C3 dgrad convs);
+    //  BN 64: + static priority 1 for waves 4-7 (-1 % on the 64 -> 64 layer at 160^3).
+    constexpr bool F32T = (DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1);
+    constexpr int V_FULL = CV_M16 | CV_PIPE | CV_DMA_A;
+#ifdef MMR_DIAG
+    const bool stamps = g_diag_stamps != 0;   // mmr_debug_set_stamps(1), tools/conv_stamps.py; not in the default build
+    if (stamps && BN == 256) return launch_conv<DT, 2, 4, 4, 2, V_FULL | (F32T ? CV_BATCHA : 0) | CV_STAMP>(p, nt, st, nblk_out);
+    if (stamps && BN == 64) return launch_conv<DT, 8, 1, 2, 2, V_FULL | CV_BATCHA | CV_PRIO_Y | CV_STAMP>(p, nt, st, nblk_out);
+#endif
     switch (BN) {
-        case 256:
-            if (var == 96) return launch_conv<DT, 2, 4, 4, 2, 96>(p, nt, st, nblk_out);
-            if (var == 32) return launch_conv<DT, 2, 4, 4, 2, 32>(p, nt, st, nblk_out);    // compiler-scheduled fragments
-            if (var == 160) return launch_conv<DT, 2, 4, 4, 2, 160>(p, nt, st, nblk_out);  // + explicit fragment pipeline
-            if (var == 416) return launch_conv<DT, 2, 4, 4, 2, 416>(p, nt, st, nblk_out);  // + A tile by LDS-DMA (round-1 default)
-            if (var == 928) return launch_conv<DT, 2, 4, 4, 2, 928>(p, nt, st, nblk_out);  // + staggered mid-tap weight DMA
-            if (var == 2464) return launch_conv<DT, 2, 4, 4, 2, 2464>(p, nt, st, nblk_out); // split weight-DMA placement
-            if (var == 10144) return launch_conv<DT, 2, 4, 4, 2, 10144>(p, nt, st, nblk_out); // default + cycle stamps (diagnostic)
-            if (var == 1440) return launch_conv<DT, 2, 4, 4, 2, 1440>(p, nt, st, nblk_out); // 416 + cycle stamps (diagnostic)
-            if (var == 3488) return launch_conv<DT, 2, 4, 4, 2, 3488>(p, nt, st, nblk_out); // 2464 + cycle stamps (diagnostic)
-            if (var == 10656) return launch_conv<DT, 2, 4, 4, 2, 10656>(p, nt, st, nblk_out); // 2464 + all weight DMA by waves 0-3
-            if (var == 41888) return launch_conv<DT, 2, 4, 4, 2, 41888>(p, nt, st, nblk_out); // default + static priority 1 for waves 4-7
-            if (var == 13216) return launch_conv<DT, 2, 4, 4, 2, 13216>(p, nt, st, nblk_out); // default + batched branch-free A staging (fp32x3 / x1)
-            if (var == 107424) return launch_conv<DT, 2, 4, 4, 2, 107424>(p, nt, st, nblk_out); // + waves 0-3: priority 2 until MFMA 40 of 64, then 0
-            if (var == 238496) return launch_conv<DT, 2, 4, 4, 2, 238496>(p, nt, st, nblk_out); // + waves 0-3: priority 2 until MFMA 16 of 64, then 0
-            if (var == 11680) return launch_conv<DT, 2, 4, 4, 2, 11680>(p, nt, st, nblk_out); // 10656 + cycle stamps (diagnostic)
-            // default: the weight DMA of the next tap is issued by waves 0-3 only, from two points inside their MFMA stream
-            // (after MFMA groups 4 and 10 of 16: own pieces, then the pieces of wave w + 4); waves 4-7 never issue.
-            // Measured against the alternatives on one box, back to back (ms per C2 pair): all waves at the top of the tap
-            // (round 1) 44.2 | waves 4-7 at the top, 0-3 after their MFMAs 43.7 | waves 0-3 issue everything after their
-            // MFMAs 43.2 | this 42.1-42.7; issue points (2,6) 43.8, (3,9) 43.2, (4,8) 42.4, (5,9) 42.5, (4,10) 42.1
-            if (DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1)   // fp32 tensors: + batched branch-free A staging (-1.5 %: 32.4 vs 32.9 ms
-                return launch_conv<DT, 2, 4, 4, 2, 13216>(p, nt, st, nblk_out);   // for the 256 -> 256 layer of C2, alternated)
-            return launch_conv<DT, 2, 4, 4, 2, 9120>(p, nt, st, nblk_out);
-        case 128:  // 8x8x8-voxel tiles for the narrow N
-            if (var == 32) return launch_conv<DT, 4, 2, 4, 2, 32>(p, nt, st, nblk_out);
-            if (DT == MMR_DT_BF16)  // neither the bf16 fragment pipeline nor the DMA staging fit 256 VGPRs at this tile
-                return launch_conv<DT, 4, 2, 4, 2, 32>(p, nt, st, nblk_out);
-            if (var == 2464) return launch_conv<DT, 4, 2, 4, 2, 2464>(p, nt, st, nblk_out);
-            if (var == 416) return launch_conv<DT, 4, 2, 4, 2, 416>(p, nt, st, nblk_out);   // round-1 default
-            if (var == 37280 || var == 41888) return launch_conv<DT, 4, 2, 4, 2, 37280>(p, nt, st, nblk_out);  // + static priority 1 for waves 4-7
-            // fp32x3 / x1 / exact fp32: 416 + batched branch-free A staging (-2.3 % on the C3 dgrad convs, same-box A/B)
-            return launch_conv<DT, 4, 2, 4, 2, 4512>(p, nt, st, nblk_out);
-        case 64:
-            if (var == 32) return launch_conv<DT, 8, 1, 2, 2, 32>(p, nt, st, nblk_out);
-            if (var == 2464) return launch_conv<DT, 8, 1, 2, 2, 2464>(p, nt, st, nblk_out);
-            if (var == 1440) return launch_conv<DT, 8, 1, 2, 2, 1440>(p, nt, st, nblk_out);
-            if (var == 3488) return launch_conv<DT, 8, 1, 2, 2, 3488>(p, nt, st, nblk_out);
-            if (var == 4512) return launch_conv<DT, 8, 1, 2, 2, 4512>(p, nt, st, nblk_out);  // 416 + batched branch-free A staging
-            if (var == 5536) return launch_conv<DT, 8, 1, 2, 2, 5536>(p, nt, st, nblk_out);  // 4512 + cycle stamps (diagnostic)
-            if (var == 416) return launch_conv<DT, 8, 1, 2, 2, 416>(p, nt, st, nblk_out);    // round-1 default
-            if (var == 4096 && DT != MMR_DT_BF16) return launch_conv<DT, 8, 1, 2, 2, 4096>(p, nt, st, nblk_out);  // 32x32x16 MFMA + batched A staging
-            if (var == 53664) return launch_conv<DT, 8, 1, 2, 2, 53664>(p, nt, st, nblk_out);   // 37280 + two taps per barrier
-            if (var == 37280 || var == 41888) return launch_conv<DT, 8, 1, 2, 2, 37280>(p, nt, st, nblk_out);   // 4512 + static priority 1 for waves 4-7
-            if (var == 102816) return launch_conv<DT, 8, 1, 2, 2, 102816>(p, nt, st, nblk_out); // + older half 2 -> 0 at mid-tap
-            if (var == 103840) return launch_conv<DT, 8, 1, 2, 2, 103840>(p, nt, st, nblk_out); // 102816 + cycle stamps (diagnostic)
-            if (var == 20896) return launch_conv<DT, 8, 1, 2, 2, 20896>(p, nt, st, nblk_out); // 4512 + two taps per barrier
-            if (var == 21920) return launch_conv<DT, 8, 1, 2, 2, 21920>(p, nt, st, nblk_out); // 20896 + cycle stamps (diagnostic)
-            // fp32x3 / x1: batched branch-free A staging (-5 % on the C3 training convs) + static priority 1 for waves 4-7
-            // (-1 %: 2.445 / 2.463 vs 2.475 / 2.487 ms on the 64 -> 64 layer at 160^3, alternated on one box; the same bit costs
-            // the 256-column bf16 tile +14 %, whose weight DMA is issued by waves 0-3 from inside their MFMA stream, and
-            // nothing on the 128-column tile); bf16 / exact fp32 stage A by DMA
-            return launch_conv<DT, 8, 1, 2, 2, 37280>(p, nt, st, nblk_out);
-        default: return launch_conv<DT, 8, 1, 2, 1, 256>(p, nt, st, nblk_out);
+        case 256: return launch_conv<DT, 2, 4, 4, 2, V_FULL | (F32T ? CV_BATCHA : 0)>(p, nt, st, nblk_out);
+        case 128:
+            if (DT == MMR_DT_BF16) return launch_conv<DT, 4, 2, 4, 2, CV_M16>(p, nt, st, nblk_out);
+            return launch_conv<DT, 4, 2, 4, 2, V_FULL | CV_BATCHA>(p, nt, st, nblk_out);
+        case 64: return launch_conv<DT, 8, 1, 2, 2, V_FULL | CV_BATCHA | CV_PRIO_Y>(p, nt, st, nblk_out);
+        default: return launch_conv<DT, 8, 1, 2, 1, CV_DMA_A>(p, nt, st, nblk_out);
     }
 }
 
-// Diagnostic: copy out and clear the cycle stamps of the MMR_CONV_VARIANT=1440 build (tools/conv_stamps.py); not in mmr.h.
+#ifdef MMR_DIAG
+// Diagnostic (-DMMR_DIAG builds only, not in mmr.h): switch the stamped instantiations on / off; copy out and clear
+// the cycle stamps (tools/conv_stamps.py).
+extern "C" int mmr_debug_set_stamps(int on) { g_diag_stamps = on; return MMR_OK; }
 extern "C" int mmr_debug_conv_stamps(unsigned long long* out64)
 {
     unsigned long long z[64] = {0};
@@ -1183,6 +1053,7 @@ extern "C" int mmr_debug_conv_stamps(unsigned long long* out64)
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamp), z, sizeof(z)) != hipSuccess) return MMR_EHIP;
     return MMR_OK;
 }
+#endif
 
 // ---- first layer: concat(moving, fixed) (2 ch) -> Cout, VALU ------------- //
 // Block = 4x4x16 voxel tile; thread = (cout, voxel-group); the thread's 54
@@ -1958,15 +1829,12 @@ extern "C" int mmr_conv3d_k3_pack(const float* w_keras, void* w_packed, int Cin,
     const int BN = conv_bn(Cout);
     const int nt = (Cout + BN - 1) / BN;
     const int grid = stream_grid(bytes / 16, 256);
-    // A/B runs of the 32x32x16 instantiation of the 64-column fp32x3 tile (MMR_CONV_VARIANT=4096) need unpermuted columns
-    static const bool plain64 = getenv("MMR_CONV_VARIANT") && atoi(getenv("MMR_CONV_VARIANT")) == 4096;
-    const int plain = (plain64 && BN == 64 && dtype != MMR_DT_BF16) ? 1 : 0;
     if (dtype == MMR_DT_BF16)
         hipLaunchKernelGGL(pack_kernel<MMR_DT_BF16>, dim3(grid), dim3(256), 0, as_stream(stream), w_keras,
                            (char*)w_packed, Cin, Cout, BN, nt, transpose_flip, 0);
     else if (dtype == MMR_DT_F32X3 || dtype == MMR_DT_F32X1)
         hipLaunchKernelGGL(pack_kernel<MMR_DT_F32X3>, dim3(grid), dim3(256), 0, as_stream(stream), w_keras,
-                           (char*)w_packed, Cin, Cout, BN, nt, transpose_flip, plain);
+                           (char*)w_packed, Cin, Cout, BN, nt, transpose_flip, 0);
     else
         hipLaunchKernelGGL(pack_kernel<MMR_DT_F32>, dim3(grid), dim3(256), 0, as_stream(stream), w_keras,
                            (char*)w_packed, Cin, Cout, BN, nt, transpose_flip, 0);
@@ -2153,11 +2021,6 @@ extern "C" int mmr_conv3d_k3_cout3_fwd(const void* in, const float* w_keras, con
     if (!in || !w_keras || !out || B < 1 || X < 1 || Y < 1 || Z < 1 || Cin < 32 || Cin % 32) return MMR_EINVAL;
     if (dtype != MMR_DT_BF16 && dtype != MMR_DT_F32X3) return MMR_EUNSUPPORTED;
     const int npl = dtype == MMR_DT_F32X3 ? 2 : 1;
-    static int use_march = -1;  // MMR_FLOW_HEAD=tile selects the older 2x4x8-tile kernel (A/B runs)
-    if (use_march < 0) {
-        const char* e = getenv("MMR_FLOW_HEAD");
-        use_march = (e && e[0] == 't') ? 0 : 1;
-    }
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipSuccess;
@@ -2179,12 +2042,11 @@ extern "C" int mmr_conv3d_k3_cout3_fwd(const void* in, const float* w_keras, con
     const int lds_w = npl * (Cin / 8) * 96 * 16;
     int pbufs = (lds_w + 2 * MH_ROWS * 81 * 4 <= 160 * 1024) ? 2 : 1;
     // narrow inputs: two workgroups per CU with a single P buffer each (one more barrier per plane, but a second workgroup
-    // to cover it: 0.52 -> 0.40 ms for fp32x3 at 160^3 x 64); MMR_FLOW_HEAD_1WG=1 restores one double-buffered workgroup
-    static const bool one_wg_env = getenv("MMR_FLOW_HEAD_1WG") != nullptr;
-    const bool two_wg = !one_wg_env && 2 * (lds_w + MH_ROWS * 81 * 4) <= 160 * 1024;
+    // to cover it: 0.52 -> 0.40 ms for fp32x3 at 160^3 x 64)
+    const bool two_wg = 2 * (lds_w + MH_ROWS * 81 * 4) <= 160 * 1024;
     if (two_wg) pbufs = 1;
     const int lds_m = lds_w + pbufs * MH_ROWS * 81 * 4;
-    if (use_march && lds_m <= 160 * 1024) {
+    if (lds_m <= 160 * 1024) {   // else: the 2x4x8-tile kernel below (weights + one P plane do not fit)
         const int nty = (Y + MH_TY - 1) / MH_TY, ntz = (Z + MH_TZ - 1) / MH_TZ;
         const int64_t tyz = (int64_t)B * nty * ntz;
         // x segments: the makespan of the persistent grid is (tiles of the busiest workgroup) x (planes per tile, + 2 of
@@ -2193,7 +2055,6 @@ extern "C" int mmr_conv3d_k3_cout3_fwd(const void* in, const float* w_keras, con
         const int gmax = two_wg ? 512 : 256;
         int nseg = 1;
         {
-            static const bool old_rule = getenv("MMR_FLOW_HEAD_SEG1024") != nullptr;   // A/B knob
             int64_t best = -1;
             const int smax = (X + 3) / 4;
             for (int c = 1; c <= smax && c <= 64; ++c) {
@@ -2203,37 +2064,31 @@ extern "C" int mmr_conv3d_k3_cout3_fwd(const void* in, const float* w_keras, con
                 const int64_t cost = per * (sl + 2);
                 if (best < 0 || cost < best) { best = cost; nseg = ns; }
             }
-            if (old_rule) {
-                nseg = (int)((1024 + tyz - 1) / tyz);
-                if (nseg > (X + 7) / 8) nseg = (X + 7) / 8;
-                if (nseg < 1) nseg = 1;
-            }
         }
         const int seglen = (X + nseg - 1) / nseg;
         nseg = (X + seglen - 1) / seglen;
         const int64_t nt = tyz * nseg;
         if (nt > 0x7fffffff) return MMR_EINVAL;
         const int grid = nt < gmax ? (int)nt : gmax;
-        const bool ns0 = getenv("MMR_FLOW_HEAD_NS0") != nullptr;   // A/B knob: the un-prefetched generic path
-        if (dtype == MMR_DT_F32X3 && Cin == 128 && !ns0)
+        if (dtype == MMR_DT_F32X3 && Cin == 128)
             hipLaunchKernelGGL((flow_head_march_kernel<true, 4>), dim3(grid), dim3(MH_THREADS), lds_m, as_stream(stream),
                                (const char*)in, w_keras, bias, out, B, X, Y, Z, Cin, nseg, seglen, nty, ntz, (int)nt, pbufs);
-        else if (dtype == MMR_DT_F32X3 && Cin == 64 && !ns0)
+        else if (dtype == MMR_DT_F32X3 && Cin == 64)
             hipLaunchKernelGGL((flow_head_march_kernel<true, 2>), dim3(grid), dim3(MH_THREADS), lds_m, as_stream(stream),
                                (const char*)in, w_keras, bias, out, B, X, Y, Z, Cin, nseg, seglen, nty, ntz, (int)nt, pbufs);
-        else if (dtype == MMR_DT_F32X3 && Cin == 32 && !ns0)
+        else if (dtype == MMR_DT_F32X3 && Cin == 32)
             hipLaunchKernelGGL((flow_head_march_kernel<true, 1>), dim3(grid), dim3(MH_THREADS), lds_m, as_stream(stream),
                                (const char*)in, w_keras, bias, out, B, X, Y, Z, Cin, nseg, seglen, nty, ntz, (int)nt, pbufs);
         else if (dtype == MMR_DT_F32X3)
             hipLaunchKernelGGL(flow_head_march_kernel<true>, dim3(grid), dim3(MH_THREADS), lds_m, as_stream(stream),
                                (const char*)in, w_keras, bias, out, B, X, Y, Z, Cin, nseg, seglen, nty, ntz, (int)nt, pbufs);
-        else if (Cin == 256 && !getenv("MMR_FLOW_HEAD_NS0"))
+        else if (Cin == 256)
             hipLaunchKernelGGL((flow_head_march_kernel<false, 8>), dim3(grid), dim3(MH_THREADS), lds_m, as_stream(stream),
                                (const char*)in, w_keras, bias, out, B, X, Y, Z, Cin, nseg, seglen, nty, ntz, (int)nt, pbufs);
-        else if (Cin == 128 && !getenv("MMR_FLOW_HEAD_NS0"))
+        else if (Cin == 128)
             hipLaunchKernelGGL((flow_head_march_kernel<false, 4>), dim3(grid), dim3(MH_THREADS), lds_m, as_stream(stream),
                                (const char*)in, w_keras, bias, out, B, X, Y, Z, Cin, nseg, seglen, nty, ntz, (int)nt, pbufs);
-        else if (Cin == 64 && !getenv("MMR_FLOW_HEAD_NS0"))
+        else if (Cin == 64)
             hipLaunchKernelGGL((flow_head_march_kernel<false, 2>), dim3(grid), dim3(MH_THREADS), lds_m, as_stream(stream),
                                (const char*)in, w_keras, bias, out, B, X, Y, Z, Cin, nseg, seglen, nty, ntz, (int)nt, pbufs);
         else

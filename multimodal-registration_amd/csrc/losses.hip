@@ -1201,8 +1201,7 @@ extern "C" int mmr_ncc_fwd_f32(const float* I, const float* J, float* out, void*
     if (win != 9) return MMR_EUNSUPPORTED;
     if ((int64_t)Y * Z > 0x7fffffff) return MMR_EINVAL;
     int nzt, nyt, nxs, xseg;
-    static const bool force_v1 = getenv("MMR_NCC_1Z") != nullptr;   // A/B knob: the one-z-per-lane kernel
-    if (ncc_fused4_ok((int64_t)X * Y * Z, Z) && !force_v1) {
+    if (ncc_fused4_ok((int64_t)X * Y * Z, Z)) {
         ncc_fused4_geom(B, X, Y, nyt, nxs, xseg);
         const int64_t nblk4 = (int64_t)nyt * nxs;            // per batch item
         if ((int64_t)B * nblk4 > 0x7fffffff) return MMR_EINVAL;
@@ -1249,8 +1248,7 @@ inline void bend_geom(int B, int X, int Y, int Z, int& nzs, int& nyg, int& nxs, 
 {
     nzs = (Z - 2 + BF_ZOUT - 1) / BF_ZOUT;
     nyg = (Y - 2 + R - 1) / R;
-    static const int xseg_env = [] { const char* e = getenv("MMR_BEND_XSEG"); return e ? atoi(e) : 0; }();   // A/B knob
-    xseg = xseg_env >= 4 ? xseg_env : 16;
+    xseg = 16;   // measured at 256^3: 8 planes 72 us, 16: 57, 32: 73, 64: 88
     nxs = (X - 2 + xseg - 1) / xseg;
     nwaves = (int64_t)B * nzs * nyg * nxs;
 }
@@ -1271,21 +1269,13 @@ extern "C" int mmr_bending_fwd_f32(const float* flow, float* out, void* ws, int 
     if ((int64_t)Y * Z * 3 > 0x7fffffff) return MMR_EINVAL;
     int nzs, nyg, nxs, xseg;
     int64_t nwaves;
-    static const int rows = [] { const char* e = getenv("MMR_BEND_ROWS"); const int r = e ? atoi(e) : 0; return (r == 6 || r == 5) ? r : BF_ROWS; }();  // A/B knob
-    bend_geom(1, X, Y, Z, nzs, nyg, nxs, xseg, nwaves, rows);  // per batch item, so that a block never straddles items
+    bend_geom(1, X, Y, Z, nzs, nyg, nxs, xseg, nwaves, BF_ROWS);  // per batch item, so that a block never straddles items
     const int64_t nblk = (nwaves + 3) / 4;
     if (nblk * B > 0x7fffffff) return MMR_EINVAL;
     const int64_t n = (int64_t)(X - 2) * (Y - 2) * (Z - 2) * 3;
     for (int b = 0; b < B; ++b) {
         double* part = (double*)ws + (int64_t)b * nblk;
-        if (rows == 5)
-            hipLaunchKernelGGL(bending_fused_kernel<5>, dim3((unsigned)nblk), dim3(RED_BLOCK), 0, as_stream(stream),
-                               flow + (size_t)b * X * Y * Z * 3, part, X, Y, Z, xseg, nxs, nyg, nzs, nwaves);
-        else if (rows == 6)
-            hipLaunchKernelGGL(bending_fused_kernel<6>, dim3((unsigned)nblk), dim3(RED_BLOCK), 0, as_stream(stream),
-                               flow + (size_t)b * X * Y * Z * 3, part, X, Y, Z, xseg, nxs, nyg, nzs, nwaves);
-        else
-            hipLaunchKernelGGL(bending_fused_kernel<BF_ROWS>, dim3((unsigned)nblk), dim3(RED_BLOCK), 0, as_stream(stream),
+        hipLaunchKernelGGL(bending_fused_kernel<BF_ROWS>, dim3((unsigned)nblk), dim3(RED_BLOCK), 0, as_stream(stream),
                                flow + (size_t)b * X * Y * Z * 3, part, X, Y, Z, xseg, nxs, nyg, nzs, nwaves);
         int rc = check_launch();
         if (rc) return rc;

@@ -984,7 +984,10 @@ __device__ __forceinline__ void split_bf16(float f, unsigned short& hi, unsigned
 constexpr int WX_A_BYTES = W_HROWS * 128;  // 76800
 constexpr int WX_B_BYTES = 256 * 256;      // 65536
 
-// Diagnostic (MMR_WGRAD_STAMP=1): per wave slot the s_memtime sums over all workgroups of [0] wait at the top-of-tile
+#ifdef MMR_DIAG
+extern int g_diag_stamps;   // conv3d.hip
+#endif
+// Diagnostic (-DMMR_DIAG build + mmr_debug_set_stamps(1)): per wave slot the s_memtime sums over all workgroups of [0] wait at the top-of-tile
 // barrier, [1] hi/lo split + LDS stores + barrier, [2] issue of the next tile's loads, [3] the 16 k-blocks, [4] tiles.
 __device__ unsigned long long g_wgrad_stamp[8][8];
 __device__ __forceinline__ unsigned long long wstamp_now()
@@ -1004,7 +1007,7 @@ __device__ __forceinline__ unsigned long long wstamp_now()
 // into the same kernel behind a wave-uniform branch, hipcc put `s_waitcnt vmcnt(0)` in front of every dZ load at the
 // join of the two paths: 8 more dependent round trips per tile.)
 template <int N> struct IC { static constexpr int value = N; };
-template <int COT, bool LO, bool STAMP = false, int PF = 3, bool FULLCO = false, bool BUF = false, bool SPREAD = false>
+template <int COT, bool LO, bool STAMP = false, int PF = 3, bool FULLCO = false, bool BUF = false>
 __global__ void __launch_bounds__(W_THREADS, 2)
 wgrad_x3_kernel(const WgradParams p)
 {
@@ -1259,13 +1262,8 @@ wgrad_x3_kernel(const WgradParams p)
         __syncthreads();
         if constexpr (STAMP) { const unsigned long long t = wstamp_now(); st_acc[1] += t - st_t; st_t = t; }
         const int nxt = tile + gridDim.x;
-        // SPREAD (opt-in, MMR_WGRAD_SPREAD=1; measured, not faster): the next tile's loads issued in four groups between the
-        // quarters of the k-loop instead of in one burst in front of it.  The burst takes 2.8 - 3.9 k cycles per tile with the
-        // matrix cores idle (141 KB per workgroup through a 64 B/clk address path; tools/wgrad_stamps.py, "issue next loads").
-        // Spread out, the issue phase drops to 0.35 - 0.67 k but the k-loop grows by 2.6 - 3.1 k: its 32 transposing LDS reads
-        // per k-block and the returning global loads compete for the same VGPR write path, and the four loop entries each
-        // expose an LDS round trip.  Net: 2.74 ms either way for the 64 -> 64 layer at 160^3 against 2.58 ms for the burst
-        // in front of one 16-iteration loop.
+        // the next tile's loads go out in one burst in front of the k-loop (spread over its quarters they compete with the
+        // transposing LDS reads for the VGPR write path: same 2.6 ms per launch)
         int nb = 0, nx0 = 0, ny0 = 0, nz0 = 0;
         if (nxt < p.ntiles) tile_origin(nxt, nb, nx0, ny0, nz0);
         auto issue_group = [&](auto gc) {
@@ -1284,9 +1282,7 @@ wgrad_x3_kernel(const WgradParams p)
                 }
             }
         };
-        if constexpr (!SPREAD) {
-            issue_group(IC<0>{}); issue_group(IC<1>{}); issue_group(IC<2>{}); issue_group(IC<3>{});
-        }
+        issue_group(IC<0>{}); issue_group(IC<1>{}); issue_group(IC<2>{}); issue_group(IC<3>{});
         if constexpr (STAMP) { const unsigned long long t = wstamp_now(); st_acc[2] += t - st_t; st_t = t; }
         auto k_range = [&](int k0, int k1) {
 #pragma unroll 1
@@ -1316,14 +1312,7 @@ wgrad_x3_kernel(const WgradParams p)
             }
         }
         };
-        if constexpr (SPREAD) {
-            issue_group(IC<0>{}); k_range(0, 4);
-            issue_group(IC<1>{}); k_range(4, 8);
-            issue_group(IC<2>{}); k_range(8, 12);
-            issue_group(IC<3>{}); k_range(12, 16);
-        } else {
-            k_range(0, 16);
-        }
+        k_range(0, 16);
         if constexpr (STAMP) { const unsigned long long t = wstamp_now(); st_acc[3] += t - st_t; st_acc[4] += 1; }
     }
     if constexpr (STAMP) {
@@ -2344,14 +2333,13 @@ extern "C" int mmr_resize_trilinear_bwd_f32(const float* dout, float* din, int B
     return check_launch();
 }
 
-// da, db zeroed by the caller.  MMR_COMPOSE_BWD_FLAT=1: the one-atomic-per-corner kernel (A/B runs).
+// da, db zeroed by the caller.
 static int launch_compose_bwd(const float* a, const float* b, const float* dout, float* da, float* db, int B, int X, int Y,
                               int Z, float s, hipStream_t st)
 {
-    static const bool flat = getenv("MMR_COMPOSE_BWD_FLAT") != nullptr;
     const int ntx = (X + CB_TX - 1) / CB_TX, nty = (Y + CB_TY - 1) / CB_TY, ntz = (Z + CB_TZ - 1) / CB_TZ;
     const int64_t nt = (int64_t)B * ntx * nty * ntz;
-    if (flat || nt > 0x7fffffff)
+    if (nt > 0x7fffffff)   // the one-atomic-per-corner kernel only when the tile count overflows the grid
         hipLaunchKernelGGL(compose_bwd_kernel, dim3(stream_grid((int64_t)B * X * Y * Z, TB)), dim3(TB), 0, st, a, b, dout,
                            da, db, B, X, Y, Z, s);
     else
@@ -2565,7 +2553,7 @@ static int wgrad_impl(const float* in0, int C0, int up0, const float* in1, int C
         return MMR_EINVAL;
     if (up0 && ((X | Y | Z) & 1)) return MMR_EINVAL;
     if (Cout == 3 && C1 == 0 && !up0 && C0 % 64 == 0) {  // flow head: taps folded into the GEMM N axis (81 of 96 used)
-        if (x3 == 1 && !getenv("MMR_THIN_WGRAD_F32"))
+        if (x3 == 1)
             return launch_thin_wgrad_x3(in0, C0, dz, nullptr, 3, -1, dw, ws, B, X, Y, Z, 0, accumulate, stream);
         const int ntx = (X + W_TX - 1) / W_TX, nty = (Y + W_TY - 1) / W_TY, ntz = (Z + W_TZ - 1) / W_TZ;
         const int ntiles = B * ntx * nty * ntz;
@@ -2602,7 +2590,7 @@ static int wgrad_impl(const float* in0, int C0, int up0, const float* in1, int C
         p.bytes_src[1] = fits ? (unsigned)b1 : 0;
         p.bytes_dz = fits ? (unsigned)bz : 0;
     }
-    const bool usebuf = p.bytes_dz != 0 && !getenv("MMR_WGRAD_NOBUF");
+    const bool usebuf = p.bytes_dz != 0;
     constexpr int LDS = W_A_BYTES + W_B_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
@@ -2622,23 +2610,14 @@ static int wgrad_impl(const float* in0, int C0, int up0, const float* in1, int C
                                 reinterpret_cast<const void*>(wgrad_x3_kernel<1, true>),
                                 reinterpret_cast<const void*>(wgrad_x3_kernel<2, false>),
                                 reinterpret_cast<const void*>(wgrad_x3_kernel<1, false>),
-                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, true, 3>),
-                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, true, 2>),
-                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, true, 1>),
-                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, true, 0>),
-                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, false, 2>),
-                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, false, 1>),
-                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, false, 0>),
                                 reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, false, 3, true>),
-                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, false, 2, true>),
-                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, false, 0, true>),
-                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, true, 3, true>),
                                 reinterpret_cast<const void*>(wgrad_x3_kernel<2, false, false, 3, true>),
                                 reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, false, 3, true, true>),
-                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, true, 3, true, true>),
                                 reinterpret_cast<const void*>(wgrad_x3_kernel<2, false, false, 3, true, true>),
-                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, false, 3, true, true, true>),
-                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, true, 3, true, true, true>)};
+#ifdef MMR_DIAG
+                                reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, true, 3, true, true>),
+#endif
+            };
             for (size_t i = 0; i < sizeof(ks) / sizeof(ks[0]); ++i) {
                 hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDSX);
                 if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
@@ -2647,26 +2626,17 @@ static int wgrad_impl(const float* in0, int C0, int up0, const float* in1, int C
         }
         const dim3 g3(gx, nslices, ncob), b3(W_THREADS);
         if (x3 == 1) {
-            static const bool stamp = getenv("MMR_WGRAD_STAMP") != nullptr;   // diagnostic build, tools/wgrad_stamps.py
-            static const int pf = getenv("MMR_WGRAD_PF") ? atoi(getenv("MMR_WGRAD_PF")) : 3;   // A/B knob
+            // Cout % 64 == 0: one branch-free dZ load path; usebuf: buffer loads with hardware bounds (tensors < 4 GB).
+            // Both operand tiles of the next voxel tile are prefetched under the k-loop (PF = 3)
             const bool fullco = (Cout % 64) == 0;
-            static const bool spread = getenv("MMR_WGRAD_SPREAD") != nullptr;   // A/B knob: next tile's loads spread over the k-loop
+#ifdef MMR_DIAG
+            const bool stamp = g_diag_stamps != 0;   // mmr_debug_set_stamps(1), tools/wgrad_stamps.py
+            if (fullco && usebuf && stamp) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, true, 3, true, true>), g3, b3, LDSX, as_stream(stream), p);
+            else
+#endif
             if (Cout <= 32) hipLaunchKernelGGL((wgrad_x3_kernel<1, true>), g3, b3, LDSX, as_stream(stream), p);
-            else if (fullco && stamp && usebuf && spread) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, true, 3, true, true, true>), g3, b3, LDSX, as_stream(stream), p);
-            else if (fullco && stamp && usebuf) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, true, 3, true, true>), g3, b3, LDSX, as_stream(stream), p);
-            else if (fullco && stamp) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, true, 3, true>), g3, b3, LDSX, as_stream(stream), p);
-            else if (fullco && pf == 2) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 2, true>), g3, b3, LDSX, as_stream(stream), p);
-            else if (fullco && pf == 0) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 0, true>), g3, b3, LDSX, as_stream(stream), p);
-            else if (fullco && usebuf && spread && pf == 3) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 3, true, true, true>), g3, b3, LDSX, as_stream(stream), p);
             else if (fullco && usebuf) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 3, true, true>), g3, b3, LDSX, as_stream(stream), p);
             else if (fullco) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 3, true>), g3, b3, LDSX, as_stream(stream), p);
-            else if (stamp && pf == 3) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, true, 3>), g3, b3, LDSX, as_stream(stream), p);
-            else if (stamp && pf == 2) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, true, 2>), g3, b3, LDSX, as_stream(stream), p);
-            else if (stamp && pf == 1) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, true, 1>), g3, b3, LDSX, as_stream(stream), p);
-            else if (stamp) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, true, 0>), g3, b3, LDSX, as_stream(stream), p);
-            else if (pf == 2) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 2>), g3, b3, LDSX, as_stream(stream), p);
-            else if (pf == 1) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 1>), g3, b3, LDSX, as_stream(stream), p);
-            else if (pf == 0) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 0>), g3, b3, LDSX, as_stream(stream), p);
             else hipLaunchKernelGGL((wgrad_x3_kernel<2, true>), g3, b3, LDSX, as_stream(stream), p);
         } else {
             if (Cout <= 32) hipLaunchKernelGGL((wgrad_x3_kernel<1, false>), g3, b3, LDSX, as_stream(stream), p);
@@ -2685,6 +2655,7 @@ static int wgrad_impl(const float* in0, int C0, int up0, const float* in1, int C
     return check_launch();
 }
 
+#ifdef MMR_DIAG
 // Diagnostic: copy out and clear the wgrad cycle stamps (tools/wgrad_stamps.py); not part of mmr.h.
 extern "C" int mmr_debug_wgrad_stamps(unsigned long long* out64)
 {
@@ -2693,6 +2664,7 @@ extern "C" int mmr_debug_wgrad_stamps(unsigned long long* out64)
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_wgrad_stamp), z, sizeof(z)) != hipSuccess) return MMR_EHIP;
     return MMR_OK;
 }
+#endif
 
 extern "C" int mmr_conv3d_k3_wgrad_f32(const float* in0, int C0, int up0, const float* in1, int C1, const float* dz,
                                        float* dw, void* ws, int B, int X, int Y, int Z, int Cout, int accumulate,
@@ -2728,7 +2700,7 @@ static int cin2_wgrad_impl(const float* src, const float* trg, const float* dz, 
                            int Z, int Cout, int accumulate, int x3, void* stream)
 {
     if (!src || !trg || !dz || !dw || !ws || B < 1 || X < 1 || Y < 1 || Z < 1) return MMR_EINVAL;
-    if (Cout % 64 == 0 && x3 && !getenv("MMR_THIN_WGRAD_F32"))
+    if (Cout % 64 == 0 && x3)
         return launch_thin_wgrad_x3(dz, Cout, src, trg, 2, +1, dw, ws, B, X, Y, Z, 1, accumulate, stream);
     if (Cout % 64 == 0) {  // fp32 matrix cores: T[co][tap*2 + ci] = sum_v dZ[v][co] * img_ci[v + off(tap)]
         const int ntx = (X + W_TX - 1) / W_TX, nty = (Y + W_TY - 1) / W_TY, ntz = (Z + W_TZ - 1) / W_TZ;

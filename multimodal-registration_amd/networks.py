@@ -92,6 +92,31 @@ def _write_keras_weights(g, layer_names, weights):
         lg.create_dataset(wn[1], np.asarray(weights[2 * i + 1], dtype=np.float32))
 
 
+class InputModel:
+    """The generator pair in front of the network: what ``tf.keras.Model(inputs=gen_model_1.inputs + gen_model_2.inputs,
+    outputs=(ima_1, ima_2))`` is in train_synthmorph.py:290-295.  Calling it on two label-map batches runs both
+    ``labels_to_image`` generators on the device and returns the two grayscale images; the label maps they were rendered
+    from (after the generators' own nearest-neighbour warp) stay in ``.maps`` for the Dice term (``map_1`` / ``map_2``
+    of :291-292), the one-hot tensors are only built when asked for."""
+
+    def __init__(self, gen_1, gen_2):
+        for g in (gen_1, gen_2):
+            if not (hasattr(g, "generate") and hasattr(g, "in_shape") and hasattr(g, "L")):
+                raise TypeError("InputModel needs two synth.labels_to_image generators")
+        if gen_1.in_shape != gen_2.in_shape or gen_1.L != gen_2.L:
+            raise ValueError("the two generators must share in_shape and the label list")
+        self.gen_1, self.gen_2 = gen_1, gen_2
+        self.inputs = list(gen_1.inputs) + list(gen_2.inputs)
+        self.outputs = (gen_1.outputs[0], gen_2.outputs[0])
+        self.maps = None
+
+    def __call__(self, labels_1, labels_2, draws_1=None, draws_2=None, want_onehot=False):
+        g1 = self.gen_1.generate(labels_1, draws=draws_1, want_onehot=want_onehot)
+        g2 = self.gen_2.generate(labels_2, draws=draws_2, want_onehot=want_onehot)
+        self.maps = (g1["onehot"] if want_onehot else g1["labels"], g2["onehot"] if want_onehot else g2["labels"])
+        return g1["image"], g2["image"]
+
+
 class VxmDense:
     """VoxelMorph dense registration network, forward on gfx950 HIP kernels.
 
@@ -123,6 +148,13 @@ class VxmDense:
         self.enc, self.dec = enc, dec
         self.int_steps, self.int_resolution, self.svf_resolution = int(int_steps), int_resolution, svf_resolution
         self.fill_value = fill_value
+        # input_model (train_synthmorph.py:294-296): its two outputs are source / target and its inputs (the label maps)
+        # become the model's inputs.  Anything that is not the generator pair is refused rather than ignored.
+        if input_model is not None and not isinstance(input_model, InputModel):
+            raise TypeError("input_model must be a networks.InputModel(gen_1, gen_2) (the reference's generator pair, "
+                            "train_synthmorph.py:288-296) or None")
+        if input_model is not None and tuple(input_model.gen_1.in_shape) != tuple(int(s) for s in inshape):
+            raise ValueError(f"input_model generates {tuple(input_model.gen_1.in_shape)} volumes, inshape is {tuple(inshape)}")
         self.input_model = input_model
         self.name = name
         self.device = torch.device(device)
@@ -369,7 +401,10 @@ class VxmDense:
         return self._conv(li, last, in1=skip, up0=skip is not None, leaky=False, out_f32=True)
 
     def forward(self, source, target):
-        """Device tensors [B,X,Y,Z,1] f32 -> dict(y_source, preint_flow, pos_flow, flow)."""
+        """Device tensors [B,X,Y,Z,1] f32 -> dict(y_source, preint_flow, pos_flow, flow).  With an ``input_model`` the two
+        arguments are the LABEL MAPS (uint8 [B,X,Y,Z,1]) and the generators' images become source / target."""
+        if self.input_model is not None:
+            source, target = self.input_model(source, target)
         if tuple(source.shape[1:4]) != self.inshape:
             raise ValueError(f"input shape {tuple(source.shape[1:4])} != model inshape {self.inshape}")
         flow = self.unet(source, target)
@@ -399,8 +434,11 @@ class VxmDense:
         out_m, out_f = [], []
         n = np.asarray(src).shape[0] if not isinstance(src, torch.Tensor) else src.shape[0]
         for b in range(n):  # Keras predicts in batches; one pair at a time bounds activation memory
-            s = h2d_volume(src[b:b + 1], self.device, tag=0)
-            t = h2d_volume(trg[b:b + 1], self.device, tag=1)
+            if self.input_model is not None:   # label maps in: the generators take NumPy uint8 or device tensors as they are
+                s, t = src[b:b + 1], trg[b:b + 1]
+            else:
+                s = h2d_volume(src[b:b + 1], self.device, tag=0)
+                t = h2d_volume(trg[b:b + 1], self.device, tag=1)
             o = self.forward(s, t)
             out_m.append(d2h_volume(o["y_source"], tag=0))
             out_f.append(d2h_volume(o["preint_flow"], tag=1))

@@ -374,7 +374,7 @@ def ncc_loss(I, J, win=9, eps=1e-5, form=None):
     ws = _ws(lib.mmr_ncc_ws_bytes(B, X, Y, Z), I.device)
     out = torch.empty(B, dtype=torch.float32, device=I.device)
     # the kernel mmr_ncc_fwd_f32 picks (csrc/losses.hip: ncc_fused4_ok): four z per lane for whole rows, else one
-    four = Z % 4 == 0 and Z <= 256 and X * Y * Z * 4 < 0xF0000000 and not os.environ.get("MMR_NCC_1Z")
+    four = Z % 4 == 0 and Z <= 256 and X * Y * Z * 4 < 0xF0000000
     with _Timed("hbm:ncc_fused4_kernel" if four else "hbm:ncc_fused_kernel", (X, Y, Z), 2.0 * 4 * B * X * Y * Z):   # I, J read once
         rc = lib.mmr_ncc_fwd_f32(I.data_ptr(), J.data_ptr(), out.data_ptr(), ws.data_ptr(), B, X, Y, Z, int(win), float(eps),
                                  semantics.code("ncc_form", form), _stream())

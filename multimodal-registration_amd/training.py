@@ -41,13 +41,22 @@ class Adam:
 class SynthMorphTrainer:
     """model: fp32 VxmDense; gen_1/gen_2: synth.LabelsToImage (sharing the label list)."""
 
-    def __init__(self, model, gen_1, gen_2, reg_param=1.0, optimizer=None, zero_pad_dice=False,
+    def __init__(self, model, gen_1=None, gen_2=None, reg_param=1.0, optimizer=None, zero_pad_dice=False,
                  process_group=None, world_size=1, rank=0, backward_precision=None):
-        """backward_precision: None = same arithmetic as the forward (fp32 / fp32x3); 'bf16' = dgrad and wgrad
+        """gen_1 / gen_2 default to the generator pair of ``model.input_model`` (a model built the reference's way,
+        ``VxmDense(..., input_model=InputModel(gen_1, gen_2))``, train_synthmorph.py:294-296).
+        backward_precision: None = same arithmetic as the forward (fp32 / fp32x3); 'bf16' = dgrad and wgrad
         products on the bf16 hi halves only (one MFMA instead of three, fp32 accumulate) -- an opt-in
         mixed-precision backward; the forward (and therefore every output and loss) keeps fp32-grade accuracy."""
         if model.dtype != torch.float32:
             raise NotImplementedError("training runs the fp32 path (the reference trains in fp32)")
+        im = getattr(model, "input_model", None)
+        if gen_1 is None and gen_2 is None and im is not None:
+            gen_1, gen_2 = im.gen_1, im.gen_2
+        if gen_1 is None or gen_2 is None:
+            raise ValueError("SynthMorphTrainer needs the two labels_to_image generators (arguments or model.input_model)")
+        if im is not None and (im.gen_1 is not gen_1 or im.gen_2 is not gen_2):
+            raise ValueError("the generators passed differ from model.input_model's")
         self.model, self.gen_1, self.gen_2 = model, gen_1, gen_2
         self.L = gen_1.L
         self.reg_param = float(reg_param)

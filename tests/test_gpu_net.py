@@ -161,3 +161,40 @@ def test_vxmdense_256_features_80x80x96_matches_torch_oracle(dev):
     print("80x80x96 / 256-feature whole-net parity [fp32x3]: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
     for name, err in errs.items():
         assert err < 1e-4, f"{name}: rel-to-scale err {err:.3e} >= 1e-4"
+
+
+def test_input_model_wires_the_generator_pair(dev):
+    """train_synthmorph.py:288-296: ``VxmDense(..., input_model=Model(labels -> (ima_1, ima_2)))`` -- the model's inputs are
+    the two label maps, its source / target the generators' images.  Same seeds, same draws: predicting through the
+    input_model equals rendering the pair by hand and predicting with a plain model; the trainer picks the generators up
+    from the model."""
+    import mmr
+    from mmr import synth, training
+    shape, L = (16, 16, 32), 4
+    rng = np.random.default_rng(0)
+    lab = np.repeat(np.repeat(np.repeat(rng.integers(0, L, (1, 4, 4, 8)), 4, 1), 4, 2), 4, 3).astype(np.uint8)[..., None]
+    kw = dict(in_shape=shape, in_label_list=np.arange(L), out_label_list=np.arange(L), warp_std=1, warp_res=8, blur_std=1,
+              bias_std=0.3, bias_res=8, gamma_std=0.25)
+    feats = ([32, 32], [32, 32, 32])
+    mk = lambda: (synth.labels_to_image(**kw, id=0, seed=1), synth.labels_to_image(**kw, id=1, seed=2))
+    g1, g2 = mk()
+    im = mmr.networks.InputModel(g1, g2)
+    assert im.inputs == ["labels_input_0", "labels_input_1"]
+    m = mmr.networks.VxmDense(shape, nb_unet_features=feats, int_steps=3, int_resolution=2, svf_resolution=2,
+                              input_model=im, compute_dtype="fp32", seed=3)
+    w = m.get_weights()
+    w[-2] = (rng.standard_normal(w[-2].shape) * 3e-2).astype(np.float32)
+    m.set_weights(w)
+    moved, warp = m.predict([lab, lab])
+    h1, h2 = mk()
+    a, b = h1.generate(lab)["image"], h2.generate(lab)["image"]
+    plain = mmr.networks.VxmDense(shape, nb_unet_features=feats, int_steps=3, int_resolution=2, svf_resolution=2,
+                                  compute_dtype="fp32", seed=3)
+    plain.set_weights(w)
+    moved2, warp2 = plain.predict([a.cpu().numpy(), b.cpu().numpy()])
+    assert np.array_equal(moved, moved2) and np.array_equal(warp, warp2) and np.abs(warp).max() > 0
+    assert im.maps[0].dtype == torch.uint8 and tuple(im.maps[0].shape) == (1,) + shape + (1,)
+    tr = training.SynthMorphTrainer(m, reg_param=0.5, optimizer=training.Adam(1e-3))
+    assert tr.gen_1 is g1 and tr.gen_2 is g2 and np.isfinite(float(tr.train_step(lab, lab)["loss"]))
+    with pytest.raises(TypeError):
+        mmr.networks.VxmDense(shape, nb_unet_features=feats, input_model=object())

@@ -1,11 +1,15 @@
 #!/usr/bin/env python
-"""Where the cycles of a tap of the BN=256 bf16 conv go (diagnostic build, MMR_CONV_VARIANT=1440): runs the C2
+"""Where the cycles of a tap of the BN=256 bf16 conv go (diagnostic -DMMR_DIAG build, python -m ... build.py --diag): runs the C2
 dec_final_1 layer (256 -> 256, 160x160x192) and prints the per-wave shares of the in-kernel stamps."""
 import ctypes
 import os
 import sys
 
-os.environ.setdefault("MMR_CONV_VARIANT", "1440")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import importlib.util
+_spec = importlib.util.spec_from_file_location("mmr_build", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multimodal-registration_amd", "build.py"))
+_b = importlib.util.module_from_spec(_spec); _spec.loader.exec_module(_b)
+os.environ["MMR_LIB"] = _b.DIAG_LIB if os.path.exists(_b.DIAG_LIB) else _b.build_diag()   # -DMMR_DIAG twin of the library
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
@@ -23,7 +27,9 @@ wp = mmr.ops.pack_conv_weights(w, dt, x3=train)
 _conv = mmr.ops.conv3d_k3
 mmr.ops.conv3d_k3 = lambda x, wp, b, C: _conv(x, wp, b, C, out_f32=train, x3=train)
 lib = mmr._lib.load()
-fn = ctypes.CDLL(mmr._lib.lib_path()).mmr_debug_conv_stamps
+_dl = ctypes.CDLL(mmr._lib.lib_path())
+_dl.mmr_debug_set_stamps(1)
+fn = _dl.mmr_debug_conv_stamps
 buf = (ctypes.c_ulonglong * 64)()
 for _ in range(2):
     y = mmr.ops.conv3d_k3(x, wp, b, C)
