@@ -246,13 +246,15 @@ grad_l2_bwd_kernel(const float* __restrict__ f, float* __restrict__ df, int B, i
 // index j are a short index range per axis (about 2 / st of them); no atomics -> one pass, fixed summation order.
 // The weights are recomputed exactly as the forward computes them (axis_setup_g of (float)i * st).
 // ------------------------------------------------------------------------- //
-__device__ __forceinline__ void axis_range(int j, float st, int no, int& lo, int& hi)
+__device__ __forceinline__ void axis_range(int j, float st, int no, int maxi, int& lo, int& hi)
 {
     if (st > 0.f) {
         lo = (int)floorf((float)(j - 1) / st) - 1;
         hi = (int)ceilf((float)(j + 1) / st) + 1;
         lo = lo < 0 ? 0 : lo;
-        hi = hi > no - 1 ? no - 1 : hi;
+        // the forward clamps every position beyond the last voxel onto it (arange_over_f grid with Xo > X * zoom): all of
+        // those outputs read index maxi with weight 1 and must be gathered here, or this is not the adjoint
+        hi = (hi > no - 1 || j == maxi) ? no - 1 : hi;
     } else {  // single input sample along this axis: every output reads index 0
         lo = 0;
         hi = no - 1;
@@ -277,9 +279,9 @@ resize_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int B
         const int64_t r = v - b * nvi;
         const int z = (int)(r % Z), y = (int)((r / Z) % Y), x = (int)(r / ((int64_t)Z * Y));
         int x0, x1, y0, y1, z0, z1;
-        axis_range(x, stx, Xo, x0, x1);
-        axis_range(y, sty, Yo, y0, y1);
-        axis_range(z, stz, Zo, z0, z1);
+        axis_range(x, stx, Xo, X - 1, x0, x1);
+        axis_range(y, sty, Yo, Y - 1, y0, y1);
+        axis_range(z, stz, Zo, Z - 1, z0, z1);
         const float* src = dout + b * nvo * C + c;
         float acc = 0.f;
         constexpr int RW = 10;   // candidates per axis for factors down to 1/2 (8); longer ranges take the generic loop

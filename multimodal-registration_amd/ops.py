@@ -331,6 +331,8 @@ def dice_loss(y_true, y_pred, return_parts=False, eps_mode=None, zeropad=False):
     loss = torch.empty(1, dtype=torch.float32, device=y_true.device)
     tb = torch.empty((B, L, 2), dtype=torch.float32, device=y_true.device)
     fn = lib.mmr_dice_zeropad_fwd_f32 if zeropad else lib.mmr_dice_fwd_f32
+    if zeropad:   # losses.py:64-66 hard-codes tf.math.divide_no_nan whatever the voxelmorph version: the A6 switch is Dice's only
+        eps_mode = "divide_no_nan"
     rc = fn(y_true.data_ptr(), y_pred.data_ptr(), loss.data_ptr(), tb.data_ptr(), ws.data_ptr(),
                               B, nvox, L, semantics.code("dice_eps", eps_mode), _stream())
     _lib.check(rc, "mmr_dice_fwd_f32")
@@ -550,6 +552,8 @@ def dice_labels_fwd(lab1, lab2, flow, L, zeropad=False, eps_mode=None):
     loss = torch.empty(1, dtype=torch.float32, device=flow.device)
     tb = torch.empty((B, L, 2), dtype=torch.float32, device=flow.device)
     fn = lib.mmr_dice_labels_zeropad_fwd if zeropad else lib.mmr_dice_labels_fwd
+    if zeropad:   # losses.py:64-66: always divide_no_nan
+        eps_mode = "divide_no_nan"
     rc = fn(lab1.data_ptr(), lab2.data_ptr(), flow.data_ptr(), loss.data_ptr(), tb.data_ptr(),
             ws.data_ptr(), B, X, Y, Z, int(L), semantics.code("dice_eps", eps_mode), _stream())
     _lib.check(rc, "mmr_dice_labels_fwd")
@@ -562,6 +566,8 @@ def dice_labels_bwd(lab1, lab2, flow, top_bot, L, scale=1.0, out=None, zeropad=F
     if out is None:
         out = torch.empty_like(flow)
     fn = _lib.load().mmr_dice_labels_zeropad_bwd if zeropad else _lib.load().mmr_dice_labels_bwd
+    if zeropad:
+        eps_mode = "divide_no_nan"
     rc = fn(lab1.data_ptr(), lab2.data_ptr(), flow.data_ptr(), top_bot.data_ptr(),
             out.data_ptr(), B, X, Y, Z, int(L), float(scale), int(acc), semantics.code("dice_eps", eps_mode), _stream())
     _lib.check(rc, "mmr_dice_labels_bwd")

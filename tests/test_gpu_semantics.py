@@ -55,7 +55,8 @@ def test_resize_arange_over_f_kat(dev):
 
 @pytest.mark.parametrize("grid", ["align_corners", "arange_over_f"])
 @pytest.mark.parametrize("shape,new,zoom", [((6, 8, 10), (12, 16, 20), 2.0), ((12, 16, 20), (6, 8, 10), 0.5),
-                                            ((5, 7, 4), (7, 10, 6), 1.5)])
+                                            ((5, 7, 4), (7, 10, 6), 1.5),
+                                            ((4, 5, 6), (14, 16, 19), 2.0)])   # Xo > X * zoom + 2: many outputs clamp onto the last voxel
 def test_resize_bwd_is_adjoint_for_both_grids(dev, grid, shape, new, zoom):
     import mmr
     from oracle import grad_torch as G

@@ -84,3 +84,39 @@ def test_resident_batch_generator_matches_host_generator():
             assert isinstance(ds, torch.Tensor) and ds.dtype == torch.uint8 and tuple(ds.shape) == hs.shape
             assert np.array_equal(ds.numpy(), hs) and np.array_equal(dt_.numpy(), ht)
             assert void[0].shape == (bs, 12, 10, 14, 3)
+
+
+def test_preprocess_and_rai_warp_match_reference_register():
+    """goldens captured by driving the reference's own ``bids_registration.register()`` through declared stubs
+    (tests/golden/make_golden_f2.py): min-max scaling, lexicographic ``max(shape)``, the floor-to-16 crop shape
+    (bids_registration.py:127-159) and the RAI permutation / sign table + intent 1007 of the saved warp (:394-425)."""
+    from mmr import registration as R
+    from mmr import tiling
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "host_preproc_rai.npz"))
+    specs = dict(use_subvol=False, subvol_size=[32, 32, 32], min_perc_overlap=0.1)
+    seen_orient = set()
+    for i in range(int(g["n_cases"])):
+        fx, mv = g[f"c{i}_fixed"].astype(np.float64), g[f"c{i}_moving"].astype(np.float64)
+        fa, ma = g[f"c{i}_fixed_affine"], g[f"c{i}_moving_affine"]
+        want_fx, want_mv = g[f"c{i}_fixed_proc"], g[f"c{i}_moving_proc"]
+        # shape rule on the reference's own (possibly different) shapes: tuple max, then floor to a multiple of 16
+        assert tiling.round_down_16(max(fx.shape, mv.shape)) == want_fx.shape == tuple(g[f"c{i}_model_inshape"])
+        # the product's preprocess on the fixed image alone (moving := fixed grid, so no stubbed resampling is involved):
+        # min-max + crop must reproduce the reference's _proc volume
+        fx_r, _, _, _, _ = R.preprocess(specs, R.Volume(fx, fa), R.Volume(fx, fa), "linear")
+        same_shape = tiling.round_down_16(fx.shape)
+        sl = tuple(slice(0, min(a, b)) for a, b in zip(same_shape, want_fx.shape))
+        np.testing.assert_allclose(fx_r.data[sl], want_fx[sl], atol=1e-9)
+        np.testing.assert_allclose(R._minmax(mv)[tuple(slice(0, min(a, b)) for a, b in zip(mv.shape, want_mv.shape))],
+                                   want_mv[tuple(slice(0, min(a, b)) for a, b in zip(mv.shape, want_mv.shape))], atol=1e-12)
+        assert 0.0 <= want_fx.min() and want_fx.max() <= 1.0
+        # RAI reordering of the (full-resolution, scale 1) field
+        got = R.to_rai_warp(g[f"c{i}_field"].astype(np.float64), fa)
+        assert got.shape == g[f"c{i}_warp_rai"].shape and got.shape[3] == 1
+        np.testing.assert_array_equal(got.astype(np.float32), g[f"c{i}_warp_rai"])
+        assert int(g[f"c{i}_warp_intent"]) == 1007 and int(g[f"c{i}_warp_original_intent"]) == 1007
+        np.testing.assert_array_equal(g[f"c{i}_warp_affine"], fa)          # saved with the FIXED image's affine
+        assert tuple(g[f"c{i}_warp_original_shape"])[:3] == mv.shape and tuple(g[f"c{i}_moved_original_shape"]) == mv.shape
+        assert bool(g[f"c{i}_moved_saved_equals_moving_proc"])
+        seen_orient.add("".join(R.axcodes(-fa)))
+    assert len(seen_orient) >= 5   # RAS, LPS, LPI and three axis permutations

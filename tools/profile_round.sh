@@ -8,6 +8,10 @@ out=gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 step() { echo "[profile_round] $*"; }
+# build OUTSIDE the profiler (hipcc chain-execs clang / lld, which must not happen under rocprofv3's preload), then pin the
+# profiled runs to the built library so that none of them can start a build
+python3 multimodal-registration_amd/build.py > $out/${tag}_build.log 2>&1 || exit 1
+export MMR_LIB="$GRAFT_REPO_ROOT/multimodal-registration_amd/csrc/libmmr_hip.so"
 # 1. kernel-trace stats of the exact default bench command (headline line with roofline, cpu_baseline, secondary)
 step "stats: default bench"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats_infer -- python3 bench.py > $out/${tag}_bench_default.json 2> $out/${tag}_bench_default.err || exit 1
