@@ -333,6 +333,20 @@ def roofline_from_profile(prof, steps, traffic_file):
                                            "frac": round(v[1] / (v[0] * 1e-3) / 1e12 / peak_of(k), 3),
                                            "ms_per_step": round(v[0] / steps, 3)}
                                        for k, v in kern.items() if k != dom and not k.startswith("hbm:") and v[0] > 0}}
+        # folded upsampling (family *_upfold): `TFLOPs` is the algorithmic 27-tap count of that half-layer; the
+        # kernel EXECUTES 8/27 of it on the matrix cores -- state both
+        for k, d in roof["other_mfma_kernels"].items():
+            if k.endswith("_upfold"):
+                d["executed_TFLOPs"] = round(d["TFLOPs"] * 8 / 27, 1)
+                d["executed_frac"] = round(d["frac"] * 8 / 27, 3)
+        mf = {k: v for k, v in kern.items() if not k.startswith("hbm:")}
+        alg = sum(v[1] for v in mf.values())
+        exe = sum(v[1] * (8 / 27 if k.endswith("_upfold") else 1.0) for k, v in mf.items())
+        tms = sum(v[0] for v in mf.values())
+        roof["all_mfma_kernels"] = {"ms_per_step": round(tms / steps, 3), "algorithmic_tflop_per_step": round(alg / steps / 1e12, 3),
+                                    "executed_tflop_per_step": round(exe / steps / 1e12, 3),
+                                    "algorithmic_TFLOPs": round(alg / (tms * 1e-3) / 1e12, 1) if tms > 0 else 0.0,
+                                    "executed_TFLOPs": round(exe / (tms * 1e-3) / 1e12, 1) if tms > 0 else 0.0}
         name = dom
     tpath = os.path.join(ROOT, "profiles", traffic_file)
     if os.path.exists(tpath):

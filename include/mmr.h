@@ -110,6 +110,25 @@ int mmr_conv3d_k3_fwd_ws(const void* in0, int C0, int up0, const void* in1, int 
                          const void* w_packed, const float* bias, void* out, void* pool_out,
                          int B, int X, int Y, int Z, int Cout,
                          int leaky, float alpha, int dtype, int out_f32, void* ws, void* stream);
+/* Folded upsampling -- the decoder layers of VxmDense convolve concatenate([UpSampling3D(2)(x), skip])
+ * (3d_reg.py:297-305 builds four of them).  For the upsampled channels the 27 taps at a
+ * full-resolution voxel 2i+p touch only a 2x2x2 block of x, so that half of the layer is 8 convolutions (one per
+ * parity class p) with 8 taps each on the LOW-resolution grid with pre-summed weights: 8/27 of the multiply-adds.
+ *   mmr_conv3d_k3_upfold_pack: w_up_keras [27][C0][Cout] fp32 (the first C0 input channels of the layer's Keras
+ *       kernel, contiguous) -> folded MFMA operand image of mmr_conv3d_k3_upfold_packed_bytes() bytes;
+ *   mmr_conv3d_k3_upfold_fwd:  in_low [B,X2,Y2,Z2,C0] (bf16 for MMR_DT_BF16, fp32 for MMR_DT_F32X3) ->
+ *       partial [B,2*X2,2*Y2,2*Z2,Cout] fp32 (raw sums, no bias; every element written);
+ *   mmr_conv3d_k3_fwd_init:    out = act(cinit + conv3x3x3(in) + bias) over the skip channels, cinit = that partial.
+ * The pair equals mmr_conv3d_k3_fwd(in_low, C0, up0 = 1, skip, C1, ...) up to the summation order of the weights.
+ * bf16 / fp32x3 only, C0 a multiple of the channel slice (64 / 32), Cout a multiple of 64; else MMR_EUNSUPPORTED /
+ * MMR_EINVAL. */
+int64_t mmr_conv3d_k3_upfold_packed_bytes(int C0, int Cout, int dtype);
+int mmr_conv3d_k3_upfold_pack(const float* w_up_keras, void* w_packed, int C0, int Cout, int dtype, void* stream);
+int mmr_conv3d_k3_upfold_fwd(const void* in_low, int C0, const void* w_packed, float* partial,
+                             int B, int X2, int Y2, int Z2, int Cout, int dtype, void* stream);
+int mmr_conv3d_k3_fwd_init(const void* in, int Cin, const void* w_packed, const float* bias, const float* cinit,
+                           void* out, int B, int X, int Y, int Z, int Cout,
+                           int leaky, float alpha, int dtype, int out_f32, void* stream);
 /* First layer: concatenate([moving, fixed]) (2 x 1 channel, fp32) -> Cout.  pool_out (optional, same element type as
  * out, [B,X/2,Y/2,Z/2,Cout]): MaxPooling3D(2) of the activated output from the same kernel (bf16 and fp32x3 kernels;
  * MMR_EUNSUPPORTED with the exact-fp32 kernel).  Saves the 2.5 GB read of a separate pooling pass at C2.        */

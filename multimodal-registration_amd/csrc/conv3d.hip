@@ -73,6 +73,9 @@ struct ConvParams {
     // the second range only (the skip tensor's LeakyReLU backward + bias sums)
     char* out1;
     int csplit;
+    // CV_CINIT: the accumulators start from this fp32 tensor [B,X,Y,Z,Cout] instead of zero -- the second half of a
+    // folded-upsample layer (see CV_UPFOLD): out = act(cinit + conv(in) + bias)
+    const float* cinit = nullptr;
 };
 
 template <int N> struct IntTag { static constexpr int value = N; };
@@ -84,6 +87,18 @@ constexpr int CV_DMA_A = 1 << 8;    // bf16 / exact fp32: the haloed A tile goes
 constexpr int CV_STAMP = 1 << 10;   // cycle stamps (only with -DMMR_DIAG; never the measured build)
 constexpr int CV_BATCHA = 1 << 12;  // fp32x3 / x1: all staging loads of a slice issued branch-free, masked when stored
 constexpr int CV_PRIO_Y = 1 << 15;  // static s_setprio 1 for waves 4-7
+// Folded upsampling.  A decoder layer convolves concat([UpSampling3D(2)(x) | skip]).  For the upsampled channels the 27
+// taps at a full-resolution voxel g = 2 i + p touch only a 2x2x2 block of x: per axis, parity p = 0 reads x[i-1] with
+// W[-1] and x[i] with W[0] + W[+1]; p = 1 reads x[i] with W[-1] + W[0] and x[i+1] with W[+1] (zero padding of the
+// upsampled tensor = zero padding of x).  So that half of the layer is 8 convolutions (one per parity class) with 8 taps
+// each ON THE LOW-RESOLUTION GRID: 64 tap-steps per low-res voxel instead of 8 x 27 = 216 -- 8/27 of the MACs.
+//   CV_UPFOLD: the kernel runs on x (p.X/Y/Z = low-res dims), blockIdx.y = class * ntiles_n + n-tile, walks the class's
+//              8 taps (halo offsets p + s, s in {0,1}: the same offsets a 3x3x3 tap has) over pre-folded weights
+//              (mmr_conv3d_k3_upfold_pack) and stores the raw fp32 sums at (2 i + p) of a full-resolution tensor;
+//   CV_CINIT:  the ordinary 27-tap kernel over the skip channels starts its accumulators from that tensor.
+// dec_final_0 of BASELINE configs[1] (512 -> 256 at 160x160x192): 17.4 -> 11.3 TMAC.
+constexpr int CV_UPFOLD = 1 << 16;
+constexpr int CV_CINIT = 1 << 17;
 
 #ifdef MMR_DIAG
 int g_diag_stamps = 0;   // host switch of the stamped instantiations (conv and wgrad), set by mmr_debug_set_stamps
@@ -201,6 +216,10 @@ conv3d_k3_kernel(const ConvParams p)
     // static priority for the younger half of the workgroup (-1 % on the 64-column fp32x3 tile, +14 % on the 256-column
     // bf16 tile whose DMA issue needs waves 0-3 to be the arbitration winners)
     constexpr bool PRIO_Y = (VAR & CV_PRIO_Y) != 0;
+    constexpr bool UPF = (VAR & CV_UPFOLD) != 0;
+    constexpr bool CINIT = (VAR & CV_CINIT) != 0;
+    constexpr int TAPS = UPF ? 8 : 27;
+    static_assert(!(UPF || CINIT) || (((VAR & CV_M16) != 0) && DT != MMR_DT_F32 && NT == 2), "folded upsampling: 16x16x32 kernels");
 #ifdef MMR_DIAG
     constexpr bool STAMP = (VAR & CV_STAMP) != 0;
     unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = 0;
@@ -230,7 +249,9 @@ conv3d_k3_kernel(const ConvParams p)
     const int txi = bid % p.ntx;
     const int b = bid / p.ntx;
     const int x0 = txi * TXT, y0 = tyi * TY, z0 = tzi * TZ;
-    const int ntile = blockIdx.y;
+    const int ntn = UPF ? (p.Cout + BN - 1) / BN : 1;
+    const int cls = UPF ? (int)blockIdx.y / ntn : 0;                 // parity class (px, py, pz) = bits 2, 1, 0
+    const int ntile = UPF ? (int)blockIdx.y % ntn : (int)blockIdx.y;
 
     const int pv = row_perm(lane & 31);
     const int vyl = pv >> 3, vz = pv & 7;  // y inside the M-tile's 4-row patch, z
@@ -269,11 +290,25 @@ conv3d_k3_kernel(const ConvParams p)
         }
 #pragma unroll
         for (int ni = 0; ni < 2 * NT; ++ni) b16_off[ni] = (q16 * BN + wn * NT * 32 + ni * 16 + r16) * 16;
+        if constexpr (CINIT) {
+            // accumulator (mi, ni)[r] <-> cout co + ni * 4 + r of voxel (mi, r16): the epilogue's layout, read the same way
+            const int co = ntile * BN + wn * 64 + q16 * 16;
+#pragma unroll
+            for (int mi = 0; mi < 2 * MT; ++mi) {
+                const int mt = wm * MT + (mi >> 1);
+                const int gx = x0 + (mt >> 1), gy = y0 + (mt & 1) * 4 + 2 * (mi & 1) + (r16 >> 3), gz = z0 + (r16 & 7);
+                if (co + 15 < p.Cout && gx < p.X && gy < p.Y && gz < p.Z) {
+                    const float* ci = p.cinit + ((((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz) * p.Cout + co;
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) acc16[mi][ni] = *reinterpret_cast<const f32x4*>(ci + ni * 4);
+                }
+            }
+        }
     }
 
     const int nslices = (p.C0 + p.C1) / KC;
-    const int G = nslices * 27;
-    const char* wtile = p.wp + (size_t)ntile * G * B_BYTES;
+    const int G = nslices * TAPS;
+    const char* wtile = p.wp + (size_t)blockIdx.y * G * B_BYTES;   // UPF: [class][n-tile], else [n-tile]
     const int X2 = p.X >> 1, Y2 = p.Y >> 1, Z2 = p.Z >> 1;
 
     // global load of item `it` of this thread's share of the haloed tile of channel slice s.
@@ -415,7 +450,7 @@ conv3d_k3_kernel(const ConvParams p)
     // ---- prologue: first slice of A, first tap of B of this block's step range ----
     const int g0 = p.kpart ? (int)blockIdx.z * p.gsplit : 0;
     const int g1 = p.kpart ? min(g0 + p.gsplit, G) : G;
-    int cur = 0, tap = g0 % 27, s = g0 / 27;
+    int cur = 0, tap = g0 % TAPS, s = g0 / TAPS;
     issue_b(g0, 0);
     // a macro, not a lambda: wrapped in one more closure, hipcc no longer scalarises the by-value kernel argument
     // struct and every instantiation reads ConvParams from scratch (288 B/lane; the bn64 convs ran 1.8x slower)
@@ -478,7 +513,10 @@ conv3d_k3_kernel(const ConvParams p)
             if (more) issue_b(g + 1, cur ^ 1);
         }
         MMR_STAMP(0);
-        const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
+        // halo offset of this tap; folded upsampling: parity bit + tap bit per axis
+        const int dx = UPF ? ((cls >> 2) & 1) + ((tap >> 2) & 1) : tap / 9;
+        const int dy = UPF ? ((cls >> 1) & 1) + ((tap >> 1) & 1) : (tap / 3) % 3;
+        const int dz = UPF ? (cls & 1) + (tap & 1) : tap % 3;
         const int tapoff = (dx * (HY * HZ) + dy * HZ + dz) * ROWB;
         const int sw = (swz(vyl + dy, vz + dz) ^ h) << 4;
         const char* bA = sA + tapoff;
@@ -660,7 +698,7 @@ conv3d_k3_kernel(const ConvParams p)
 #endif
         cur ^= 1;
         ++tap;
-        if (tap == 27) {
+        if (tap == TAPS) {
             tap = 0;
             ++s;
             if (s < nslices && more) {  // every wave is past its last read of sA: install the next slice
@@ -735,6 +773,24 @@ conv3d_k3_kernel(const ConvParams p)
         static_assert(NT == 2, "16x16x32 path: 64 columns per wave");
         const int cl = wn * 64 + q16 * 16;
         const int co = ntile * BN + cl;
+        if constexpr (UPF) {
+            // raw fp32 sums of parity class cls to voxel 2 i + p of the full-resolution partial tensor [B,2X,2Y,2Z,Cout]
+            const int px = (cls >> 2) & 1, py = (cls >> 1) & 1, pz = cls & 1;
+#pragma unroll
+            for (int mi = 0; mi < 2 * MT; ++mi) {
+                const int mt = wm * MT + (mi >> 1);
+                const int lx = x0 + (mt >> 1), ly = y0 + (mt & 1) * 4 + 2 * (mi & 1) + (r16 >> 3), lz = z0 + (r16 & 7);
+                if (co + 15 < p.Cout && lx < p.X && ly < p.Y && lz < p.Z) {
+                    float* po = reinterpret_cast<float*>(p.out) +
+                                ((((size_t)b * (2 * p.X) + 2 * lx + px) * (2 * p.Y) + 2 * ly + py) * (2 * p.Z) + 2 * lz + pz) * p.Cout + co;
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        *reinterpret_cast<float4*>(po + ni * 4) =
+                            make_float4(acc16[mi][ni][0], acc16[mi][ni][1], acc16[mi][ni][2], acc16[mi][ni][3]);
+                }
+            }
+            return;
+        }
         const int cs = p.csplit;
         const bool second = cs > 0 && co >= cs;
         const int ostride = cs ? (second ? p.Cout - cs : cs) : p.Cout;  // row stride and column of this lane's block
@@ -949,6 +1005,54 @@ __global__ void pack_kernel(const float* __restrict__ w, char* __restrict__ wp, 
     }
 }
 
+// Folded-upsampling weight image (CV_UPFOLD): [class 8][n-tile][slice][tap 8][chunk 8][BN][16 B]; tap bit s per axis of
+// parity class bit p sums the original taps { p=0,s=0: {0} | p=0,s=1: {1,2} | p=1,s=0: {0,1} | p=1,s=1: {2} } (fp32 sums,
+// then the same bf16 / hi-lo encoding and column permutation as pack_kernel).  w = Keras [27][C0][Cout] of the upsampled
+// channels only.
+template <int DT>
+__global__ void pack_upfold_kernel(const float* __restrict__ w, char* __restrict__ wp, int Cin, int Cout, int BN, int ntiles)
+{
+    constexpr int KC = Elt<DT>::kc;
+    constexpr int EPC = 8;
+    const int nslices = Cin / KC;
+    const int64_t total = (int64_t)8 * ntiles * nslices * 8 * 8 * BN;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i;
+        const int col = (int)(r % BN); r /= BN;
+        const int chunk = (int)(r % 8); r /= 8;
+        const int tap = (int)(r % 8); r /= 8;
+        const int s = (int)(r % nslices); r /= nslices;
+        const int t = (int)(r % ntiles);
+        const int cls = (int)(r / ntiles);
+        const int co = t * BN + conv_cout_of_col(col);
+        int lo3[3], n3[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int pb = (cls >> (2 - a)) & 1, sb = (tap >> (2 - a)) & 1;
+            lo3[a] = pb == 0 ? (sb == 0 ? 0 : 1) : (sb == 0 ? 0 : 2);
+            n3[a] = (pb == 0) == (sb == 0) ? 1 : 2;        // (0,0) and (1,1): one tap; (0,1) and (1,0): two
+        }
+        char* dst = wp + i * 16;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const int cc = (DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) ? (chunk & 3) : chunk;
+            const int ci = s * KC + cc * EPC + e;
+            float v = 0.f;
+            if (co < Cout) {
+                for (int a = 0; a < n3[0]; ++a)
+                    for (int bb = 0; bb < n3[1]; ++bb)
+                        for (int c = 0; c < n3[2]; ++c) {
+                            const int tp = ((lo3[0] + a) * 3 + (lo3[1] + bb)) * 3 + (lo3[2] + c);
+                            v += w[((int64_t)tp * Cin + ci) * Cout + co];
+                        }
+            }
+            bf16_t hb = f32_to_bf16(v);
+            if ((DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) && chunk >= 4) hb = f32_to_bf16(v - bf16_to_f32(hb));  // lo part
+            reinterpret_cast<bf16_t*>(dst)[e] = hb;
+        }
+    }
+}
+
 // out = act(sum_k kpart[k] + bias), summed in index order (bitwise reproducible), fp32 or bf16 store
 __global__ void __launch_bounds__(256)
 conv_ksplit_finalize_kernel(const float* __restrict__ kpart, int nk, const float* __restrict__ bias, void* __restrict__ out,
@@ -1008,7 +1112,7 @@ int launch_conv(const ConvParams& p, int ntiles_n, hipStream_t st, int64_t* nblk
         return check_launch();
     }
     q.kpart = nullptr;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, ntiles_n), dim3(CONV_THREADS), LDS, st, q);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, ((VAR & CV_UPFOLD) != 0 ? 8 : 1) * ntiles_n), dim3(CONV_THREADS), LDS, st, q);
     return check_launch();
 }
 
@@ -1039,6 +1143,25 @@ int dispatch_conv(const ConvParams& p, hipStream_t st, int64_t* nblk_out = nullp
             return launch_conv<DT, 4, 2, 4, 2, V_FULL | CV_BATCHA>(p, nt, st, nblk_out);
         case 64: return launch_conv<DT, 8, 1, 2, 2, V_FULL | CV_BATCHA | CV_PRIO_Y>(p, nt, st, nblk_out);
         default: return launch_conv<DT, 8, 1, 2, 1, CV_DMA_A>(p, nt, st, nblk_out);
+    }
+}
+
+// The two halves of a folded-upsampling layer (EXTRA = CV_UPFOLD or CV_CINIT) on the per-tile default of the plain conv
+template <int DT, int EXTRA>
+int dispatch_conv_fold(const ConvParams& p, hipStream_t st)
+{
+    static_assert(DT == MMR_DT_BF16 || DT == MMR_DT_F32X3, "folded upsampling: bf16 / fp32x3");
+    const int BN = conv_bn(p.Cout);
+    const int nt = (p.Cout + BN - 1) / BN;
+    constexpr bool F32T = (DT == MMR_DT_F32X3);
+    constexpr int V_FULL = CV_M16 | CV_PIPE | CV_DMA_A;
+    switch (BN) {
+        case 256: return launch_conv<DT, 2, 4, 4, 2, V_FULL | (F32T ? CV_BATCHA : 0) | EXTRA>(p, nt, st, nullptr);
+        case 128:
+            if constexpr (DT == MMR_DT_BF16) return launch_conv<DT, 4, 2, 4, 2, CV_M16 | EXTRA>(p, nt, st, nullptr);
+            else return launch_conv<DT, 4, 2, 4, 2, V_FULL | CV_BATCHA | EXTRA>(p, nt, st, nullptr);
+        case 64: return launch_conv<DT, 8, 1, 2, 2, V_FULL | (F32T ? CV_BATCHA : 0) | CV_PRIO_Y | EXTRA>(p, nt, st, nullptr);
+        default: return MMR_EUNSUPPORTED;
     }
 }
 
@@ -1888,6 +2011,72 @@ extern "C" int mmr_conv3d_k3_fwd_ws(const void* in0, int C0, int up0, const void
     if (dtype == MMR_DT_F32X3) return dispatch_conv<MMR_DT_F32X3>(p, as_stream(stream));
     if (dtype == MMR_DT_F32X1) return dispatch_conv<MMR_DT_F32X1>(p, as_stream(stream));
     return dispatch_conv<MMR_DT_F32>(p, as_stream(stream));
+}
+
+// ---- folded upsampling (decoder layers: conv over concat([UpSampling3D(2)(x) | skip]); see CV_UPFOLD) ---- //
+extern "C" int64_t mmr_conv3d_k3_upfold_packed_bytes(int C0, int Cout, int dtype)
+{
+    if (dtype != MMR_DT_BF16 && dtype != MMR_DT_F32X3) return MMR_EUNSUPPORTED;
+    const int kc = (dtype == MMR_DT_BF16) ? 64 : 32;
+    if (C0 < kc || C0 % kc || Cout < 64 || Cout % 64) return MMR_EINVAL;
+    const int BN = conv_bn(Cout);
+    return (int64_t)8 * (Cout / BN) * (C0 / kc) * 8 * BN * 128;
+}
+
+// w_up_keras: [27][C0][Cout] fp32 = the first C0 input channels of the layer's Keras kernel (contiguous)
+extern "C" int mmr_conv3d_k3_upfold_pack(const float* w_up_keras, void* w_packed, int C0, int Cout, int dtype, void* stream)
+{
+    const int64_t bytes = mmr_conv3d_k3_upfold_packed_bytes(C0, Cout, dtype);
+    if (bytes < 0) return (int)bytes;
+    if (!w_up_keras || !w_packed) return MMR_EINVAL;
+    const int BN = conv_bn(Cout);
+    const int grid = stream_grid(bytes / 16, 256);
+    if (dtype == MMR_DT_BF16)
+        hipLaunchKernelGGL(pack_upfold_kernel<MMR_DT_BF16>, dim3(grid), dim3(256), 0, as_stream(stream), w_up_keras,
+                           (char*)w_packed, C0, Cout, BN, Cout / BN);
+    else
+        hipLaunchKernelGGL(pack_upfold_kernel<MMR_DT_F32X3>, dim3(grid), dim3(256), 0, as_stream(stream), w_up_keras,
+                           (char*)w_packed, C0, Cout, BN, Cout / BN);
+    return check_launch();
+}
+
+// partial [B,2X2,2Y2,2Z2,Cout] fp32 = conv3x3x3(UpSampling3D(2)(in_low)) restricted to the C0 upsampled channels, no bias.
+// in_low [B,X2,Y2,Z2,C0] bf16 (MMR_DT_BF16) or fp32 (MMR_DT_F32X3).  Every element of `partial` is written.
+extern "C" int mmr_conv3d_k3_upfold_fwd(const void* in_low, int C0, const void* w_packed, float* partial, int B, int X2,
+                                        int Y2, int Z2, int Cout, int dtype, void* stream)
+{
+    if (!in_low || !w_packed || !partial || B < 1 || X2 < 1 || Y2 < 1 || Z2 < 1) return MMR_EINVAL;
+    if (mmr_conv3d_k3_upfold_packed_bytes(C0, Cout, dtype) < 0) return (int)mmr_conv3d_k3_upfold_packed_bytes(C0, Cout, dtype);
+    ConvParams p;
+    p.in0 = (const char*)in_low; p.in1 = nullptr; p.wp = (const char*)w_packed; p.bias = nullptr;
+    p.out = (char*)partial;
+    p.B = B; p.X = X2; p.Y = Y2; p.Z = Z2; p.C0 = C0; p.C1 = 0; p.up0 = 0; p.Cout = Cout;
+    p.leaky = 0; p.alpha = 0.f; p.out_f32 = 1; p.ymask = nullptr; p.part = nullptr;
+    p.kpart = nullptr; p.gsplit = 0; p.out1 = nullptr; p.csplit = 0;
+    p.ntx = (X2 + TX - 1) / TX; p.nty = (Y2 + TY - 1) / TY; p.ntz = (Z2 + TZ - 1) / TZ;
+    if (dtype == MMR_DT_BF16) return dispatch_conv_fold<MMR_DT_BF16, CV_UPFOLD>(p, as_stream(stream));
+    return dispatch_conv_fold<MMR_DT_F32X3, CV_UPFOLD>(p, as_stream(stream));
+}
+
+// out = act(cinit + conv3x3x3(in) + bias): the skip half of a folded layer (cinit = mmr_conv3d_k3_upfold_fwd's partial),
+// otherwise mmr_conv3d_k3_fwd without the concat / split-K options.
+extern "C" int mmr_conv3d_k3_fwd_init(const void* in, int Cin, const void* w_packed, const float* bias, const float* cinit,
+                                      void* out, int B, int X, int Y, int Z, int Cout, int leaky, float alpha, int dtype,
+                                      int out_f32, void* stream)
+{
+    if (!in || !w_packed || !out || !cinit || B < 1 || X < 1 || Y < 1 || Z < 1) return MMR_EINVAL;
+    if (dtype != MMR_DT_BF16 && dtype != MMR_DT_F32X3) return MMR_EUNSUPPORTED;
+    const int kc = (dtype == MMR_DT_BF16) ? 64 : 32;
+    if (Cin < kc || Cin % kc || Cout < 64 || Cout % 64) return MMR_EINVAL;
+    ConvParams p;
+    p.in0 = (const char*)in; p.in1 = nullptr; p.wp = (const char*)w_packed; p.bias = bias;
+    p.out = (char*)out;
+    p.B = B; p.X = X; p.Y = Y; p.Z = Z; p.C0 = Cin; p.C1 = 0; p.up0 = 0; p.Cout = Cout;
+    p.leaky = leaky; p.alpha = alpha; p.out_f32 = out_f32; p.ymask = nullptr; p.part = nullptr;
+    p.kpart = nullptr; p.gsplit = 0; p.out1 = nullptr; p.csplit = 0; p.cinit = cinit;
+    p.ntx = (X + TX - 1) / TX; p.nty = (Y + TY - 1) / TY; p.ntz = (Z + TZ - 1) / TZ;
+    if (dtype == MMR_DT_BF16) return dispatch_conv_fold<MMR_DT_BF16, CV_CINIT>(p, as_stream(stream));
+    return dispatch_conv_fold<MMR_DT_F32X3, CV_CINIT>(p, as_stream(stream));
 }
 
 extern "C" int64_t mmr_conv3d_k3_dgrad_masked_ws_bytes(int B, int X, int Y, int Z, int Cout)

@@ -129,7 +129,8 @@ class VxmDense:
                  nb_unet_conv_per_level=1, int_steps=7, svf_resolution=1, int_resolution=2,
                  int_downsize=None, bidir=False, use_probs=False, src_feats=1, trg_feats=1,
                  unet_half_res=False, input_model=None, hyp_model=None, fill_value=None,
-                 reg_field="preintegrated", name="vxm_dense", compute_dtype="fp32x3", device="cuda", seed=0):
+                 reg_field="preintegrated", name="vxm_dense", compute_dtype="fp32x3", device="cuda", seed=0,
+                 fold_upsampling=True):
         if len(inshape) != 3:
             raise ValueError("VxmDense here is 3-D only (the reference registers 3-D volumes)")
         if bidir or use_probs or unet_half_res or hyp_model is not None or nb_unet_conv_per_level != 1:
@@ -148,6 +149,10 @@ class VxmDense:
         self.enc, self.dec = enc, dec
         self.int_steps, self.int_resolution, self.svf_resolution = int(int_steps), int_resolution, svf_resolution
         self.fill_value = fill_value
+        # decoder layers as folded upsampling (ops.conv3d_k3_upfold: the upsampled half of concat([up2(x), skip]) on the
+        # low-resolution grid, 8/27 of its multiply-adds) wherever ops.upfold_supported says both launches fill the chip
+        self.fold_upsampling = bool(fold_upsampling)
+        self._packed_fold = {}
         # input_model (train_synthmorph.py:294-296): its two outputs are source / target and its inputs (the label maps)
         # become the model's inputs.  Anything that is not the generator pair is refused rather than ignored.
         if input_model is not None and not isinstance(input_model, InputModel):
@@ -254,10 +259,12 @@ class VxmDense:
             self._w[2 * li][..., :cout].index_copy_(3, idx, k)
             self._w[2 * li + 1][:cout].copy_(b)
         self._packed = None
+        self._packed_fold = {}
 
     def invalidate_packed(self):
         """Call after the flat parameter buffer was updated in place (optimizer step)."""
         self._packed = None
+        self._packed_fold = {}
 
     def _pack(self):
         if self._packed is None:
@@ -367,7 +374,15 @@ class VxmDense:
     # ------------------------------------------------------------------ forward
     def _conv(self, li, x, **kw):
         """Layer li of the plan on the MFMA kernel."""
-        return ops.conv3d_k3(x, self._packed[li], self._w[2 * li + 1], self.pplan[li][2], x3=self.x3, **kw)
+        in1, cout = kw.get("in1"), self.pplan[li][2]
+        if (self.fold_upsampling and kw.get("up0") and in1 is not None
+                and ops.upfold_supported(x.shape[-1], in1.shape[-1], cout, self.dtype, self.x3, *in1.shape[:4])):
+            if li not in self._packed_fold:
+                self._packed_fold[li] = ops.pack_upfold_weights(self._w[2 * li].contiguous(), x.shape[-1], self.dtype, x3=self.x3)
+            w_up, w_skip = self._packed_fold[li]
+            return ops.conv3d_k3_upfold(x, in1, w_up, w_skip, self._w[2 * li + 1], cout, x3=self.x3,
+                                        **{k: v for k, v in kw.items() if k not in ("in1", "up0")})
+        return ops.conv3d_k3(x, self._packed[li], self._w[2 * li + 1], cout, x3=self.x3, **kw)
 
     def unet(self, src, trg):
         """[B,X,Y,Z,1] x2 (f32) -> flow [B,X,Y,Z,3] f32."""

@@ -200,6 +200,70 @@ def conv3d_k3(in0, w_packed, bias, cout, in1=None, up0=False, leaky=True, alpha=
     return out
 
 
+def upfold_supported(C0, C1, cout, dtype, x3, B, X, Y, Z):
+    """Folded upsampling (include/mmr.h, mmr_conv3d_k3_upfold_*) serves a decoder layer conv(concat([up2(x), skip])) when
+    the element type is bf16 or fp32x3, the widths fit the MFMA slices and BOTH launches fill the chip on their own (the
+    1/8- and 1/16-resolution levels keep the one-launch split-K path).  X, Y, Z: full resolution of the layer."""
+    if not (dtype == torch.bfloat16 or (dtype == torch.float32 and x3 is True)):
+        return False
+    kc = conv_kc(dtype)
+    if C0 < kc or C0 % kc or C1 < kc or C1 % kc or cout < 64 or cout % 64 or (X | Y | Z) & 1:
+        return False
+    bn = 256 if cout % 256 == 0 else 128 if cout % 128 == 0 else 64
+    tx = 4 if bn == 256 else 8
+    tiles = lambda x, y, z: B * (-(-x // tx)) * (-(-y // 8)) * (-(-z // 8)) * (cout // bn)
+    return tiles(X // 2, Y // 2, Z // 2) * 8 >= 256 and tiles(X, Y, Z) >= 256
+
+
+def pack_upfold_weights(w_keras, C0, dtype, x3=False):
+    """Keras kernel [3,3,3,C0+C1,Cout] of a decoder layer -> (folded image of the C0 upsampled channels, plain image of the
+    C1 skip channels)."""
+    _chk(w_keras, torch.float32, "w_keras")
+    cin, cout = int(w_keras.shape[3]), int(w_keras.shape[4])
+    lib = _lib.load()
+    mode = conv_mode(dtype, x3)
+    nbytes = lib.mmr_conv3d_k3_upfold_packed_bytes(int(C0), cout, mode)
+    if nbytes < 0:
+        raise _lib.MmrError(f"cannot fold conv weights C0={C0} Cout={cout} for {dtype}")
+    w_up = w_keras[:, :, :, :C0, :].contiguous()
+    up = torch.empty(nbytes, dtype=torch.uint8, device=w_keras.device)
+    rc = lib.mmr_conv3d_k3_upfold_pack(w_up.data_ptr(), up.data_ptr(), int(C0), cout, mode, _stream())
+    _lib.check(rc, "mmr_conv3d_k3_upfold_pack")
+    skip = pack_conv_weights(w_keras[:, :, :, C0:, :].contiguous(), dtype, x3=x3)
+    return up, skip
+
+
+def conv3d_k3_upfold(in_low, skip, w_up, w_skip, bias, cout, leaky=True, alpha=0.2, out_f32=False, x3=False):
+    """Conv3D(cout,3,'same')(concat([UpSampling3D(2)(in_low), skip])) + bias (+LeakyReLU) as two launches: the upsampled half
+    on the low-resolution grid with folded weights (8 parity classes x 8 taps) into an fp32 partial tensor, then the skip
+    half with its accumulators started from that partial."""
+    dtype = in_low.dtype
+    _chk(in_low, dtype, "in_low")
+    _chk(skip, dtype, "skip")
+    B, X2, Y2, Z2, C0 = in_low.shape
+    X, Y, Z = 2 * X2, 2 * Y2, 2 * Z2
+    if tuple(skip.shape[:4]) != (B, X, Y, Z):
+        raise _lib.MmrError(f"skip shape {tuple(skip.shape)} does not match {(B, X, Y, Z)}")
+    C1 = skip.shape[4]
+    mode = conv_mode(dtype, x3)
+    odt = torch.float32 if (out_f32 or dtype == torch.float32) else torch.bfloat16
+    partial = torch.empty((B, X, Y, Z, cout), dtype=torch.float32, device=in_low.device)
+    out = torch.empty((B, X, Y, Z, cout), dtype=odt, device=in_low.device)
+    lib = _lib.load()
+    fam = f"conv3d_k3_mfma_{('f32', 'bf16', 'f32x3', 'f32x1')[mode]}_bn{256 if cout % 256 == 0 else 128 if cout % 128 == 0 else 64}"
+    # algorithmic flops = the plain 27-tap count of the layer's two halves (SURVEY 8d); the folded half executes 8/27 of it
+    with _Timed(fam + "_upfold", (C0, int(cout), X, Y, Z), 2.0 * 27 * C0 * cout * B * X * Y * Z):
+        rc = lib.mmr_conv3d_k3_upfold_fwd(in_low.data_ptr(), C0, w_up.data_ptr(), partial.data_ptr(), B, X2, Y2, Z2,
+                                          int(cout), mode, _stream())
+    _lib.check(rc, "mmr_conv3d_k3_upfold_fwd")
+    with _Timed(fam, (C1, int(cout), X, Y, Z), 2.0 * 27 * C1 * cout * B * X * Y * Z):
+        rc = lib.mmr_conv3d_k3_fwd_init(skip.data_ptr(), C1, w_skip.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                        partial.data_ptr(), out.data_ptr(), B, X, Y, Z, int(cout), int(leaky), float(alpha),
+                                        mode, int(out_f32), _stream())
+    _lib.check(rc, "mmr_conv3d_k3_fwd_init")
+    return out
+
+
 def conv3d_k3_dgrad_masked(dz, wt_packed, cin, ymask, dbias, alpha=0.2, accumulate=False, x3=False):
     """d(input) of a k3 conv, already multiplied by LeakyReLU'(ymask) of the layer that produced that input, whose
     bias gradient (column sums of the result) lands in ``dbias``: the dgrad + leaky_bwd_bias_ pair in one kernel."""
@@ -224,8 +288,6 @@ def conv3d_k3_dgrad_masked(dz, wt_packed, cin, ymask, dbias, alpha=0.2, accumula
 
 def dgrad_split_supported(C0, C1, x3):
     """The split-store dgrad runs on the 16x16x32 kernels only (fp32x3 / x1, 64-column tiles)."""
-    if os.environ.get("MMR_NO_DGRAD_SPLIT"):  # A/B runs
-        return False
     return bool(x3) and (C0 + C1) % 64 == 0 and C0 % 16 == 0 and C1 % 16 == 0
 
 

@@ -96,8 +96,13 @@ class SynthMorphTrainer:
                 tape.append(("conv", li, x, up0, in1, y, leaky))
                 li += 1
                 return y
-            y = ops.conv3d_k3(x, m._packed[li], w[2 * li + 1], m.pplan[li][2] if cout is None else cout, in1=in1,
-                              up0=up0, leaky=leaky, out_f32=True, x3=m.x3)
+            if up0 and in1 is not None and cout is None:
+                # decoder layers: folded upsampling where it applies (VxmDense._conv decides); the tape records the same
+                # (inputs, output) either way, so the backward does not care how the forward was computed
+                y = m._conv(li, x, in1=in1, up0=True, leaky=leaky, out_f32=True)
+            else:
+                y = ops.conv3d_k3(x, m._packed[li], w[2 * li + 1], m.pplan[li][2] if cout is None else cout, in1=in1,
+                                  up0=up0, leaky=leaky, out_f32=True, x3=m.x3)
             tape.append(("conv", li, x, up0, in1, y, leaky))
             li += 1
             return y

@@ -67,6 +67,60 @@ def test_conv_matches_oracle(dev, dtype, shape, C0, C1, up0, Cout):
     assert _scale_err(got, ref) < tol
 
 
+UPFOLD_CASES = [
+    # (full-res shape, C0 upsampled, C1 skip, Cout): every N tile (256 / 128 / 64), ragged low-res tiles, C0 != C1
+    ((8, 16, 16), 64, 64, 64),
+    ((8, 16, 32), 256, 256, 256),     # the dec_final_0 shape class of BASELINE configs[1]
+    ((12, 20, 28), 128, 64, 128),     # low-res 6x10x14: partial tiles on every axis
+    ((4, 4, 6), 64, 128, 64),         # volume smaller than one tile: every voxel on a zero-padded border
+]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32x3"])
+@pytest.mark.parametrize("shape,C0,C1,Cout", UPFOLD_CASES)
+def test_folded_upsampling_conv_matches_oracle(dev, dtype, shape, C0, C1, Cout):
+    """mmr_conv3d_k3_upfold_fwd + mmr_conv3d_k3_fwd_init against the C oracle of conv(concat([UpSampling3D(2)(x), skip]))
+    (upsampled channels first).  The folded half sums up to 8 weights before the bf16 / hi-lo
+    encoding, so bf16 is compared with the oracle on bf16-rounded inputs and UNROUNDED weights at the bf16 bound; fp32x3
+    at north_star's 1e-4.  Also: the partial tensor alone equals the oracle conv over the upsampled channels only."""
+    import mmr
+    from oracle.cbind import conv3d_same
+    from oracle.net_np import bf16_round
+    from oracle import ops_np as O
+    rng = np.random.default_rng(hash((shape, C0, C1, Cout)) % 2 ** 31)
+    X, Y, Z = shape
+    B = 2 if np.prod(shape) < 600 else 1
+    a0 = rng.standard_normal((B, X // 2, Y // 2, Z // 2, C0)).astype(np.float32)
+    a1 = rng.standard_normal((B, X, Y, Z, C1)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, C0 + C1, Cout)) * np.sqrt(2.0 / (27 * (C0 + C1)))).astype(np.float32)
+    bias = (rng.standard_normal(Cout) * 0.1).astype(np.float32)
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    x3 = dtype == "fp32x3"
+    if dtype == "bf16":
+        a0, a1 = bf16_round(a0), bf16_round(a1)
+    ref = conv3d_same(np.concatenate([O.upsample2(a0), a1], -1), w, bias, leaky=True, alpha=0.2)
+    ref_up = conv3d_same(O.upsample2(a0), np.ascontiguousarray(w[:, :, :, :C0]), None, leaky=False)
+    wd = torch.from_numpy(w).to(dev)
+    w_up, w_skip = mmr.ops.pack_upfold_weights(wd, C0, tdt, x3=x3)
+    t0, t1 = torch.from_numpy(a0).to(dev).to(tdt), torch.from_numpy(a1).to(dev).to(tdt)
+    got = mmr.ops.conv3d_k3_upfold(t0, t1, w_up, w_skip, torch.from_numpy(bias).to(dev), Cout, x3=x3).float().cpu().numpy()
+    tol = 1e-4 if x3 else 6e-3
+    err = _scale_err(got, ref)
+    print(f"folded upsampling [{dtype}] {shape} {C0}+{C1}->{Cout}: rel-to-scale error {err:.2e}")
+    assert got.shape == ref.shape and err < tol
+    # the partial tensor on its own (launch A): NaN-poisoned first, so that an unwritten element would show
+    lib = mmr._lib.load()
+    part = torch.full((B, X, Y, Z, Cout), float("nan"), dtype=torch.float32, device=dev)
+    rc = lib.mmr_conv3d_k3_upfold_fwd(t0.data_ptr(), C0, w_up.data_ptr(), part.data_ptr(), B, X // 2, Y // 2, Z // 2, Cout,
+                                      mmr.ops.conv_mode(tdt, x3), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert _scale_err(part.cpu().numpy(), ref_up) < (1e-4 if x3 else 4e-3)
+    # and the one-launch path of the same layer agrees with the folded pair to the arithmetic's accuracy
+    plain = mmr.ops.conv3d_k3(t0, mmr.ops.pack_conv_weights(wd, tdt, x3=x3), torch.from_numpy(bias).to(dev), Cout, in1=t1,
+                              up0=True, x3=x3).float().cpu().numpy()
+    assert _scale_err(got, plain) < (2e-5 if x3 else 1.2e-2)
+
+
 @pytest.mark.parametrize("shape,Cout,odt", [((8, 8, 16), 64, "fp32"), ((5, 6, 19), 256, "fp32"), ((8, 8, 16), 256, "bf16"),
                                             ((5, 9, 7), 64, "bf16"), ((8, 8, 16), 64, "fp32x3"), ((5, 6, 19), 256, "fp32x3"),
                                             ((4, 8, 8), 32, "fp32x3")])
