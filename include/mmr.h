@@ -117,17 +117,20 @@ int mmr_conv3d_k3_fwd_ws(const void* in0, int C0, int up0, const void* in1, int 
  *   mmr_conv3d_k3_upfold_pack: w_up_keras [27][C0][Cout] fp32 (the first C0 input channels of the layer's Keras
  *       kernel, contiguous) -> folded MFMA operand image of mmr_conv3d_k3_upfold_packed_bytes() bytes;
  *   mmr_conv3d_k3_upfold_fwd:  in_low [B,X2,Y2,Z2,C0] (bf16 for MMR_DT_BF16, fp32 for MMR_DT_F32X3) ->
- *       partial [B,2*X2,2*Y2,2*Z2,Cout] fp32 (raw sums, no bias; every element written);
- *   mmr_conv3d_k3_fwd_init:    out = act(cinit + conv3x3x3(in) + bias) over the skip channels, cinit = that partial.
+ *       partial [B,2*X2,2*Y2,2*Z2,Cout] (raw sums, no bias; every element written) in fp32, or -- partial_half != 0,
+ *       MMR_DT_BF16 only -- in IEEE half saturated to +-65504 (its 2^-12 rounding is below the layer's bf16 output
+ *       rounding; halves the round trip of the partial tensor through HBM);
+ *   mmr_conv3d_k3_fwd_init:    out = act(cinit + conv3x3x3(in) + bias) over the skip channels, cinit = that partial
+ *       (cinit_half says which of the two formats it holds).
  * The pair equals mmr_conv3d_k3_fwd(in_low, C0, up0 = 1, skip, C1, ...) up to the summation order of the weights.
  * bf16 / fp32x3 only, C0 a multiple of the channel slice (64 / 32), Cout a multiple of 64; else MMR_EUNSUPPORTED /
  * MMR_EINVAL. */
 int64_t mmr_conv3d_k3_upfold_packed_bytes(int C0, int Cout, int dtype);
 int mmr_conv3d_k3_upfold_pack(const float* w_up_keras, void* w_packed, int C0, int Cout, int dtype, void* stream);
-int mmr_conv3d_k3_upfold_fwd(const void* in_low, int C0, const void* w_packed, float* partial,
+int mmr_conv3d_k3_upfold_fwd(const void* in_low, int C0, const void* w_packed, void* partial, int partial_half,
                              int B, int X2, int Y2, int Z2, int Cout, int dtype, void* stream);
-int mmr_conv3d_k3_fwd_init(const void* in, int Cin, const void* w_packed, const float* bias, const float* cinit,
-                           void* out, int B, int X, int Y, int Z, int Cout,
+int mmr_conv3d_k3_fwd_init(const void* in, int Cin, const void* w_packed, const float* bias, const void* cinit,
+                           int cinit_half, void* out, int B, int X, int Y, int Z, int Cout,
                            int leaky, float alpha, int dtype, int out_f32, void* stream);
 /* First layer: concatenate([moving, fixed]) (2 x 1 channel, fp32) -> Cout.  pool_out (optional, same element type as
  * out, [B,X/2,Y/2,Z/2,Cout]): MaxPooling3D(2) of the activated output from the same kernel (bf16 and fp32x3 kernels;

@@ -99,6 +99,12 @@ constexpr int CV_PRIO_Y = 1 << 15;  // static s_setprio 1 for waves 4-7
 // dec_final_0 of BASELINE configs[1] (512 -> 256 at 160x160x192): 17.4 -> 11.3 TMAC.
 constexpr int CV_UPFOLD = 1 << 16;
 constexpr int CV_CINIT = 1 << 17;
+// The partial tensor between the two launches as IEEE half (saturated to +-65504) instead of fp32 -- bf16 layers only: the
+// partial's 2^-12 relative rounding disappears under the 2^-9 of the layer's bf16 output, and the 10 GB round trip of
+// dec_final_0 at 160x160x192 x 256 (written by one launch, read by the next, neither overlapped with MFMA work at one
+// workgroup per CU) halves.  fp32x3 layers keep the fp32 partial.
+constexpr int CV_PART16 = 1 << 18;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 #ifdef MMR_DIAG
 int g_diag_stamps = 0;   // host switch of the stamped instantiations (conv and wgrad), set by mmr_debug_set_stamps
@@ -218,6 +224,7 @@ conv3d_k3_kernel(const ConvParams p)
     constexpr bool PRIO_Y = (VAR & CV_PRIO_Y) != 0;
     constexpr bool UPF = (VAR & CV_UPFOLD) != 0;
     constexpr bool CINIT = (VAR & CV_CINIT) != 0;
+    constexpr bool PART16 = (VAR & CV_PART16) != 0;
     constexpr int TAPS = UPF ? 8 : 27;
     static_assert(!(UPF || CINIT) || (((VAR & CV_M16) != 0) && DT != MMR_DT_F32 && NT == 2), "folded upsampling: 16x16x32 kernels");
 #ifdef MMR_DIAG
@@ -291,16 +298,48 @@ conv3d_k3_kernel(const ConvParams p)
 #pragma unroll
         for (int ni = 0; ni < 2 * NT; ++ni) b16_off[ni] = (q16 * BN + wn * NT * 32 + ni * 16 + r16) * 16;
         if constexpr (CINIT) {
-            // accumulator (mi, ni)[r] <-> cout co + ni * 4 + r of voxel (mi, r16): the epilogue's layout, read the same way
+            // accumulator (mi, ni)[r] <-> cout co + ni * 4 + r of voxel (mi, r16): the epilogue's layout, read the same way.
+            // Branch-free: every lane loads from a clamped, always-valid address and out-of-tile values are zeroed afterwards
+            // -- behind `if (voxel in volume)` hipcc waits for each tile's loads before it issues the next tile's (eight
+            // dependent round trips per workgroup: 14 us of a 168-us tile, +9 % on the 256 -> 256 layer at 160x160x192;
+            // branch-free +5.7 %).  Adding the partial in the EPILOGUE instead (all loads in flight at its top) measured
+            // slower still, 12.87 vs 12.23 ms for that layer: the prologue's loads at least share the wait for the A tile.
             const int co = ntile * BN + wn * 64 + q16 * 16;
+            const int cco = co + 15 < p.Cout ? co : 0;
+            bool okv[2 * MT];
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            u32x4 raw16[2 * MT][2];
 #pragma unroll
             for (int mi = 0; mi < 2 * MT; ++mi) {
                 const int mt = wm * MT + (mi >> 1);
                 const int gx = x0 + (mt >> 1), gy = y0 + (mt & 1) * 4 + 2 * (mi & 1) + (r16 >> 3), gz = z0 + (r16 & 7);
-                if (co + 15 < p.Cout && gx < p.X && gy < p.Y && gz < p.Z) {
-                    const float* ci = p.cinit + ((((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz) * p.Cout + co;
+                okv[mi] = co + 15 < p.Cout && gx < p.X && gy < p.Y && gz < p.Z;
+                const int cx = gx < p.X ? gx : p.X - 1, cy = gy < p.Y ? gy : p.Y - 1, cz = gz < p.Z ? gz : p.Z - 1;
+                const size_t o = ((((size_t)b * p.X + cx) * p.Y + cy) * p.Z + cz) * p.Cout + cco;
+                if constexpr (PART16) {
+                    const _Float16* ci = reinterpret_cast<const _Float16*>(p.cinit) + o;
+                    raw16[mi][0] = *reinterpret_cast<const u32x4*>(ci);
+                    raw16[mi][1] = *reinterpret_cast<const u32x4*>(ci + 8);
+                } else {
+                    const float* ci = p.cinit + o;
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni) acc16[mi][ni] = *reinterpret_cast<const f32x4*>(ci + ni * 4);
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2 * MT; ++mi) {
+                if constexpr (PART16) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const f16x8 hv = __builtin_bit_cast(f16x8, raw16[mi][k]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc16[mi][2 * k + (e >> 2)][e & 3] = okv[mi] ? (float)hv[e] : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc16[mi][ni][r] = okv[mi] ? acc16[mi][ni][r] : 0.f;
                 }
             }
         }
@@ -781,12 +820,24 @@ conv3d_k3_kernel(const ConvParams p)
                 const int mt = wm * MT + (mi >> 1);
                 const int lx = x0 + (mt >> 1), ly = y0 + (mt & 1) * 4 + 2 * (mi & 1) + (r16 >> 3), lz = z0 + (r16 & 7);
                 if (co + 15 < p.Cout && lx < p.X && ly < p.Y && lz < p.Z) {
-                    float* po = reinterpret_cast<float*>(p.out) +
-                                ((((size_t)b * (2 * p.X) + 2 * lx + px) * (2 * p.Y) + 2 * ly + py) * (2 * p.Z) + 2 * lz + pz) * p.Cout + co;
+                    const size_t o = ((((size_t)b * (2 * p.X) + 2 * lx + px) * (2 * p.Y) + 2 * ly + py) * (2 * p.Z) + 2 * lz + pz) * p.Cout + co;
+                    if constexpr (PART16) {
+                        _Float16* po = reinterpret_cast<_Float16*>(p.out) + o;
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
-                        *reinterpret_cast<float4*>(po + ni * 4) =
-                            make_float4(acc16[mi][ni][0], acc16[mi][ni][1], acc16[mi][ni][2], acc16[mi][ni][3]);
+                        for (int k = 0; k < 2; ++k) {
+                            f16x8 hv;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                hv[e] = (_Float16)fminf(fmaxf(acc16[mi][2 * k + (e >> 2)][e & 3], -65504.f), 65504.f);
+                            *reinterpret_cast<f16x8*>(po + 8 * k) = hv;
+                        }
+                    } else {
+                        float* po = reinterpret_cast<float*>(p.out) + o;
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+                            *reinterpret_cast<float4*>(po + ni * 4) =
+                                make_float4(acc16[mi][ni][0], acc16[mi][ni][1], acc16[mi][ni][2], acc16[mi][ni][3]);
+                    }
                 }
             }
             return;
@@ -1154,6 +1205,7 @@ int dispatch_conv_fold(const ConvParams& p, hipStream_t st)
     const int BN = conv_bn(p.Cout);
     const int nt = (p.Cout + BN - 1) / BN;
     constexpr bool F32T = (DT == MMR_DT_F32X3);
+    static_assert(!((EXTRA & CV_PART16) != 0 && F32T), "half partial: bf16 layers only");
     constexpr int V_FULL = CV_M16 | CV_PIPE | CV_DMA_A;
     switch (BN) {
         case 256: return launch_conv<DT, 2, 4, 4, 2, V_FULL | (F32T ? CV_BATCHA : 0) | EXTRA>(p, nt, st, nullptr);
@@ -2040,11 +2092,13 @@ extern "C" int mmr_conv3d_k3_upfold_pack(const float* w_up_keras, void* w_packed
     return check_launch();
 }
 
-// partial [B,2X2,2Y2,2Z2,Cout] fp32 = conv3x3x3(UpSampling3D(2)(in_low)) restricted to the C0 upsampled channels, no bias.
+// partial [B,2X2,2Y2,2Z2,Cout] = conv3x3x3(UpSampling3D(2)(in_low)) restricted to the C0 upsampled channels, no bias.
 // in_low [B,X2,Y2,Z2,C0] bf16 (MMR_DT_BF16) or fp32 (MMR_DT_F32X3).  Every element of `partial` is written.
-extern "C" int mmr_conv3d_k3_upfold_fwd(const void* in_low, int C0, const void* w_packed, float* partial, int B, int X2,
-                                        int Y2, int Z2, int Cout, int dtype, void* stream)
+// partial_half != 0 (MMR_DT_BF16 only): `partial` holds IEEE half values saturated to +-65504 instead of fp32.
+extern "C" int mmr_conv3d_k3_upfold_fwd(const void* in_low, int C0, const void* w_packed, void* partial, int partial_half,
+                                        int B, int X2, int Y2, int Z2, int Cout, int dtype, void* stream)
 {
+    if (partial_half && dtype != MMR_DT_BF16) return MMR_EUNSUPPORTED;
     if (!in_low || !w_packed || !partial || B < 1 || X2 < 1 || Y2 < 1 || Z2 < 1) return MMR_EINVAL;
     if (mmr_conv3d_k3_upfold_packed_bytes(C0, Cout, dtype) < 0) return (int)mmr_conv3d_k3_upfold_packed_bytes(C0, Cout, dtype);
     ConvParams p;
@@ -2054,16 +2108,18 @@ extern "C" int mmr_conv3d_k3_upfold_fwd(const void* in_low, int C0, const void* 
     p.leaky = 0; p.alpha = 0.f; p.out_f32 = 1; p.ymask = nullptr; p.part = nullptr;
     p.kpart = nullptr; p.gsplit = 0; p.out1 = nullptr; p.csplit = 0;
     p.ntx = (X2 + TX - 1) / TX; p.nty = (Y2 + TY - 1) / TY; p.ntz = (Z2 + TZ - 1) / TZ;
+    if (dtype == MMR_DT_BF16 && partial_half) return dispatch_conv_fold<MMR_DT_BF16, CV_UPFOLD | CV_PART16>(p, as_stream(stream));
     if (dtype == MMR_DT_BF16) return dispatch_conv_fold<MMR_DT_BF16, CV_UPFOLD>(p, as_stream(stream));
     return dispatch_conv_fold<MMR_DT_F32X3, CV_UPFOLD>(p, as_stream(stream));
 }
 
 // out = act(cinit + conv3x3x3(in) + bias): the skip half of a folded layer (cinit = mmr_conv3d_k3_upfold_fwd's partial),
 // otherwise mmr_conv3d_k3_fwd without the concat / split-K options.
-extern "C" int mmr_conv3d_k3_fwd_init(const void* in, int Cin, const void* w_packed, const float* bias, const float* cinit,
-                                      void* out, int B, int X, int Y, int Z, int Cout, int leaky, float alpha, int dtype,
-                                      int out_f32, void* stream)
+extern "C" int mmr_conv3d_k3_fwd_init(const void* in, int Cin, const void* w_packed, const float* bias, const void* cinit,
+                                      int cinit_half, void* out, int B, int X, int Y, int Z, int Cout, int leaky, float alpha,
+                                      int dtype, int out_f32, void* stream)
 {
+    if (cinit_half && dtype != MMR_DT_BF16) return MMR_EUNSUPPORTED;
     if (!in || !w_packed || !out || !cinit || B < 1 || X < 1 || Y < 1 || Z < 1) return MMR_EINVAL;
     if (dtype != MMR_DT_BF16 && dtype != MMR_DT_F32X3) return MMR_EUNSUPPORTED;
     const int kc = (dtype == MMR_DT_BF16) ? 64 : 32;
@@ -2073,8 +2129,9 @@ extern "C" int mmr_conv3d_k3_fwd_init(const void* in, int Cin, const void* w_pac
     p.out = (char*)out;
     p.B = B; p.X = X; p.Y = Y; p.Z = Z; p.C0 = Cin; p.C1 = 0; p.up0 = 0; p.Cout = Cout;
     p.leaky = leaky; p.alpha = alpha; p.out_f32 = out_f32; p.ymask = nullptr; p.part = nullptr;
-    p.kpart = nullptr; p.gsplit = 0; p.out1 = nullptr; p.csplit = 0; p.cinit = cinit;
+    p.kpart = nullptr; p.gsplit = 0; p.out1 = nullptr; p.csplit = 0; p.cinit = (const float*)cinit;
     p.ntx = (X + TX - 1) / TX; p.nty = (Y + TY - 1) / TY; p.ntz = (Z + TZ - 1) / TZ;
+    if (dtype == MMR_DT_BF16 && cinit_half) return dispatch_conv_fold<MMR_DT_BF16, CV_CINIT | CV_PART16>(p, as_stream(stream));
     if (dtype == MMR_DT_BF16) return dispatch_conv_fold<MMR_DT_BF16, CV_CINIT>(p, as_stream(stream));
     return dispatch_conv_fold<MMR_DT_F32X3, CV_CINIT>(p, as_stream(stream));
 }

@@ -233,7 +233,7 @@ def pack_upfold_weights(w_keras, C0, dtype, x3=False):
     return up, skip
 
 
-def conv3d_k3_upfold(in_low, skip, w_up, w_skip, bias, cout, leaky=True, alpha=0.2, out_f32=False, x3=False):
+def conv3d_k3_upfold(in_low, skip, w_up, w_skip, bias, cout, leaky=True, alpha=0.2, out_f32=False, x3=False, half_partial=None):
     """Conv3D(cout,3,'same')(concat([UpSampling3D(2)(in_low), skip])) + bias (+LeakyReLU) as two launches: the upsampled half
     on the low-resolution grid with folded weights (8 parity classes x 8 taps) into an fp32 partial tensor, then the skip
     half with its accumulators started from that partial."""
@@ -247,19 +247,21 @@ def conv3d_k3_upfold(in_low, skip, w_up, w_skip, bias, cout, leaky=True, alpha=0
     C1 = skip.shape[4]
     mode = conv_mode(dtype, x3)
     odt = torch.float32 if (out_f32 or dtype == torch.float32) else torch.bfloat16
-    partial = torch.empty((B, X, Y, Z, cout), dtype=torch.float32, device=in_low.device)
+    # the tensor between the two launches: IEEE half for bf16 layers (include/mmr.h), fp32 for fp32x3 layers
+    half = (dtype == torch.bfloat16) if half_partial is None else bool(half_partial)
+    partial = torch.empty((B, X, Y, Z, cout), dtype=torch.float16 if half else torch.float32, device=in_low.device)
     out = torch.empty((B, X, Y, Z, cout), dtype=odt, device=in_low.device)
     lib = _lib.load()
     fam = f"conv3d_k3_mfma_{('f32', 'bf16', 'f32x3', 'f32x1')[mode]}_bn{256 if cout % 256 == 0 else 128 if cout % 128 == 0 else 64}"
     # algorithmic flops = the plain 27-tap count of the layer's two halves; the folded half executes 8/27 of it
     with _Timed(fam + "_upfold", (C0, int(cout), X, Y, Z), 2.0 * 27 * C0 * cout * B * X * Y * Z):
-        rc = lib.mmr_conv3d_k3_upfold_fwd(in_low.data_ptr(), C0, w_up.data_ptr(), partial.data_ptr(), B, X2, Y2, Z2,
+        rc = lib.mmr_conv3d_k3_upfold_fwd(in_low.data_ptr(), C0, w_up.data_ptr(), partial.data_ptr(), int(half), B, X2, Y2, Z2,
                                           int(cout), mode, _stream())
     _lib.check(rc, "mmr_conv3d_k3_upfold_fwd")
-    with _Timed(fam, (C1, int(cout), X, Y, Z), 2.0 * 27 * C1 * cout * B * X * Y * Z):
+    with _Timed(fam + "_cinit", (C1, int(cout), X, Y, Z), 2.0 * 27 * C1 * cout * B * X * Y * Z):
         rc = lib.mmr_conv3d_k3_fwd_init(skip.data_ptr(), C1, w_skip.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                        partial.data_ptr(), out.data_ptr(), B, X, Y, Z, int(cout), int(leaky), float(alpha),
-                                        mode, int(out_f32), _stream())
+                                        partial.data_ptr(), int(half), out.data_ptr(), B, X, Y, Z, int(cout), int(leaky),
+                                        float(alpha), mode, int(out_f32), _stream())
     _lib.check(rc, "mmr_conv3d_k3_fwd_init")
     return out
 

@@ -112,25 +112,36 @@ def round_(tag):
         b = os.path.join(root, "gpurun_out", f"{tag}_bench_{name}.json")
         if os.path.exists(b):
             shutil.copy(b, os.path.join(here, f"{tag}_bench_{name}.json"))
-    # the files bench.py reads `roofline.traffic` from: dominant kernel family -> measured HBM bytes per launch
-    fam = {"infer": ("conv3d_k3_mfma_bf16_bn256", "conv3d_k3_kernel<1, 2, 4, 4, 2"),
-           "train": ("conv3d_k3_mfma_f32x3_bn64", "conv3d_k3_kernel<2, 8, 1, 2, 2"),
-           "ncc": (None, "ncc_fused")}   # family = the kernel that ran (ncc_fused4_kernel / ncc_fused_kernel)
-    for wl, (family, sub) in fam.items():
+    # the files bench.py reads `roofline.traffic` from: kernel family (bench.py / ops.py names) -> measured HBM bytes per launch
+    for wl in ("infer", "train", "ncc"):
         pj = os.path.join(here, f"{tag}_{wl}_pmc_traffic.json")
         if not os.path.exists(pj):
             continue
         d = json.load(open(pj))
-        hit = [(k, v) for k, v in d.items() if sub in k]
-        if hit:
-            k, v = max(hit, key=lambda kv: kv[1]["launches"])
-            if family is None:
-                family = k.replace("mmr::", "").split("(")[0]
-            json.dump({family: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "kernel": k, "launches": v["launches"],
-                                "git": head, "source": f"profiles/{tag}_{wl}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
-                                "--pmc WRITE_SIZE in separate passes via tools/profile_round.sh; (2*FETCH + WRITE) KiB per "
-                                "launch, fetch doubled per the gfx950 correction)"}},
-                      open(os.path.join(here, f"traffic_{wl}.json"), "w"), indent=1)
+        out = {}
+        for k, v in d.items():
+            fam = family_of(k)
+            if fam and (fam not in out or v["launches"] > out[fam]["launches"]):
+                out[fam] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "kernel": k, "launches": v["launches"], "git": head,
+                            "source": f"profiles/{tag}_{wl}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in "
+                                      "separate passes via tools/profile_round.sh; (2*FETCH + WRITE) KiB per launch, fetch "
+                                      "doubled per the gfx950 correction)"}
+        json.dump(out, open(os.path.join(here, f"traffic_{wl}.json"), "w"), indent=1)
+
+
+def family_of(kernel_name):
+    """rocprof kernel name -> the family name ops.py times it under (None for kernels bench.py has no roofline for)."""
+    import re
+    k = kernel_name.replace("mmr::", "")
+    m = re.search(r"conv3d_k3_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", k)
+    if m:
+        dt, wm, wn, mt, nt, var = map(int, m.groups())
+        fam = f"conv3d_k3_mfma_{('f32', 'bf16', 'f32x3', 'f32x1')[dt]}_bn{wn * nt * 32}"
+        return fam + ("_upfold" if var & (1 << 16) else "_cinit" if var & (1 << 17) else "")
+    for name in ("ncc_fused4_kernel", "ncc_fused_kernel", "bending_fused_kernel"):
+        if name in k:
+            return name
+    return None
 
 
 if __name__ == "__main__":

@@ -110,11 +110,16 @@ def test_folded_upsampling_conv_matches_oracle(dev, dtype, shape, C0, C1, Cout):
     assert got.shape == ref.shape and err < tol
     # the partial tensor on its own (launch A): NaN-poisoned first, so that an unwritten element would show
     lib = mmr._lib.load()
-    part = torch.full((B, X, Y, Z, Cout), float("nan"), dtype=torch.float32, device=dev)
-    rc = lib.mmr_conv3d_k3_upfold_fwd(t0.data_ptr(), C0, w_up.data_ptr(), part.data_ptr(), B, X // 2, Y // 2, Z // 2, Cout,
-                                      mmr.ops.conv_mode(tdt, x3), torch.cuda.current_stream().cuda_stream)
-    assert rc == 0
-    assert _scale_err(part.cpu().numpy(), ref_up) < (1e-4 if x3 else 4e-3)
+    for half in ((False, True) if dtype == "bf16" else (False,)):
+        part = torch.full((B, X, Y, Z, Cout), float("nan"), dtype=torch.float16 if half else torch.float32, device=dev)
+        rc = lib.mmr_conv3d_k3_upfold_fwd(t0.data_ptr(), C0, w_up.data_ptr(), part.data_ptr(), int(half), B, X // 2, Y // 2,
+                                          Z // 2, Cout, mmr.ops.conv_mode(tdt, x3), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        assert _scale_err(part.float().cpu().numpy(), ref_up) < (1e-4 if x3 else 4e-3)
+    if dtype == "bf16":   # fp32 partial between the launches: same result up to the half rounding of the partial
+        got32 = mmr.ops.conv3d_k3_upfold(t0, t1, w_up, w_skip, torch.from_numpy(bias).to(dev), Cout, x3=x3,
+                                         half_partial=False).float().cpu().numpy()
+        assert _scale_err(got32, ref) < tol and _scale_err(got, got32) < 8e-3
     # and the one-launch path of the same layer agrees with the folded pair to the arithmetic's accuracy
     plain = mmr.ops.conv3d_k3(t0, mmr.ops.pack_conv_weights(wd, tdt, x3=x3), torch.from_numpy(bias).to(dev), Cout, in1=t1,
                               up0=True, x3=x3).float().cpu().numpy()
