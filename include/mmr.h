@@ -132,6 +132,17 @@ int mmr_conv3d_k3_upfold_fwd(const void* in_low, int C0, const void* w_packed, v
 int mmr_conv3d_k3_fwd_init(const void* in, int Cin, const void* w_packed, const float* bias, const void* cinit,
                            int cinit_half, void* out, int B, int X, int Y, int Z, int Cout,
                            int leaky, float alpha, int dtype, int out_f32, void* stream);
+/* Data gradient of the folded half w.r.t. the low-resolution input (training; fp32x3 / x1): replaces the upsampled-channel
+ * half of mmr_conv3d_k3_dgrad_split plus the 2x2x2 pooling of mmr_upcat_bwd_masked_f32 -- 64 tap-steps per low-res voxel
+ * instead of 216, no full-resolution intermediate.  dz [B,2*X2,2*Y2,2*Z2,Cz] fp32 -> out [B,X2,Y2,Z2,C0] fp32;
+ * w_up_keras [27][C0][Cz] = the first C0 input channels of the layer's FORWARD Keras kernel.  ymask != NULL: out is
+ * multiplied by LeakyReLU'(ymask) and dbias (+)= its column sums (ws of mmr_conv3d_k3_dgrad_upfold_ws_bytes). */
+int64_t mmr_conv3d_k3_dgrad_upfold_packed_bytes(int Cz, int C0, int dtype);
+int mmr_conv3d_k3_dgrad_upfold_pack(const float* w_up_keras, void* w_packed, int C0, int Cz, int dtype, void* stream);
+int64_t mmr_conv3d_k3_dgrad_upfold_ws_bytes(int B, int X2, int Y2, int Z2, int C0);
+int mmr_conv3d_k3_dgrad_upfold(const void* dz, int Cz, const void* w_packed, float* out, int B, int X2, int Y2, int Z2,
+                               int C0, const float* ymask, float alpha, float* dbias, void* ws, int accumulate,
+                               int dtype, void* stream);
 /* First layer: concatenate([moving, fixed]) (2 x 1 channel, fp32) -> Cout.  pool_out (optional, same element type as
  * out, [B,X/2,Y/2,Z/2,Cout]): MaxPooling3D(2) of the activated output from the same kernel (bf16 and fp32x3 kernels;
  * MMR_EUNSUPPORTED with the exact-fp32 kernel).  Saves the 2.5 GB read of a separate pooling pass at C2.        */

@@ -35,6 +35,10 @@ SIGNATURES = {
     "mmr_conv3d_k3_upfold_pack": (I, [P, P, I, I, I, P]),
     "mmr_conv3d_k3_upfold_fwd": (I, [P, I, P, P, I, I, I, I, I, I, I, P]),
     "mmr_conv3d_k3_fwd_init": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, F, I, I, P]),
+    "mmr_conv3d_k3_dgrad_upfold_packed_bytes": (c_int64, [I, I, I]),
+    "mmr_conv3d_k3_dgrad_upfold_pack": (I, [P, P, I, I, I, P]),
+    "mmr_conv3d_k3_dgrad_upfold_ws_bytes": (c_int64, [I, I, I, I, I]),
+    "mmr_conv3d_k3_dgrad_upfold": (I, [P, I, P, P, I, I, I, I, I, P, F, P, P, I, I, P]),
     "mmr_conv3d_k3_cin2_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, F, I, P]),
     "mmr_conv3d_k3_cout3_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "mmr_maxpool3d2_fwd": (I, [P, P, I, I, I, I, I, I, P]),

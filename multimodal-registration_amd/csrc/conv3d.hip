@@ -105,6 +105,13 @@ constexpr int CV_CINIT = 1 << 17;
 // workgroup per CU) halves.  fp32x3 layers keep the fp32 partial.
 constexpr int CV_PART16 = 1 << 18;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+// The data gradient of the folded half (training): d x[j] = sum over parity classes p and tap bits s of
+// Wf[p][s]^T dz[2 (j + 1 - p - s) + p] (per axis) -- again an 8-tap convolution per class on the low-resolution grid, now
+// gathering from the class's sub-lattice of the full-resolution dz and summing all 8 classes into ONE accumulator: the
+// K walk is (class, dz-channel slice) -> 8 taps, halo offset 2 - p - s.  64 tap-steps per low-res voxel instead of 216,
+// the gradient lands compact at low resolution (no full-resolution intermediate, no 2x2x2 pooling pass), and the masked
+// epilogue (LeakyReLU backward + bias sums of the layer that produced x) applies unchanged.  fp32x3 / x1 tensors only.
+constexpr int CV_DGFOLD = 1 << 19;
 
 #ifdef MMR_DIAG
 int g_diag_stamps = 0;   // host switch of the stamped instantiations (conv and wgrad), set by mmr_debug_set_stamps
@@ -225,7 +232,10 @@ conv3d_k3_kernel(const ConvParams p)
     constexpr bool UPF = (VAR & CV_UPFOLD) != 0;
     constexpr bool CINIT = (VAR & CV_CINIT) != 0;
     constexpr bool PART16 = (VAR & CV_PART16) != 0;
-    constexpr int TAPS = UPF ? 8 : 27;
+    constexpr bool DGF = (VAR & CV_DGFOLD) != 0;
+    static_assert(!DGF || (!UPF && !CINIT && ((VAR & CV_M16) != 0) && ((VAR & CV_BATCHA) != 0) &&
+                           (DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1)), "dgrad fold: fp32x3 / x1, batched staging");
+    constexpr int TAPS = (UPF || ((VAR & CV_DGFOLD) != 0)) ? 8 : 27;
     static_assert(!(UPF || CINIT) || (((VAR & CV_M16) != 0) && DT != MMR_DT_F32 && NT == 2), "folded upsampling: 16x16x32 kernels");
 #ifdef MMR_DIAG
     constexpr bool STAMP = (VAR & CV_STAMP) != 0;
@@ -345,7 +355,8 @@ conv3d_k3_kernel(const ConvParams p)
         }
     }
 
-    const int nslices = (p.C0 + p.C1) / KC;
+    const int ncs = (p.C0 + p.C1) / KC;              // channel slices of the input
+    const int nslices = DGF ? 8 * ncs : ncs;         // dgrad fold: (parity class, dz-channel slice) pairs
     const int G = nslices * TAPS;
     const char* wtile = p.wp + (size_t)blockIdx.y * G * B_BYTES;   // UPF: [class][n-tile], else [n-tile]
     const int X2 = p.X >> 1, Y2 = p.Y >> 1, Z2 = p.Z >> 1;
@@ -389,7 +400,8 @@ conv3d_k3_kernel(const ConvParams p)
     auto load_a_nb = [&](int s, int it) -> AItemM {
         const int i0 = tid + it * CONV_THREADS;
         const int i = i0 < A_ITEMS ? i0 : A_ITEMS - 1;
-        const int ch0 = s * KC;
+        const int scls = DGF ? s / ncs : 0;                     // dgrad fold: parity class of this K block
+        const int ch0 = (DGF ? s - scls * ncs : s) * KC;
         const bool first = ch0 < p.C0;
         const char* src = first ? p.in0 : p.in1;
         const int Cs = first ? p.C0 : p.C1;
@@ -403,7 +415,10 @@ conv3d_k3_kernel(const ConvParams p)
         const int cx = gx < 0 ? 0 : (gx >= pX ? pX - 1 : gx), cy = gy < 0 ? 0 : (gy >= pY ? pY - 1 : gy),
                   cz = gz < 0 ? 0 : (gz >= pZ ? pZ - 1 : gz);
         size_t vox;
-        if (up) vox = (((size_t)b * X2 + (cx >> 1)) * Y2 + (cy >> 1)) * Z2 + (cz >> 1);
+        if constexpr (DGF)   // row = low-res voxel i of the class's sub-lattice of the full-resolution tensor: voxel 2 i + p
+            vox = (((size_t)b * (2 * pX) + 2 * cx + ((scls >> 2) & 1)) * (2 * pY) + 2 * cy + ((scls >> 1) & 1)) * (2 * pZ) +
+                  2 * cz + (scls & 1);
+        else if (up) vox = (((size_t)b * X2 + (cx >> 1)) * Y2 + (cy >> 1)) * Z2 + (cz >> 1);
         else vox = (((size_t)b * pX + cx) * pY + cy) * pZ + cz;
         const char* q = src + (vox * Cs + chs) * ES + chunk * 32;
         AItemM val;
@@ -553,9 +568,10 @@ conv3d_k3_kernel(const ConvParams p)
         }
         MMR_STAMP(0);
         // halo offset of this tap; folded upsampling: parity bit + tap bit per axis
-        const int dx = UPF ? ((cls >> 2) & 1) + ((tap >> 2) & 1) : tap / 9;
-        const int dy = UPF ? ((cls >> 1) & 1) + ((tap >> 1) & 1) : (tap / 3) % 3;
-        const int dz = UPF ? (cls & 1) + (tap & 1) : tap % 3;
+        const int kcls = DGF ? s / ncs : cls;     // dgrad fold: the class changes with the K block
+        const int dx = UPF ? ((cls >> 2) & 1) + ((tap >> 2) & 1) : DGF ? 2 - ((kcls >> 2) & 1) - ((tap >> 2) & 1) : tap / 9;
+        const int dy = UPF ? ((cls >> 1) & 1) + ((tap >> 1) & 1) : DGF ? 2 - ((kcls >> 1) & 1) - ((tap >> 1) & 1) : (tap / 3) % 3;
+        const int dz = UPF ? (cls & 1) + (tap & 1) : DGF ? 2 - (kcls & 1) - (tap & 1) : tap % 3;
         const int tapoff = (dx * (HY * HZ) + dy * HZ + dz) * ROWB;
         const int sw = (swz(vyl + dy, vz + dz) ^ h) << 4;
         const char* bA = sA + tapoff;
@@ -1104,6 +1120,52 @@ __global__ void pack_upfold_kernel(const float* __restrict__ w, char* __restrict
     }
 }
 
+// Weight image of the dgrad fold (CV_DGFOLD): [n-tile over the C0 gradient channels][class 8][dz-channel slice][tap 8][chunk]
+// [BN][16 B], value(k = dz channel co, n = up channel c) = sum of the forward weights W[t][c][co] over the taps t that
+// (class, tap bit) covers (same table as pack_upfold_kernel; no tap flip: the halo offsets 2 - p - s carry the transpose).
+// w = Keras [27][C0][Cz] of the upsampled input channels (Cz = the layer's output channels = dz channels).
+template <int DT>
+__global__ void pack_dgfold_kernel(const float* __restrict__ w, char* __restrict__ wp, int C0, int Cz, int BN, int ntiles)
+{
+    constexpr int KC = Elt<DT>::kc;
+    const int ncs = Cz / KC;
+    const int64_t total = (int64_t)ntiles * 8 * ncs * 8 * 8 * BN;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i;
+        const int col = (int)(r % BN); r /= BN;
+        const int chunk = (int)(r % 8); r /= 8;
+        const int tap = (int)(r % 8); r /= 8;
+        const int cs = (int)(r % ncs); r /= ncs;
+        const int cls = (int)(r % 8);
+        const int t = (int)(r / 8);
+        const int n = t * BN + (conv_uses_m16(DT, BN) ? conv_cout_of_col(col) : col);   // up channel c
+        int lo3[3], n3[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int pb = (cls >> (2 - a)) & 1, sb = (tap >> (2 - a)) & 1;
+            lo3[a] = pb == 0 ? (sb == 0 ? 0 : 1) : (sb == 0 ? 0 : 2);
+            n3[a] = (pb == 0) == (sb == 0) ? 1 : 2;
+        }
+        char* dst = wp + i * 16;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = cs * KC + (chunk & 3) * 8 + e;                                 // dz channel co
+            float v = 0.f;
+            if (n < C0) {
+                for (int a = 0; a < n3[0]; ++a)
+                    for (int bb = 0; bb < n3[1]; ++bb)
+                        for (int c = 0; c < n3[2]; ++c) {
+                            const int tp = ((lo3[0] + a) * 3 + (lo3[1] + bb)) * 3 + (lo3[2] + c);
+                            v += w[((int64_t)tp * C0 + n) * Cz + k];
+                        }
+            }
+            bf16_t hb = f32_to_bf16(v);
+            if (chunk >= 4) hb = f32_to_bf16(v - bf16_to_f32(hb));  // lo part
+            reinterpret_cast<bf16_t*>(dst)[e] = hb;
+        }
+    }
+}
+
 // out = act(sum_k kpart[k] + bias), summed in index order (bitwise reproducible), fp32 or bf16 store
 __global__ void __launch_bounds__(256)
 conv_ksplit_finalize_kernel(const float* __restrict__ kpart, int nk, const float* __restrict__ bias, void* __restrict__ out,
@@ -1199,20 +1261,21 @@ int dispatch_conv(const ConvParams& p, hipStream_t st, int64_t* nblk_out = nullp
 
 // The two halves of a folded-upsampling layer (EXTRA = CV_UPFOLD or CV_CINIT) on the per-tile default of the plain conv
 template <int DT, int EXTRA>
-int dispatch_conv_fold(const ConvParams& p, hipStream_t st)
+int dispatch_conv_fold(const ConvParams& p, hipStream_t st, int64_t* nblk_out = nullptr)
 {
-    static_assert(DT == MMR_DT_BF16 || DT == MMR_DT_F32X3, "folded upsampling: bf16 / fp32x3");
+    static_assert(DT == MMR_DT_BF16 || DT == MMR_DT_F32X3 || (DT == MMR_DT_F32X1 && (EXTRA & CV_DGFOLD) != 0),
+                  "folded upsampling: bf16 / fp32x3 (dgrad also x1)");
     const int BN = conv_bn(p.Cout);
     const int nt = (p.Cout + BN - 1) / BN;
-    constexpr bool F32T = (DT == MMR_DT_F32X3);
+    constexpr bool F32T = (DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1);
     static_assert(!((EXTRA & CV_PART16) != 0 && F32T), "half partial: bf16 layers only");
     constexpr int V_FULL = CV_M16 | CV_PIPE | CV_DMA_A;
     switch (BN) {
-        case 256: return launch_conv<DT, 2, 4, 4, 2, V_FULL | (F32T ? CV_BATCHA : 0) | EXTRA>(p, nt, st, nullptr);
+        case 256: return launch_conv<DT, 2, 4, 4, 2, V_FULL | (F32T ? CV_BATCHA : 0) | EXTRA>(p, nt, st, nblk_out);
         case 128:
-            if constexpr (DT == MMR_DT_BF16) return launch_conv<DT, 4, 2, 4, 2, CV_M16 | EXTRA>(p, nt, st, nullptr);
-            else return launch_conv<DT, 4, 2, 4, 2, V_FULL | CV_BATCHA | EXTRA>(p, nt, st, nullptr);
-        case 64: return launch_conv<DT, 8, 1, 2, 2, V_FULL | (F32T ? CV_BATCHA : 0) | CV_PRIO_Y | EXTRA>(p, nt, st, nullptr);
+            if constexpr (DT == MMR_DT_BF16) return launch_conv<DT, 4, 2, 4, 2, CV_M16 | EXTRA>(p, nt, st, nblk_out);
+            else return launch_conv<DT, 4, 2, 4, 2, V_FULL | CV_BATCHA | EXTRA>(p, nt, st, nblk_out);
+        case 64: return launch_conv<DT, 8, 1, 2, 2, V_FULL | (F32T ? CV_BATCHA : 0) | CV_PRIO_Y | EXTRA>(p, nt, st, nblk_out);
         default: return MMR_EUNSUPPORTED;
     }
 }
@@ -2134,6 +2197,60 @@ extern "C" int mmr_conv3d_k3_fwd_init(const void* in, int Cin, const void* w_pac
     if (dtype == MMR_DT_BF16 && cinit_half) return dispatch_conv_fold<MMR_DT_BF16, CV_CINIT | CV_PART16>(p, as_stream(stream));
     if (dtype == MMR_DT_BF16) return dispatch_conv_fold<MMR_DT_BF16, CV_CINIT>(p, as_stream(stream));
     return dispatch_conv_fold<MMR_DT_F32X3, CV_CINIT>(p, as_stream(stream));
+}
+
+// ---- data gradient of the folded half (see CV_DGFOLD) ---- //
+extern "C" int64_t mmr_conv3d_k3_dgrad_upfold_packed_bytes(int Cz, int C0, int dtype)
+{
+    if (dtype != MMR_DT_F32X3 && dtype != MMR_DT_F32X1) return MMR_EUNSUPPORTED;
+    if (Cz < 32 || Cz % 32 || C0 < 64 || C0 % 64) return MMR_EINVAL;
+    const int BN = conv_bn(C0);
+    return (int64_t)(C0 / BN) * 8 * (Cz / 32) * 8 * BN * 128;
+}
+
+// w_up_keras: [27][C0][Cz] fp32 = the first C0 input channels of the layer's FORWARD Keras kernel (contiguous)
+extern "C" int mmr_conv3d_k3_dgrad_upfold_pack(const float* w_up_keras, void* w_packed, int C0, int Cz, int dtype, void* stream)
+{
+    const int64_t bytes = mmr_conv3d_k3_dgrad_upfold_packed_bytes(Cz, C0, dtype);
+    if (bytes < 0) return (int)bytes;
+    if (!w_up_keras || !w_packed) return MMR_EINVAL;
+    const int BN = conv_bn(C0);
+    hipLaunchKernelGGL(pack_dgfold_kernel<MMR_DT_F32X3>, dim3(stream_grid(bytes / 16, 256)), dim3(256), 0, as_stream(stream),
+                       w_up_keras, (char*)w_packed, C0, Cz, BN, C0 / BN);
+    return check_launch();
+}
+
+extern "C" int64_t mmr_conv3d_k3_dgrad_upfold_ws_bytes(int B, int X2, int Y2, int Z2, int C0)
+{
+    return (int64_t)B * ((X2 + TX - 1) / TX) * ((Y2 + TY - 1) / TY) * ((Z2 + TZ - 1) / TZ) * C0 * (int64_t)sizeof(double);
+}
+
+// d x_low [B,X2,Y2,Z2,C0] fp32 = gradient of conv3x3x3(concat([UpSampling3D(2)(x_low) | skip])) w.r.t. x_low given
+// dz [B,2X2,2Y2,2Z2,Cz]: what mmr_conv3d_k3_dgrad_split + the 2x2x2 pooling of mmr_upcat_bwd_masked_f32 produce for the
+// upsampled channels.  ymask != NULL: multiplied by LeakyReLU'(ymask) (ymask = x_low itself, the activated output of the
+// layer that produced it) and dbias (+)= the column sums of the result, as in mmr_conv3d_k3_dgrad_masked.
+extern "C" int mmr_conv3d_k3_dgrad_upfold(const void* dz, int Cz, const void* w_packed, float* out, int B, int X2, int Y2,
+                                          int Z2, int C0, const float* ymask, float alpha, float* dbias, void* ws,
+                                          int accumulate, int dtype, void* stream)
+{
+    if (!dz || !w_packed || !out || B < 1 || X2 < 1 || Y2 < 1 || Z2 < 1) return MMR_EINVAL;
+    if (mmr_conv3d_k3_dgrad_upfold_packed_bytes(Cz, C0, dtype) < 0) return (int)mmr_conv3d_k3_dgrad_upfold_packed_bytes(Cz, C0, dtype);
+    if (ymask && (!dbias || !ws)) return MMR_EINVAL;
+    ConvParams p;
+    p.in0 = (const char*)dz; p.in1 = nullptr; p.wp = (const char*)w_packed; p.bias = nullptr;
+    p.out = (char*)out;
+    p.B = B; p.X = X2; p.Y = Y2; p.Z = Z2; p.C0 = Cz; p.C1 = 0; p.up0 = 0; p.Cout = C0;
+    p.leaky = 0; p.alpha = alpha; p.out_f32 = 1; p.ymask = ymask; p.part = ymask ? (double*)ws : nullptr;
+    p.kpart = nullptr; p.gsplit = 0; p.out1 = nullptr; p.csplit = 0;
+    p.ntx = (X2 + TX - 1) / TX; p.nty = (Y2 + TY - 1) / TY; p.ntz = (Z2 + TZ - 1) / TZ;
+    int64_t nblk = 0;
+    int rc;
+    if (dtype == MMR_DT_F32X3) rc = dispatch_conv_fold<MMR_DT_F32X3, CV_DGFOLD>(p, as_stream(stream), &nblk);
+    else rc = dispatch_conv_fold<MMR_DT_F32X1, CV_DGFOLD>(p, as_stream(stream), &nblk);
+    if (rc != MMR_OK || !ymask) return rc;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(C0), dim3(64), 0, as_stream(stream), (const double*)ws, dbias, C0, (int)nblk,
+                       accumulate);
+    return check_launch();
 }
 
 extern "C" int64_t mmr_conv3d_k3_dgrad_masked_ws_bytes(int B, int X, int Y, int Z, int Cout)

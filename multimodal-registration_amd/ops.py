@@ -266,6 +266,59 @@ def conv3d_k3_upfold(in_low, skip, w_up, w_skip, bias, cout, leaky=True, alpha=0
     return out
 
 
+def dgrad_upfold_supported(C0, C1, Cz, x3, B, X, Y, Z):
+    """The folded data gradient (mmr_conv3d_k3_dgrad_upfold) serves the upsampled half of a concat layer's backward when the
+    tensors are fp32 with bf16-split products (x3 True or 'hi'), the widths fit and both launches fill the chip.  X, Y, Z: full
+    resolution of the layer."""
+    if not x3 or C0 % 64 or C1 % 64 or C0 < 64 or C1 < 64 or Cz % 32 or (X | Y | Z) & 1:
+        return False
+    tiles = lambda x, y, z, c: B * (-(-x // (4 if c % 256 == 0 else 8))) * (-(-y // 8)) * (-(-z // 8)) * max(c // 256, 1)
+    return tiles(X // 2, Y // 2, Z // 2, C0) >= 200 and tiles(X, Y, Z, C1) >= 200
+
+
+def pack_dgrad_upfold_weights(w_keras, C0, x3=True):
+    """Forward Keras kernel [3,3,3,C0+C1,Cz] of a concat layer -> operand image of the folded dgrad of its first C0 channels."""
+    _chk(w_keras, torch.float32, "w_keras")
+    cz = int(w_keras.shape[4])
+    lib = _lib.load()
+    mode = conv_mode(torch.float32, x3)
+    nbytes = lib.mmr_conv3d_k3_dgrad_upfold_packed_bytes(cz, int(C0), mode)
+    if nbytes < 0:
+        raise _lib.MmrError(f"cannot fold dgrad weights C0={C0} Cz={cz}")
+    w_up = w_keras[:, :, :, :C0, :].contiguous()
+    out = torch.empty(nbytes, dtype=torch.uint8, device=w_keras.device)
+    rc = lib.mmr_conv3d_k3_dgrad_upfold_pack(w_up.data_ptr(), out.data_ptr(), int(C0), cz, mode, _stream())
+    _lib.check(rc, "mmr_conv3d_k3_dgrad_upfold_pack")
+    return out
+
+
+def conv3d_k3_dgrad_upfold(dz, w_packed, C0, ymask=None, dbias=None, alpha=0.2, accumulate=False, x3=True):
+    """d(low-res input) of conv(concat([up2(x_low), skip])) given dz [B,X,Y,Z,Cz] -> [B,X/2,Y/2,Z/2,C0]; with ``ymask``
+    (= x_low) the result is already multiplied by LeakyReLU'(x_low) and ``dbias`` (+)= its column sums."""
+    _chk(dz, torch.float32, "dz")
+    B, X, Y, Z, Cz = dz.shape
+    X2, Y2, Z2 = X // 2, Y // 2, Z // 2
+    out = torch.empty((B, X2, Y2, Z2, C0), dtype=torch.float32, device=dz.device)
+    lib = _lib.load()
+    mode = conv_mode(torch.float32, x3)
+    ws = None
+    if ymask is not None:
+        _chk(ymask, torch.float32, "ymask")
+        _chk(dbias, torch.float32, "dbias")
+        if tuple(ymask.shape) != tuple(out.shape) or dbias.numel() != C0:
+            raise _lib.MmrError(f"ymask {tuple(ymask.shape)} / dbias {tuple(dbias.shape)} do not match {tuple(out.shape)}")
+        ws = _ws(lib.mmr_conv3d_k3_dgrad_upfold_ws_bytes(B, X2, Y2, Z2, int(C0)), dz.device)
+    fam = f"conv3d_k3_mfma_{('f32', 'bf16', 'f32x3', 'f32x1')[mode]}_bn{256 if C0 % 256 == 0 else 128 if C0 % 128 == 0 else 64}_dgfold"
+    # algorithmic flops: the 27-tap count of this half of the concat dgrad (the kernel executes 8/27 of it)
+    with _Timed(fam, (Cz, int(C0), X, Y, Z), 2.0 * 27 * Cz * C0 * B * X * Y * Z):
+        rc = lib.mmr_conv3d_k3_dgrad_upfold(dz.data_ptr(), Cz, w_packed.data_ptr(), out.data_ptr(), B, X2, Y2, Z2, int(C0),
+                                            ymask.data_ptr() if ymask is not None else None, float(alpha),
+                                            dbias.data_ptr() if dbias is not None else None,
+                                            ws.data_ptr() if ws is not None else None, int(accumulate), mode, _stream())
+    _lib.check(rc, "mmr_conv3d_k3_dgrad_upfold")
+    return out
+
+
 def conv3d_k3_dgrad_masked(dz, wt_packed, cin, ymask, dbias, alpha=0.2, accumulate=False, x3=False):
     """d(input) of a k3 conv, already multiplied by LeakyReLU'(ymask) of the layer that produced that input, whose
     bias gradient (column sums of the result) lands in ``dbias``: the dgrad + leaky_bwd_bias_ pair in one kernel."""

@@ -200,6 +200,28 @@ class SynthMorphTrainer:
                         premasked.add(id(x))
                     if dcat is None:
                         dcat = ops.conv3d_k3_cout3_dgrad(dz, m._w[2 * li], x3=bool(self.bwd_x3))
+                elif (up0 and in1 is not None and id(in1) not in grads and id(x) not in grads and m.fold_upsampling
+                      and ops.dgrad_upfold_supported(C0, C1, dz.shape[-1], self.bwd_x3, *dz.shape[:4])):
+                    # concat layer, folded: the skip half is an ordinary (masked) dgrad over its C1 channels; the upsampled half
+                    # comes straight out at LOW resolution from the 8-class x 8-tap fold (no full-resolution intermediate,
+                    # no pooling pass), already multiplied by LeakyReLU'(x) with x's bias gradient
+                    wk = m._w[2 * li]
+                    wt_skip = ops.pack_conv_weights(wk[:, :, :, C0:, :].contiguous(), torch.float32, transpose_flip=True, x3=self.bwd_x3)
+                    if want_mask(in1):
+                        db, acc = bias_of(in1)
+                        grads[id(in1)] = ops.conv3d_k3_dgrad_masked(dz, wt_skip, C1, in1, db, accumulate=acc, x3=self.bwd_x3)
+                        premasked.add(id(in1))
+                    else:
+                        grads[id(in1)] = ops.conv3d_k3(dz, wt_skip, None, C1, leaky=False, out_f32=True, x3=self.bwd_x3)
+                    wt_up = ops.pack_dgrad_upfold_weights(wk, C0, x3=self.bwd_x3)
+                    if want_mask(x):
+                        db, acc = bias_of(x)
+                        grads[id(x)] = ops.conv3d_k3_dgrad_upfold(dz, wt_up, C0, ymask=x, dbias=db, accumulate=acc, x3=self.bwd_x3)
+                        premasked.add(id(x))
+                    else:
+                        grads[id(x)] = ops.conv3d_k3_dgrad_upfold(dz, wt_up, C0, x3=self.bwd_x3)
+                    del dz, dy
+                    continue
                 else:
                     wt = ops.pack_conv_weights(m._w[2 * li], torch.float32, transpose_flip=True, x3=self.bwd_x3)
                     if plain and want_mask(x):

@@ -137,7 +137,7 @@ def family_of(kernel_name):
     if m:
         dt, wm, wn, mt, nt, var = map(int, m.groups())
         fam = f"conv3d_k3_mfma_{('f32', 'bf16', 'f32x3', 'f32x1')[dt]}_bn{wn * nt * 32}"
-        return fam + ("_upfold" if var & (1 << 16) else "_cinit" if var & (1 << 17) else "")
+        return fam + ("_upfold" if var & (1 << 16) else "_cinit" if var & (1 << 17) else "_dgfold" if var & (1 << 19) else "")
     for name in ("ncc_fused4_kernel", "ncc_fused_kernel", "bending_fused_kernel"):
         if name in k:
             return name

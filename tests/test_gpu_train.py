@@ -595,3 +595,71 @@ def test_dgrad_split_equals_dgrad_then_upcat(dev, shape, C0, C1, Cz, x3):
     assert _rel(b1, b1r) < 1e-5 and _rel(b0, b0r) < 1e-5
     d0u, d1u = ops.conv3d_k3_dgrad_split(dz, wt, C0, C1, x3=x3)  # no mask
     assert _rel(d1u, dcat[..., C0:]) < 2e-6 and _rel(d0u, dcat[..., :C0]) < 2e-6
+
+
+@pytest.mark.parametrize("shape,C0,C1,Cz", [((8, 16, 16), 64, 64, 64), ((12, 20, 28), 128, 64, 64), ((4, 4, 6), 64, 128, 32),
+                                            ((16, 16, 32), 256, 256, 256)])
+@pytest.mark.parametrize("x3", [True, "hi"])
+def test_folded_dgrad_of_upsampled_half(dev, shape, C0, C1, Cz, x3):
+    """mmr_conv3d_k3_dgrad_upfold vs float64 autograd of conv(concat([UpSampling3D(2)(x_low), skip])) w.r.t. x_low: plain,
+    and with the fused LeakyReLU backward + bias gradient of the layer that produced x_low (what the trainer uses instead of
+    dgrad_split + the 2x2x2 pooling of upcat_bwd).  Ragged low-res tiles, a volume smaller than one tile, every N tile."""
+    import mmr
+    import torch.nn.functional as F
+    ops = mmr.ops
+    rng = np.random.default_rng(hash((shape, C0, C1, Cz)) % 2 ** 31)
+    X, Y, Z = shape
+    B = 2 if np.prod(shape) < 600 else 1
+    xl = rng.standard_normal((B, X // 2, Y // 2, Z // 2, C0)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, C0 + C1, Cz)) * np.sqrt(2.0 / (27 * (C0 + C1)))).astype(np.float32)
+    dz = rng.standard_normal((B, X, Y, Z, Cz)).astype(np.float32)
+    xt = torch.from_numpy(xl).double().requires_grad_(True)
+    up = xt.repeat_interleave(2, 1).repeat_interleave(2, 2).repeat_interleave(2, 3)
+    wt = torch.from_numpy(w[:, :, :, :C0]).double()
+    y = F.conv3d(up.permute(0, 4, 1, 2, 3), wt.permute(4, 3, 0, 1, 2), padding=1).permute(0, 2, 3, 4, 1)
+    (y * torch.from_numpy(dz).double()).sum().backward()
+    ref = xt.grad.numpy()
+    wp = ops.pack_dgrad_upfold_weights(_t(w, dev), C0, x3=x3)
+    got = ops.conv3d_k3_dgrad_upfold(_t(dz, dev), wp, C0, x3=x3)
+    tol = 1e-4 if x3 is True else 1.5e-2     # 'hi': bf16-product backward (opt-in), bf16-grade
+    assert tuple(got.shape) == ref.shape and _rel(got, ref) < tol, _rel(got, ref)
+    # masked: times LeakyReLU'(x_low), bias gradient = column sums, accumulated onto an existing value
+    mask = np.where(xl > 0, 1.0, 0.2)
+    db = torch.full((C0,), 3.0, device=dev)
+    gm = ops.conv3d_k3_dgrad_upfold(_t(dz, dev), wp, C0, ymask=_t(xl, dev), dbias=db, accumulate=True, x3=x3)
+    assert _rel(gm, ref * mask) < tol
+    assert _rel(db - 3.0, (ref * mask).sum((0, 1, 2, 3))) < (1e-4 if x3 is True else 2e-2)
+
+
+def test_folded_training_step_matches_unfolded(dev):
+    """The whole backward with the decoder layers folded (forward: upfold + cinit, backward: folded dgrad) against the same
+    step with fold_upsampling=False, at a size where the fold engages (96^3, BASELINE configs[2]'s widths): every one of the
+    22 gradient tensors to fp32x3 accuracy -- the two paths share no kernel for the upsampled halves."""
+    import mmr
+    from mmr import synth, training
+    shape, L = (96, 96, 96), 6
+    enc, dec = [64] * 4, [64] * 6
+    rng = np.random.default_rng(3)
+    lab = np.repeat(np.repeat(np.repeat(rng.integers(0, L, (1, 12, 12, 12)), 8, 1), 8, 2), 8, 3).astype(np.uint8)[..., None]
+    kw = dict(in_shape=shape, in_label_list=np.arange(L), out_label_list=np.arange(L), warp_std=2, warp_res=16, blur_std=1,
+              bias_std=0.3, bias_res=40, gamma_std=0.25)
+    grads, used = {}, {}
+    for fold in (False, True):
+        g1, g2 = synth.labels_to_image(**kw, id=0, seed=1), synth.labels_to_image(**kw, id=1, seed=2)
+        model = mmr.networks.VxmDense(shape, nb_unet_features=(enc, dec), int_steps=5, int_resolution=2, svf_resolution=2,
+                                      compute_dtype="fp32x3", seed=4, fold_upsampling=fold)
+        w = model.get_weights()
+        w[-2] = (np.random.default_rng(9).standard_normal(w[-2].shape) * 2e-2).astype(np.float32)
+        model.set_weights(w)
+        tr = training.SynthMorphTrainer(model, g1, g2, reg_param=1.0)
+        mmr.ops.PROFILE = []
+        out = tr.forward_backward(lab, lab, g1.draw(1), g2.draw(1))
+        used[fold] = {f for f, *_ in mmr.ops.PROFILE}
+        mmr.ops.PROFILE = None
+        grads[fold] = [g.clone() for g in tr.g]
+        assert torch.isfinite(out["loss"])
+    assert any(f.endswith("_upfold") for f in used[True]) and any(f.endswith("_dgfold") for f in used[True])
+    assert not any(f.endswith("_upfold") or f.endswith("_dgfold") for f in used[False])
+    for i, (a, b) in enumerate(zip(grads[True], grads[False])):
+        err = _rel(a, b)
+        assert err < 2e-4, f"gradient tensor {i}: folded vs unfolded {err:.2e}"
