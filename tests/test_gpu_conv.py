@@ -73,6 +73,7 @@ UPFOLD_CASES = [
     ((8, 16, 32), 256, 256, 256),     # the dec_final_0 shape class of BASELINE configs[1]
     ((12, 20, 28), 128, 64, 128),     # low-res 6x10x14: partial tiles on every axis
     ((4, 4, 6), 64, 128, 64),         # volume smaller than one tile: every voxel on a zero-padded border
+    ((10, 14, 18), 64, 64, 128),      # odd low-resolution sizes 5 x 7 x 9
 ]
 
 

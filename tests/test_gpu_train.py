@@ -598,7 +598,7 @@ def test_dgrad_split_equals_dgrad_then_upcat(dev, shape, C0, C1, Cz, x3):
 
 
 @pytest.mark.parametrize("shape,C0,C1,Cz", [((8, 16, 16), 64, 64, 64), ((12, 20, 28), 128, 64, 64), ((4, 4, 6), 64, 128, 32),
-                                            ((16, 16, 32), 256, 256, 256)])
+                                            ((16, 16, 32), 256, 256, 256), ((10, 14, 18), 64, 64, 96)])
 @pytest.mark.parametrize("x3", [True, "hi"])
 def test_folded_dgrad_of_upsampled_half(dev, shape, C0, C1, Cz, x3):
     """mmr_conv3d_k3_dgrad_upfold vs float64 autograd of conv(concat([UpSampling3D(2)(x_low), skip])) w.r.t. x_low: plain,
