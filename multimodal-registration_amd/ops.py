@@ -4,8 +4,6 @@ torch is used for device memory and streams only; every arithmetic operation
 below is a call into libmmr_hip.so.  Shapes are channels-last.  All functions
 raise on CPU tensors: there is no CPU path in the product.
 """
-import os
-
 import torch
 
 from . import _lib, semantics
