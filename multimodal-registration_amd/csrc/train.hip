@@ -249,8 +249,11 @@ grad_l2_bwd_kernel(const float* __restrict__ f, float* __restrict__ df, int B, i
 __device__ __forceinline__ void axis_range(int j, float st, int no, int maxi, int& lo, int& hi)
 {
     if (st > 0.f) {
-        lo = (int)floorf((float)(j - 1) / st) - 1;
-        hi = (int)ceilf((float)(j + 1) / st) + 1;
+        // output i reads inputs floor(i st) and floor(i st) + 1: it touches j iff i st lies in [j - 1, j + 1).  No extra margin:
+        // an index that floor / ceil drop through rounding sits on the edge of that interval, where its weight is 0 to rounding
+        // (the margins of +-1 this replaces made 7 - 8 candidates per axis for the x2 resize instead of 5 - 6: 2.5x the gather)
+        lo = (int)floorf((float)(j - 1) / st);
+        hi = (int)ceilf((float)(j + 1) / st);
         lo = lo < 0 ? 0 : lo;
         // the forward clamps every position beyond the last voxel onto it (arange_over_f grid with Xo > X * zoom): all of
         // those outputs read index maxi with weight 1 and must be gathered here, or this is not the adjoint
