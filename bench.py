@@ -67,20 +67,26 @@ def launch_ranks(n, argv):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     deadline = time.time() + float(os.environ.get("MMR_BENCH_LAUNCH_TIMEOUT", "1500"))
-    out0, rc = b"", 0
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)   # rank 0's JSON line
+    reader.start()
+    rc = 0
     try:
-        out0 = procs[0].communicate(timeout=max(deadline - time.time(), 1))[0]
-        for p in procs:
-            p.wait(timeout=max(deadline - time.time(), 1))
-            rc = rc or p.returncode
-    except subprocess.TimeoutExpired:
-        rc = 124
+        while any(p.poll() is None for p in procs):
+            bad = [p.returncode for p in procs if p.poll() not in (None, 0)]
+            if bad or time.time() > deadline:     # a rank died (the others would wait for it in a collective) or the run hung
+                rc = bad[0] if bad else 124
+                break
+            time.sleep(0.2)
+        rc = rc or next((p.returncode for p in procs if p.poll() not in (None, 0)), 0)
     finally:
         for p in procs:     # only the exact children started above
             if p.poll() is None:
                 p.kill()
                 p.wait()
-                rc = rc or 1
+    reader.join(timeout=5)
+    out0 = out0[0] if out0 else b""
     sys.stdout.write(out0.decode())
     sys.stdout.flush()
     return rc
