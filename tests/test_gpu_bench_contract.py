@@ -69,3 +69,23 @@ def test_train_and_ncc_lines_small():
     assert KEYS <= set(d) and d["dtype"] == "fp32x3" and d["value"] > 0 and "dp1" in d["config"]["parallelism"]
     d = _run("--workload", "ncc", "--shape", "64", "64", "64", "--steps", "3", "--warmup", "1")
     assert KEYS <= set(d) and d["roofline"]["bound"] == "hbm" and d["roofline"]["unit"] == "GB/s"
+
+
+def test_torchrun_form_two_ranks():
+    """The driver's N > 1 form: `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2` -- every process is
+    one rank (WORLD_SIZE set, so nobody becomes the launcher), rank 0 prints the one line.  gloo here (two ranks on one card)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    e = dict(os.environ, MMR_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "train", "--shape", "32", "32",
+                        "32", "--features", "32", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900, env=e)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dist"]["world_size"] == 2 and d["dist"]["launched_by"] == "torchrun" and d["dist"]["allreduce_ms_per_step"] > 0
