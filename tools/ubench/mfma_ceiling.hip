@@ -13,6 +13,43 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// 16 waves per workgroup (4 per SIMD), 64 x 64 wave tiles: 16 reads per 32 MFMAs, 64 accumulator registers per wave
+template <bool LDS>
+__global__ void __launch_bounds__(1024) k16(const uint4* __restrict__ seed, float* __restrict__ out, unsigned long long* __restrict__ stamps, int iters)
+{
+    __shared__ uint4 sm[1024 * 8];
+    const int tid = threadIdx.x;
+    for (int i = 0; i < 8; ++i) sm[i * 1024 + tid] = seed[(i * 1024 + tid) % 4096];
+    __syncthreads();
+    uint4 fa[4], fb[4];
+    for (int i = 0; i < 4; ++i) { fa[i] = sm[i * 1024 + tid]; fb[i] = sm[(4 + i) * 1024 + tid]; }
+    f32x4 acc[4][4];
+    for (int m = 0; m < 4; ++m)
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (LDS) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { fa[i] = sm[((i + ks + it) % 8) * 1024 + tid]; fb[i] = sm[((4 + i + ks + it) % 8) * 1024 + tid]; }
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[n]), __builtin_bit_cast(bf16x8, fa[m]),
+                                                                      acc[m][n], 0, 0, 0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+    for (int m = 0; m < 4; ++m)
+        for (int n = 0; n < 4; ++n) s += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+    out[blockIdx.x * 1024 + tid] = s;
+    if (tid == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 template <bool LDS>
 __global__ void __launch_bounds__(512, 2) k(const uint4* __restrict__ seed, float* __restrict__ out, unsigned long long* __restrict__ stamps, int iters)
 {
@@ -68,19 +105,21 @@ int main(int argc, char** argv)
     }
     uint4* seed; float* out; unsigned long long* st;
     hipMalloc(&seed, h.size() * sizeof(uint4));
-    hipMalloc(&out, blocks * 512 * sizeof(float));
+    hipMalloc(&out, blocks * 1024 * sizeof(float));
     hipMalloc(&st, blocks * 2 * sizeof(unsigned long long));
     hipMemcpy(seed, h.data(), h.size() * sizeof(uint4), hipMemcpyHostToDevice);
     std::vector<unsigned long long> hs(blocks * 2);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {
         float best = 1e30f;
         for (int rep = 0; rep < 6; ++rep) {             // ~1 s of back-to-back launches per mode: the clock settles
             hipEventRecord(e0);
             for (int l = 0; l < 20; ++l) {
                 if (mode == 0) hipLaunchKernelGGL(k<false>, dim3(blocks), dim3(512), 0, 0, seed, out, st, iters);
-                else hipLaunchKernelGGL(k<true>, dim3(blocks), dim3(512), 0, 0, seed, out, st, iters);
+                else if (mode == 1) hipLaunchKernelGGL(k<true>, dim3(blocks), dim3(512), 0, 0, seed, out, st, iters);
+                else if (mode == 2) hipLaunchKernelGGL(k16<false>, dim3(blocks), dim3(1024), 0, 0, seed, out, st, iters);
+                else hipLaunchKernelGGL(k16<true>, dim3(blocks), dim3(1024), 0, 0, seed, out, st, iters);
             }
             hipEventRecord(e1);
             hipEventSynchronize(e1);
@@ -90,12 +129,12 @@ int main(int argc, char** argv)
         hipMemcpy(hs.data(), st, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         double cyc = 0, real = 0;
         for (int b = 0; b < blocks; ++b) { cyc += hs[2 * b]; real += hs[2 * b + 1]; }
-        const double flops = 20.0 * blocks * 8 /*waves*/ * (double)iters * 64 /*mfma*/ * 2.0 * 16 * 16 * 32;
+        const double flops = 20.0 * blocks * (mode < 2 ? 8 : 16) /*waves*/ * (double)iters * 64 /*mfma*/ * 2.0 * 16 * 16 * 32;
         const double clock_ghz = cyc / real * 0.1;      // s_memrealtime ticks at 100 MHz
         const double tf = flops / (best * 1e-3) / 1e12;
         // cycles per MFMA and SIMD from the wall rate at the in-kernel clock (16 = the instruction's issue interval)
         printf("%s: %.0f TFLOP/s (%.1f %% of 2.5 PFLOP/s), in-kernel clock %.2f GHz, %.1f cycles per MFMA and SIMD\n",
-               mode == 0 ? "registers" : "lds-fed  ", tf, tf / 2500 * 100, clock_ghz, 16384.0 * 1024 * clock_ghz * 1e9 / (tf * 1e12));
+               mode == 0 ? "registers, 2 waves/SIMD" : mode == 1 ? "lds-fed,   2 waves/SIMD" : mode == 2 ? "registers, 4 waves/SIMD" : "lds-fed,   4 waves/SIMD (64x64 wave tiles)", tf, tf / 2500 * 100, clock_ghz, 16384.0 * 1024 * clock_ghz * 1e9 / (tf * 1e12));
     }
     return 0;
 }
