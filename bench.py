@@ -343,11 +343,15 @@ def roofline_from_profile(prof, steps, traffic_file):
         # kernel EXECUTES 8/27 of it on the matrix cores -- state both
         for k, d in roof["other_mfma_kernels"].items():
             if k.endswith("_upfold") or k.endswith("_dgfold"):
-                d["executed_TFLOPs"] = round(d["TFLOPs"] * 8 / 27, 1)
-                d["executed_frac"] = round(d["frac"] * 8 / 27, 3)
+                share = (1 + 8 / 27) / 2 if k.startswith("conv3d_k3_wgrad") else 8 / 27
+                d["executed_TFLOPs"] = round(d["TFLOPs"] * share, 1)
+                d["executed_frac"] = round(d["frac"] * share, 3)
         mf = {k: v for k, v in kern.items() if not k.startswith("hbm:")}
         alg = sum(v[1] for v in mf.values())
-        exe = sum(v[1] * (8 / 27 if (k.endswith("_upfold") or k.endswith("_dgfold")) else 1.0) for k, v in mf.items())
+        # executed share of a folded family: 8/27 (conv halves); the folded wgrad times BOTH halves of a layer under one name
+        # (equal channel counts in every shipped configuration): (1 + 8/27) / 2
+        exe = sum(v[1] * ((1 + 8 / 27) / 2 if (k.startswith("conv3d_k3_wgrad") and k.endswith("_upfold")) else
+                          8 / 27 if (k.endswith("_upfold") or k.endswith("_dgfold")) else 1.0) for k, v in mf.items())
         tms = sum(v[0] for v in mf.values())
         roof["all_mfma_kernels"] = {"ms_per_step": round(tms / steps, 3), "algorithmic_tflop_per_step": round(alg / steps / 1e12, 3),
                                     "executed_tflop_per_step": round(exe / steps / 1e12, 3),

@@ -143,6 +143,15 @@ int64_t mmr_conv3d_k3_dgrad_upfold_ws_bytes(int B, int X2, int Y2, int Z2, int C
 int mmr_conv3d_k3_dgrad_upfold(const void* dz, int Cz, const void* w_packed, float* out, int B, int X2, int Y2, int Z2,
                                int C0, const float* ymask, float alpha, float* dbias, void* ws, int accumulate,
                                int dtype, void* stream);
+/* Weight gradient of the same layer, folded: dw [27][C0 + C1][Cout] (+)= dL/dW given dz [B,2*X2,2*Y2,2*Z2,Cout].  Rows [0, C0)
+ * (the upsampled channels) come from the low-resolution x_low [B,X2,Y2,Z2,C0]: per parity class p the 8 correlations
+ * dWf[p][s] = sum_i x_low[i - 1 + p + s] (x) dz[2 i + p] on the low-resolution grid, each added to the original taps its fold
+ * covers (64 class-tap products over N / 8 voxels instead of 27 over N); rows [C0, C0 + C1) from skip [B,2*X2,..,C1] through the
+ * ordinary kernel.  x3mode 1 = fp32x3 products, 2 = bf16 hi products only.  Cout a multiple of 64, C0 / C1 of 32, every tensor
+ * under 3.75 GB; else MMR_EINVAL / MMR_EUNSUPPORTED (use mmr_conv3d_k3_wgrad_f32x3 with up0 = 1). */
+int64_t mmr_conv3d_k3_wgrad_upfold_ws_bytes(int B, int X2, int Y2, int Z2, int C0, int C1, int Cout);
+int mmr_conv3d_k3_wgrad_upfold(const float* x_low, int C0, const float* skip, int C1, const float* dz, float* dw, void* ws,
+                               int B, int X2, int Y2, int Z2, int Cout, int accumulate, int x3mode, void* stream);
 /* First layer: concatenate([moving, fixed]) (2 x 1 channel, fp32) -> Cout.  pool_out (optional, same element type as
  * out, [B,X/2,Y/2,Z/2,Cout]): MaxPooling3D(2) of the activated output from the same kernel (bf16 and fp32x3 kernels;
  * MMR_EUNSUPPORTED with the exact-fp32 kernel).  Saves the 2.5 GB read of a separate pooling pass at C2.        */

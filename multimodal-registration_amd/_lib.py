@@ -96,6 +96,8 @@ SIGNATURES = {
     "mmr_conv3d_k3_wgrad_f32": (I, [P, I, I, P, I, P, P, P, I, I, I, I, I, I, P]),
     "mmr_conv3d_k3_wgrad_f32x3": (I, [P, I, I, P, I, P, P, P, I, I, I, I, I, I, P]),
     "mmr_conv3d_k3_wgrad_f32x1": (I, [P, I, I, P, I, P, P, P, I, I, I, I, I, I, P]),
+    "mmr_conv3d_k3_wgrad_upfold_ws_bytes": (c_int64, [I, I, I, I, I, I, I]),
+    "mmr_conv3d_k3_wgrad_upfold": (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, I, P]),
     "mmr_conv3d_k3_cin2_wgrad_ws_bytes": (c_int64, [I]),
     "mmr_conv3d_k3_cin2_wgrad_f32": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
     "mmr_conv3d_k3_cin2_wgrad_f32x3": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),

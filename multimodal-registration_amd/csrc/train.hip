@@ -1012,19 +1012,37 @@ __device__ __forceinline__ unsigned long long wstamp_now()
 // into the same kernel behind a wave-uniform branch, hipcc put `s_waitcnt vmcnt(0)` in front of every dZ load at the
 // join of the two paths: 8 more dependent round trips per tile.)
 template <int N> struct IC { static constexpr int value = N; };
-template <int COT, bool LO, bool STAMP = false, int PF = 3, bool FULLCO = false, bool BUF = false>
+// FOLD (round 3): the weight gradient of the UPSAMPLED half of a decoder layer, one parity class per workgroup.  With the
+// folded weights Wf[p][s] (conv3d.hip, CV_UPFOLD) dWf[p][s] = sum_i x_low[i - 1 + p + s] (x) dz[2 i + p]: a correlation on the
+// LOW-resolution grid between x_low (haloed tile, halo offset p + s per axis: one of the 27 ordinary tap offsets) and the class's
+// sub-lattice of the full-resolution dz.  blockIdx.z = cob * 8 + class; the 8 (p, s) pairs of the class are spread over the four
+// wave pairs (two accumulator tiles per wave instead of seven), p.X / Y / Z are the low-resolution dims, dz is addressed at
+// 2 i + p of a [B, 2X, 2Y, 2Z, Cout] tensor, and the slab keeps the 27-tap layout (entry p + s).  wgrad_fold_reduce_kernel then
+// adds every dWf[p][s] to the original taps it covers.  64 (class, tap) correlations over N / 8 voxels instead of 27 over N.
+template <int COT, bool LO, bool STAMP = false, int PF = 3, bool FULLCO = false, bool BUF = false, bool FOLD = false>
 __global__ void __launch_bounds__(W_THREADS, 2)
 wgrad_x3_kernel(const WgradParams p)
 {
     constexpr bool PFX = (PF & 1) != 0, PFZ = (PF & 2) != 0;
     unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st_t = 0;
-    constexpr int NU = (COT == 2) ? 7 : 4;
+    static_assert(!FOLD || (COT == 2 && FULLCO && BUF), "folded wgrad: 64-column blocks, buffer loads");
+    constexpr int NU = FOLD ? 2 : (COT == 2) ? 7 : 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sX = smem;
     char* sZ = smem + WX_A_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int slice = blockIdx.y, cob = blockIdx.z;
+    const int slice = blockIdx.y, cob = FOLD ? (int)blockIdx.z >> 3 : (int)blockIdx.z;
+    const int fcls = FOLD ? (int)blockIdx.z & 7 : 0;     // parity class (px, py, pz) = bits 2, 1, 0
+    // tap (27-index = halo offset) of accumulator tile j of this wave
+    auto tap_of = [&](int j) -> int {
+        if constexpr (FOLD) {
+            const int tb = (wave >> 1) + 4 * j;          // (sx, sy, sz) = bits 2, 1, 0
+            return ((((fcls >> 2) & 1) + ((tb >> 2) & 1)) * 3 + ((fcls >> 1) & 1) + ((tb >> 1) & 1)) * 3 + (fcls & 1) + (tb & 1);
+        } else {
+            return (COT == 2) ? (wave >> 1) + 4 * j : wave + 8 * j;
+        }
+    };
     const int ch0 = slice * 32;
     const bool first = ch0 < p.C0;
     const float* src = first ? p.in0 : p.in1;
@@ -1044,7 +1062,7 @@ wgrad_x3_kernel(const WgradParams p)
     for (int j = 0; j < NU; ++j) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        int tap = (COT == 2) ? (wave >> 1) + 4 * j : wave + 8 * j;
+        int tap = tap_of(j);
         if (tap > 26) tap = 26;
         const int dz = tap % 3;
         const int sw = ((q + dz) >> 1) & 1;  // plane swizzle of the rows this lane addresses (hz = 4r + q + dz)
@@ -1174,7 +1192,14 @@ wgrad_x3_kernel(const WgradParams p)
         const int v = i >> 4, c4 = i & 15;
         const int gx = x0 + (v >> 6), gy = y0 + ((v >> 3) & 7), gz = z0 + (v & 7);
         const int co = cob * 64 + c4 * 4;
-        if constexpr (FULLCO && BUF) {
+        if constexpr (FOLD) {
+            // low-resolution voxel (gx, gy, gz) of the tile <-> voxel 2 g + p of the full-resolution dz [B, 2X, 2Y, 2Z, Cout]
+            const bool ok = gx < p.X && gy < p.Y && gz < p.Z;
+            const unsigned vox = (unsigned)(((b * 2 * p.X + 2 * gx + ((fcls >> 2) & 1)) * 2 * p.Y + 2 * gy + ((fcls >> 1) & 1)) * 2 * p.Z +
+                                            2 * gz + (fcls & 1));
+            okbits |= 0x10000u << it;
+            return __builtin_amdgcn_raw_buffer_load_b128(rsZ, ok ? (vox * (unsigned)p.Cout + (unsigned)co) * 4u : 0xF0000000u, 0, 0);
+        } else if constexpr (FULLCO && BUF) {
             // item `it` = voxel (vx = it >> 1, vy = vy0 + 4 (it & 1), vz): one per-thread base offset, the item part is
             // wave-uniform and goes into the instruction's scalar offset
             const int v0 = tv >> 4, vy0 = (v0 >> 3) & 3, vz0 = v0 & 7;
@@ -1326,10 +1351,11 @@ wgrad_x3_kernel(const WgradParams p)
             for (int k = 0; k < 5; ++k) atomicAdd(&g_wgrad_stamp[wave][k], st_acc[k]);
         }
     }
-    float* out = p.slab + (((size_t)blockIdx.x * gridDim.y + slice) * gridDim.z + cob) * (27 * 32 * 64);
+    // slab[blk][slice][cob (FOLD: cob * 8 + class)][27 taps][32 ci][64 co]
+    float* out = p.slab + (((size_t)blockIdx.x * gridDim.y + slice) * gridDim.z + blockIdx.z) * (27 * 32 * 64);
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
-        const int tap = (COT == 2) ? (wave >> 1) + 4 * j : wave + 8 * j;
+        const int tap = tap_of(j);
         if (tap < 27) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1340,10 +1366,11 @@ wgrad_x3_kernel(const WgradParams p)
     }
 }
 
-// dW[tap][ci][co] (+)= sum over slabs (fixed order)
+// dW[tap][ci_off + ci][co] (+)= sum over slabs (fixed order); dW has cin_total input-channel rows per tap (a layer's whole
+// Keras kernel), the slabs cover the Cin channels starting at ci_off
 __global__ void __launch_bounds__(TB)
 wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nblk, int nslices, int ncob, int Cin,
-                    int Cout, int accumulate)
+                    int Cout, int accumulate, int cin_total, int ci_off)
 {
     const int64_t total = (int64_t)27 * Cin * Cout;
     for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TB) {
@@ -1354,7 +1381,45 @@ wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int 
         float s = 0.f;
         for (int k = 0; k < nblk; ++k)
             s += slab[((((size_t)k * nslices + slice) * ncob + cob) * 27 + tap) * 2048 + (ci & 31) * 64 + (co & 63)];
-        if (accumulate) dw[i] += s; else dw[i] = s;
+        float* o = dw + ((int64_t)tap * cin_total + ci_off + ci) * Cout + co;
+        if (accumulate) *o += s; else *o = s;
+    }
+}
+
+// Folded wgrad: dW[t][ci][co] (+)= sum over slabs and over the 8 (class, tap bit) pairs whose fold covers original tap t --
+// per axis t = 0: (p, s) = (0, 0), (1, 0); t = 1: (0, 1), (1, 0); t = 2: (0, 1), (1, 1) -- read from slab entry (class p,
+// 27-index p + s).  Fixed summation order; the slabs cover the first C0 input channels of a cin_total-row kernel.
+__global__ void __launch_bounds__(TB)
+wgrad_fold_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nblk, int nslices, int ncob, int C0,
+                         int Cout, int accumulate, int cin_total)
+{
+    const int64_t total = (int64_t)27 * C0 * Cout;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TB) {
+        const int co = (int)(i % Cout);
+        const int ci = (int)((i / Cout) % C0);
+        const int tap = (int)(i / ((int64_t)Cout * C0));
+        const int slice = ci >> 5, cob = co >> 6;
+        const int t3[3] = {tap / 9, (tap / 3) % 3, tap % 3};
+        float s = 0.f;
+        for (int k = 0; k < nblk; ++k) {
+            const float* base = slab + ((((size_t)k * nslices + slice) * ncob + cob) * 8) * (27 * 2048) + (ci & 31) * 64 + (co & 63);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                int cls = 0, tau = 0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const int pick = (m >> (2 - a)) & 1, t = t3[a];
+                    // the two (p, s) pairs covering t on this axis
+                    const int pp = t == 0 ? pick : (t == 1 ? pick : pick);            // p = 0 or 1
+                    const int ss = t == 0 ? 0 : (t == 1 ? 1 - pick : 1);              // t=0: s=0; t=1: (0,1),(1,0); t=2: s=1
+                    cls = (cls << 1) | pp;
+                    tau = tau * 3 + pp + ss;
+                }
+                s += base[((size_t)cls * 27 + tau) * 2048];
+            }
+        }
+        float* o = dw + ((int64_t)tap * cin_total + ci) * Cout + co;
+        if (accumulate) *o += s; else *o = s;
     }
 }
 
@@ -2551,8 +2616,10 @@ extern "C" int64_t mmr_conv3d_k3_wgrad_ws_bytes(int B, int X, int Y, int Z, int 
 
 // dW (Keras layout [27][C0+C1][Cout]) (+)= wgrad of conv(concat([up2(in0)|in0, in1])) given dZ [B,X,Y,Z,Cout]
 static int wgrad_impl(const float* in0, int C0, int up0, const float* in1, int C1, const float* dz, float* dw, void* ws,
-                      int B, int X, int Y, int Z, int Cout, int accumulate, int x3, void* stream)
+                      int B, int X, int Y, int Z, int Cout, int accumulate, int x3, void* stream, int cin_total = 0, int ci_off = 0)
 {
+    if (cin_total == 0) cin_total = C0 + C1;     // dw is the layer's whole kernel [27][cin_total][Cout]; this call fills rows
+    if (ci_off < 0 || ci_off + C0 + C1 > cin_total) return MMR_EINVAL;   // ci_off .. ci_off + C0 + C1 of every tap
     if (!in0 || !dz || !dw || !ws || B < 1 || X < 1 || Y < 1 || Z < 1 || Cout < 1 || C0 < 32 || C0 % 32 || C1 < 0 ||
         C1 % 32 || (C1 > 0 && !in1))
         return MMR_EINVAL;
@@ -2656,7 +2723,75 @@ static int wgrad_impl(const float* in0, int C0, int up0, const float* in1, int C
     int rc = check_launch();
     if (rc) return rc;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(stream_grid((int64_t)27 * (C0 + C1) * Cout, TB)), dim3(TB), 0,
-                       as_stream(stream), (const float*)ws, dw, gx, nslices, ncob, C0 + C1, Cout, accumulate);
+                       as_stream(stream), (const float*)ws, dw, gx, nslices, ncob, C0 + C1, Cout, accumulate, cin_total, ci_off);
+    return check_launch();
+}
+
+// ---- weight gradient of a decoder layer conv(concat([UpSampling3D(2)(x_low) | skip])), folded (see wgrad_x3_kernel FOLD) ---- //
+namespace {
+inline void wgrad_fold_geom(int B, int X2, int Y2, int Z2, int C0, int Cout, int& ntx, int& nty, int& ntz, int& ntiles, int& nslices,
+                            int& ncob, int& gx)
+{
+    ntx = (X2 + W_TX - 1) / W_TX; nty = (Y2 + W_TY - 1) / W_TY; ntz = (Z2 + W_TZ - 1) / W_TZ;
+    ntiles = B * ntx * nty * ntz;
+    nslices = C0 / 32;
+    ncob = Cout / 64;
+    gx = 256 / (nslices * ncob * 8);
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+}
+}  // namespace
+
+extern "C" int64_t mmr_conv3d_k3_wgrad_upfold_ws_bytes(int B, int X2, int Y2, int Z2, int C0, int C1, int Cout)
+{
+    if (B < 1 || X2 < 1 || Y2 < 1 || Z2 < 1 || C0 < 32 || C0 % 32 || C1 < 32 || C1 % 32 || Cout < 64 || Cout % 64) return MMR_EINVAL;
+    int ntx, nty, ntz, ntiles, nslices, ncob, gx;
+    wgrad_fold_geom(B, X2, Y2, Z2, C0, Cout, ntx, nty, ntz, ntiles, nslices, ncob, gx);
+    const int64_t fold = (int64_t)gx * nslices * ncob * 8 * 27 * 2048 * sizeof(float);
+    const int64_t skip = mmr_conv3d_k3_wgrad_ws_bytes(B, 2 * X2, 2 * Y2, 2 * Z2, C1, Cout);
+    return fold > skip ? fold : skip;
+}
+
+// dw [27][C0 + C1][Cout] (+)= the layer's weight gradient given dz [B,2X2,2Y2,2Z2,Cout]: rows [0, C0) from the low-resolution
+// x_low [B,X2,Y2,Z2,C0] through the folded correlation (64 class-tap products over N / 8 voxels instead of 27 over N), rows
+// [C0, C0 + C1) from skip [B,2X2,2Y2,2Z2,C1] through the ordinary kernel.  x3mode 1 = fp32x3, 2 = bf16 hi products only.
+extern "C" int mmr_conv3d_k3_wgrad_upfold(const float* x_low, int C0, const float* skip, int C1, const float* dz, float* dw,
+                                          void* ws, int B, int X2, int Y2, int Z2, int Cout, int accumulate, int x3mode,
+                                          void* stream)
+{
+    if (!x_low || !skip || !dz || !dw || !ws || (x3mode != 1 && x3mode != 2)) return MMR_EINVAL;
+    if (mmr_conv3d_k3_wgrad_upfold_ws_bytes(B, X2, Y2, Z2, C0, C1, Cout) < 0) return MMR_EINVAL;
+    const uint64_t nvl = (uint64_t)B * X2 * Y2 * Z2, lim = 0xF0000000ull - 64;
+    if (nvl * C0 * 4 > lim || nvl * 8 * (uint64_t)Cout * 4 > lim) return MMR_EUNSUPPORTED;   // buffer-descriptor path only
+    // skip half first (it may overwrite its rows), then the folded half into rows [0, C0)
+    int rc = wgrad_impl(skip, C1, 0, nullptr, 0, dz, dw, ws, B, 2 * X2, 2 * Y2, 2 * Z2, Cout, accumulate, x3mode, stream, C0 + C1, C0);
+    if (rc) return rc;
+    WgradParams p;
+    p.in0 = x_low; p.in1 = nullptr; p.dz = dz; p.slab = (float*)ws;
+    p.B = B; p.X = X2; p.Y = Y2; p.Z = Z2; p.C0 = C0; p.C1 = 0; p.up0 = 0; p.Cout = Cout;
+    int nslices, ncob, gx;
+    wgrad_fold_geom(B, X2, Y2, Z2, C0, Cout, p.ntx, p.nty, p.ntz, p.ntiles, nslices, ncob, gx);
+    p.bytes_src[0] = (unsigned)(nvl * C0 * 4);
+    p.bytes_src[1] = 0;
+    p.bytes_dz = (unsigned)(nvl * 8 * (uint64_t)Cout * 4);
+    constexpr int LDSX = WX_A_BYTES + WX_B_BYTES;
+    static bool attr = false;
+    if (!attr) {
+        const void* ks[] = {reinterpret_cast<const void*>(wgrad_x3_kernel<2, true, false, 3, true, true, true>),
+                            reinterpret_cast<const void*>(wgrad_x3_kernel<2, false, false, 3, true, true, true>)};
+        for (size_t i = 0; i < 2; ++i) {
+            hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDSX);
+            if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
+        }
+        attr = true;
+    }
+    const dim3 g3(gx, nslices, ncob * 8), b3(W_THREADS);
+    if (x3mode == 1) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 3, true, true, true>), g3, b3, LDSX, as_stream(stream), p);
+    else hipLaunchKernelGGL((wgrad_x3_kernel<2, false, false, 3, true, true, true>), g3, b3, LDSX, as_stream(stream), p);
+    rc = check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(wgrad_fold_reduce_kernel, dim3(stream_grid((int64_t)27 * C0 * Cout, TB)), dim3(TB), 0, as_stream(stream),
+                       (const float*)ws, dw, gx, nslices, ncob, C0, Cout, accumulate, C0 + C1);
     return check_launch();
 }
 

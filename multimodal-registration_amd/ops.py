@@ -848,6 +848,43 @@ def conv3d_k3_wgrad(in0, dz, dw, in1=None, up0=False, accumulate=False, x3=False
     return dw
 
 
+def wgrad_upfold_supported(C0, C1, Cout, x3, B, X, Y, Z):
+    """The folded weight gradient (mmr_conv3d_k3_wgrad_upfold) serves a decoder layer conv(concat([up2(x_low), skip])) when the
+    products are bf16 splits (x3 True or 'hi'), the widths fit, the tensors stay under the 3.75-GB buffer-descriptor range and
+    the low-resolution volume has enough voxel tiles to keep 256 persistent workgroups busy.  X, Y, Z: full resolution."""
+    if not x3 or C0 % 32 or C1 % 32 or C0 < 32 or C1 < 32 or Cout % 64 or (X | Y | Z) & 1:
+        return False
+    nv = B * X * Y * Z
+    if nv * max(Cout, C1) * 4 > 0xF0000000 - 64:
+        return False
+    tiles_low = B * (-(-(X // 2) // 4)) * (-(-(Y // 2) // 8)) * (-(-(Z // 2) // 8))
+    return tiles_low >= 256
+
+
+def conv3d_k3_wgrad_upfold(x_low, skip, dz, dw, accumulate=False, x3=True):
+    """dw [3,3,3,C0+C1,Cout] (+)= weight gradient of conv(concat([UpSampling3D(2)(x_low), skip])) given dz: the upsampled rows
+    through the folded correlation on the low-resolution grid, the skip rows through the ordinary kernel."""
+    _chk(x_low, torch.float32, "x_low")
+    _chk(skip, torch.float32, "skip")
+    _chk(dz, torch.float32, "dz")
+    _chk(dw, torch.float32, "dw")
+    B, X, Y, Z, Cout = dz.shape
+    C0, C1 = x_low.shape[-1], skip.shape[-1]
+    if tuple(x_low.shape[:4]) != (B, X // 2, Y // 2, Z // 2) or tuple(skip.shape[:4]) != (B, X, Y, Z):
+        raise _lib.MmrError("wgrad_upfold: x_low / skip shapes do not match dz")
+    if tuple(dw.shape) != (3, 3, 3, C0 + C1, Cout):
+        raise _lib.MmrError(f"wgrad_upfold: dw {tuple(dw.shape)} != {(3, 3, 3, C0 + C1, Cout)}")
+    lib = _lib.load()
+    ws = _ws(lib.mmr_conv3d_k3_wgrad_upfold_ws_bytes(B, X // 2, Y // 2, Z // 2, C0, C1, Cout), dz.device)
+    name = "conv3d_k3_wgrad_mfma_" + ("f32x1" if x3 == "hi" else "f32x3")
+    # one timed family for the pair; algorithmic flops = the 27-tap count of the whole layer, executed = C1 rows + 8/27 of the C0 rows
+    with _Timed(name + "_upfold", (C0 + C1, Cout, X, Y, Z), 2.0 * 27 * (C0 + C1) * Cout * B * X * Y * Z):
+        rc = lib.mmr_conv3d_k3_wgrad_upfold(x_low.data_ptr(), C0, skip.data_ptr(), C1, dz.data_ptr(), dw.data_ptr(), ws.data_ptr(),
+                                            B, X // 2, Y // 2, Z // 2, Cout, int(accumulate), 2 if x3 == "hi" else 1, _stream())
+    _lib.check(rc, "mmr_conv3d_k3_wgrad_upfold")
+    return dw
+
+
 def conv3d_k3_cin2_wgrad(src, trg, dz, dw, accumulate=False, x3=False):
     B, X, Y, Z, Cout = dz.shape
     lib = _lib.load()

@@ -188,7 +188,11 @@ class SynthMorphTrainer:
                     dz = dy
                 else:
                     dz = ops.leaky_bwd_bias_(y if leaky else None, dy, self.g[2 * li + 1], leaky=leaky)
-                ops.conv3d_k3_wgrad(x, dz, self.g[2 * li], in1=in1, up0=up0, x3=self.bwd_x3)
+                if (up0 and in1 is not None and m.fold_upsampling
+                        and ops.wgrad_upfold_supported(x.shape[-1], in1.shape[-1], dz.shape[-1], self.bwd_x3, *dz.shape[:4])):
+                    ops.conv3d_k3_wgrad_upfold(x, in1, dz, self.g[2 * li], x3=self.bwd_x3)   # upsampled rows on the low-res grid
+                else:
+                    ops.conv3d_k3_wgrad(x, dz, self.g[2 * li], in1=in1, up0=up0, x3=self.bwd_x3)
                 C0 = x.shape[-1]
                 C1 = in1.shape[-1] if in1 is not None else 0
                 plain = in1 is None and not up0

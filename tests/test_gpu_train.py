@@ -659,7 +659,43 @@ def test_folded_training_step_matches_unfolded(dev):
         grads[fold] = [g.clone() for g in tr.g]
         assert torch.isfinite(out["loss"])
     assert any(f.endswith("_upfold") for f in used[True]) and any(f.endswith("_dgfold") for f in used[True])
+    assert any(f.startswith("conv3d_k3_wgrad") and f.endswith("_upfold") for f in used[True])
     assert not any(f.endswith("_upfold") or f.endswith("_dgfold") for f in used[False])
     for i, (a, b) in enumerate(zip(grads[True], grads[False])):
         err = _rel(a, b)
         assert err < 2e-4, f"gradient tensor {i}: folded vs unfolded {err:.2e}"
+
+
+@pytest.mark.parametrize("shape,C0,C1,Cout", [((8, 16, 16), 64, 64, 64), ((12, 20, 28), 32, 64, 128), ((4, 4, 6), 64, 32, 64),
+                                              ((10, 14, 18), 64, 64, 64)])
+@pytest.mark.parametrize("x3", [True, "hi"])
+def test_folded_wgrad_of_concat_layer(dev, shape, C0, C1, Cout, x3):
+    """mmr_conv3d_k3_wgrad_upfold vs float64 autograd of conv(concat([UpSampling3D(2)(x_low), skip])) w.r.t. the kernel: all
+    27 x (C0 + C1) x Cout entries -- the upsampled rows through the per-class correlations on the low-resolution grid, the skip
+    rows through the ordinary kernel -- plain and accumulated onto an existing gradient.  Ragged and odd low-res sizes."""
+    import mmr
+    import torch.nn.functional as F
+    ops = mmr.ops
+    rng = np.random.default_rng(hash((shape, C0, C1, Cout)) % 2 ** 31)
+    X, Y, Z = shape
+    B = 2 if np.prod(shape) < 600 else 1
+    xl = rng.standard_normal((B, X // 2, Y // 2, Z // 2, C0)).astype(np.float32)
+    sk = rng.standard_normal((B, X, Y, Z, C1)).astype(np.float32)
+    dz = rng.standard_normal((B, X, Y, Z, Cout)).astype(np.float32)
+    wt = torch.zeros((3, 3, 3, C0 + C1, Cout), dtype=torch.float64, requires_grad=True)
+    up = torch.from_numpy(xl).double().repeat_interleave(2, 1).repeat_interleave(2, 2).repeat_interleave(2, 3)
+    cat = torch.cat([up, torch.from_numpy(sk).double()], -1)
+    y = F.conv3d(cat.permute(0, 4, 1, 2, 3), wt.permute(4, 3, 0, 1, 2), padding=1).permute(0, 2, 3, 4, 1)
+    (y * torch.from_numpy(dz).double()).sum().backward()
+    ref = wt.grad.numpy()
+    dw = torch.zeros((3, 3, 3, C0 + C1, Cout), device=dev)
+    ops.conv3d_k3_wgrad_upfold(_t(xl, dev), _t(sk, dev), _t(dz, dev), dw, x3=x3)
+    tol = 2e-5 if x3 is True else 1.5e-2
+    assert _rel(dw[:, :, :, :C0], ref[:, :, :, :C0]) < tol, ("upsampled rows", _rel(dw[:, :, :, :C0], ref[:, :, :, :C0]))
+    assert _rel(dw[:, :, :, C0:], ref[:, :, :, C0:]) < tol, ("skip rows", _rel(dw[:, :, :, C0:], ref[:, :, :, C0:]))
+    ops.conv3d_k3_wgrad_upfold(_t(xl, dev), _t(sk, dev), _t(dz, dev), dw, accumulate=True, x3=x3)
+    assert _rel(dw, 2 * ref) < tol
+    # and against the one-launch kernel with the upsampling folded into its loader
+    one = torch.zeros_like(dw)
+    ops.conv3d_k3_wgrad(_t(xl, dev), _t(dz, dev), one, in1=_t(sk, dev), up0=True, x3=x3)
+    assert _rel(dw, 2 * one) < (2e-5 if x3 is True else 2e-2)
