@@ -858,7 +858,7 @@ def wgrad_upfold_supported(C0, C1, Cout, x3, B, X, Y, Z):
     if nv * max(Cout, C1) * 4 > 0xF0000000 - 64:
         return False
     tiles_low = B * (-(-(X // 2) // 4)) * (-(-(Y // 2) // 8)) * (-(-(Z // 2) // 8))
-    return tiles_low >= 256
+    return tiles_low >= 256   # measured: at 250 low-res tiles (80^3 layer of C3) the folded pair is 0.1 ms slower than the one-launch kernel
 
 
 def conv3d_k3_wgrad_upfold(x_low, skip, dz, dw, accumulate=False, x3=True):
