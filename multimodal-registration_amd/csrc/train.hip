@@ -1015,8 +1015,9 @@ template <int N> struct IC { static constexpr int value = N; };
 // FOLD (round 3): the weight gradient of the UPSAMPLED half of a decoder layer, one parity class per workgroup.  With the
 // folded weights Wf[p][s] (conv3d.hip, CV_UPFOLD) dWf[p][s] = sum_i x_low[i - 1 + p + s] (x) dz[2 i + p]: a correlation on the
 // LOW-resolution grid between x_low (haloed tile, halo offset p + s per axis: one of the 27 ordinary tap offsets) and the class's
-// sub-lattice of the full-resolution dz.  blockIdx.z = cob * 8 + class; the 8 (p, s) pairs of the class are spread over the four
-// wave pairs (two accumulator tiles per wave instead of seven), p.X / Y / Z are the low-resolution dims, dz is addressed at
+// sub-lattice of the full-resolution dz.  blockIdx.z = cob * 2 + class group; a workgroup takes FOUR classes per voxel tile (x_low
+// staged once, then per class its dz tile and a k-loop); the 8 (p, s) pairs of a class are spread over the four wave pairs (two
+// accumulator tiles per wave and class, eight in all instead of seven), p.X / Y / Z are the low-resolution dims, dz is addressed at
 // 2 i + p of a [B, 2X, 2Y, 2Z, Cout] tensor, and the slab keeps the 27-tap layout (entry p + s).  wgrad_fold_reduce_kernel then
 // adds every dWf[p][s] to the original taps it covers.  64 (class, tap) correlations over N / 8 voxels instead of 27 over N.
 template <int COT, bool LO, bool STAMP = false, int PF = 3, bool FULLCO = false, bool BUF = false, bool FOLD = false>
@@ -1026,18 +1027,20 @@ wgrad_x3_kernel(const WgradParams p)
     constexpr bool PFX = (PF & 1) != 0, PFZ = (PF & 2) != 0;
     unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st_t = 0;
     static_assert(!FOLD || (COT == 2 && FULLCO && BUF), "folded wgrad: 64-column blocks, buffer loads");
-    constexpr int NU = FOLD ? 2 : (COT == 2) ? 7 : 4;
+    constexpr int FNC = 4;                                  // FOLD: parity classes per workgroup (two accumulator tiles per wave each)
+    constexpr int NU = FOLD ? 2 * FNC : (COT == 2) ? 7 : 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sX = smem;
     char* sZ = smem + WX_A_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int slice = blockIdx.y, cob = FOLD ? (int)blockIdx.z >> 3 : (int)blockIdx.z;
-    const int fcls = FOLD ? (int)blockIdx.z & 7 : 0;     // parity class (px, py, pz) = bits 2, 1, 0
-    // tap (27-index = halo offset) of accumulator tile j of this wave
+    const int slice = blockIdx.y, cob = FOLD ? (int)blockIdx.z >> 1 : (int)blockIdx.z;
+    const int fcls0 = FOLD ? ((int)blockIdx.z & 1) * FNC : 0;   // FOLD: this workgroup's parity classes fcls0 .. fcls0 + 3
+    // tap (27-index = halo offset) of accumulator tile j of this wave; FOLD: tile j belongs to class fcls0 + (j >> 1)
     auto tap_of = [&](int j) -> int {
         if constexpr (FOLD) {
-            const int tb = (wave >> 1) + 4 * j;          // (sx, sy, sz) = bits 2, 1, 0
+            const int fcls = fcls0 + (j >> 1);           // (px, py, pz) = bits 2, 1, 0
+            const int tb = (wave >> 1) + 4 * (j & 1);    // (sx, sy, sz) = bits 2, 1, 0
             return ((((fcls >> 2) & 1) + ((tb >> 2) & 1)) * 3 + ((fcls >> 1) & 1) + ((tb >> 1) & 1)) * 3 + (fcls & 1) + (tb & 1);
         } else {
             return (COT == 2) ? (wave >> 1) + 4 * j : wave + 8 * j;
@@ -1187,7 +1190,7 @@ wgrad_x3_kernel(const WgradParams p)
             if constexpr (LO) *reinterpret_cast<u32x4_t*>(sX + row * 128 + ((1 ^ sw) << 6) + c * 16) = v.b;
         }
     };
-    auto load_z = [&](int tv, int b, int x0, int y0, int z0, int it) -> u32x4_t {
+    auto load_z = [&](int tv, int b, int x0, int y0, int z0, int it, int fcls = 0) -> u32x4_t {
         const int i = tv + it * W_THREADS;
         const int v = i >> 4, c4 = i & 15;
         const int gx = x0 + (v >> 6), gy = y0 + ((v >> 3) & 7), gz = z0 + (v & 7);
@@ -1255,6 +1258,74 @@ wgrad_x3_kernel(const WgradParams p)
     // the arithmetic (a few hundred VALU per 45 k-cycle tile) is redone where it is needed and nothing stays live.
     auto opaque_tid = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t; };
     int tile = blockIdx.x;
+    if constexpr (FOLD) {
+        // Four classes per workgroup and voxel tile: the x_low tile is staged once, then per class its dz sub-lattice tile and a
+        // k-loop over the class's two accumulator tiles.  The next operand tile (dz of the next class, or x_low + dz of the next
+        // voxel tile) is prefetched into registers under each k-loop.
+        if (tile < p.ntiles) {
+            const int tv = opaque_tid();
+            int b, x0, y0, z0;
+            tile_origin(tile, b, x0, y0, z0);
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) px[it] = load_x(tv, b, x0, y0, z0, it);
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it) pz[it] = load_z(tv, b, x0, y0, z0, it, fcls0);
+        }
+        for (; tile < p.ntiles; tile += gridDim.x) {
+            int b, x0, y0, z0;
+            tile_origin(tile, b, x0, y0, z0);
+            const int nxt = tile + gridDim.x;
+            int nb = 0, nx0 = 0, ny0 = 0, nz0 = 0;
+            if (nxt < p.ntiles) tile_origin(nxt, nb, nx0, ny0, nz0);
+            __syncthreads();          // the previous tile's last k-loop is done with sX and sZ
+            {
+                const int tv = opaque_tid();
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it) store_x(tv, it, convert_x(it, px[it]));
+            }
+            auto one_class = [&](auto cc) {
+                constexpr int C = decltype(cc)::value;
+                if constexpr (C > 0) __syncthreads();     // class C - 1's k-loop is done with sZ
+                {
+                    const int tv = opaque_tid();
+#pragma unroll
+                    for (int it = 0; it < B_IT; ++it) store_z(tv, it, convert_z(it, pz[it]));
+                }
+                __syncthreads();
+                {
+                    const int tv2 = opaque_tid();
+                    if constexpr (C + 1 < FNC) {
+#pragma unroll
+                        for (int it = 0; it < B_IT; ++it) pz[it] = load_z(tv2, b, x0, y0, z0, it, fcls0 + C + 1);
+                    } else if (nxt < p.ntiles) {
+#pragma unroll
+                        for (int it = 0; it < A_IT; ++it) px[it] = load_x(tv2, nb, nx0, ny0, nz0, it);
+#pragma unroll
+                        for (int it = 0; it < B_IT; ++it) pz[it] = load_z(tv2, nb, nx0, ny0, nz0, it, fcls0);
+                    }
+                }
+#pragma unroll 1
+                for (int kb = 0; kb < 16; ++kb) {
+                    const char* xa = sX + ((kb >> 2) * (W_HY * W_HZ) + (kb & 3) * 2 * W_HZ) * 128;
+                    const char* zb = sZ + kb * 16 * 256;
+                    const bf16x8_t b_hi = frag8(tr_read(zb + laneBh[0]), tr_read(zb + laneBh[1]));
+                    bf16x8_t b_lo = b_hi;
+                    if constexpr (LO) b_lo = frag8(tr_read(zb + laneBl[0]), tr_read(zb + laneBl[1]));
+#pragma unroll
+                    for (int j = 2 * C; j < 2 * C + 2; ++j) {
+                        const bf16x8_t a_hi = frag8(tr_read(xa + laneA[0] + offA_hi[j]), tr_read(xa + laneA[1] + offA_hi[j]));
+                        if constexpr (LO) {
+                            const bf16x8_t a_lo = frag8(tr_read(xa + laneA[0] + offA_lo[j]), tr_read(xa + laneA[1] + offA_lo[j]));
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[j], 0, 0, 0);
+                        }
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[j], 0, 0, 0);
+                    }
+                }
+            };
+            one_class(IC<0>{}); one_class(IC<1>{}); one_class(IC<2>{}); one_class(IC<3>{});
+        }
+    } else {
     if (tile < p.ntiles) {
         const int tv = opaque_tid();
         int b, x0, y0, z0;
@@ -1345,6 +1416,7 @@ wgrad_x3_kernel(const WgradParams p)
         k_range(0, 16);
         if constexpr (STAMP) { const unsigned long long t = wstamp_now(); st_acc[3] += t - st_t; st_acc[4] += 1; }
     }
+    }   // !FOLD
     if constexpr (STAMP) {
         if (lane == 0) {
 #pragma unroll
@@ -1352,9 +1424,11 @@ wgrad_x3_kernel(const WgradParams p)
         }
     }
     // slab[blk][slice][cob (FOLD: cob * 8 + class)][27 taps][32 ci][64 co]
-    float* out = p.slab + (((size_t)blockIdx.x * gridDim.y + slice) * gridDim.z + blockIdx.z) * (27 * 32 * 64);
+    const int zcount = FOLD ? (int)gridDim.z * FNC : (int)gridDim.z;     // FOLD: gridDim.z = 2 cob blocks of 4 classes each
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
+        const int zi = FOLD ? cob * 8 + fcls0 + (j >> 1) : (int)blockIdx.z;
+        float* out = p.slab + (((size_t)blockIdx.x * gridDim.y + slice) * zcount + zi) * (27 * 32 * 64);
         const int tap = tap_of(j);
         if (tap < 27) {
 #pragma unroll
@@ -2736,7 +2810,7 @@ inline void wgrad_fold_geom(int B, int X2, int Y2, int Z2, int C0, int Cout, int
     ntiles = B * ntx * nty * ntz;
     nslices = C0 / 32;
     ncob = Cout / 64;
-    gx = 256 / (nslices * ncob * 8);
+    gx = 256 / (nslices * ncob * 2);   // two workgroups (four parity classes each) per (voxel-tile run, slice, cob)
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
 }
@@ -2785,7 +2859,7 @@ extern "C" int mmr_conv3d_k3_wgrad_upfold(const float* x_low, int C0, const floa
         }
         attr = true;
     }
-    const dim3 g3(gx, nslices, ncob * 8), b3(W_THREADS);
+    const dim3 g3(gx, nslices, ncob * 2), b3(W_THREADS);
     if (x3mode == 1) hipLaunchKernelGGL((wgrad_x3_kernel<2, true, false, 3, true, true, true>), g3, b3, LDSX, as_stream(stream), p);
     else hipLaunchKernelGGL((wgrad_x3_kernel<2, false, false, 3, true, true, true>), g3, b3, LDSX, as_stream(stream), p);
     rc = check_launch();
