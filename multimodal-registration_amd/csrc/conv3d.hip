@@ -112,20 +112,6 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 // the gradient lands compact at low resolution (no full-resolution intermediate, no 2x2x2 pooling pass), and the masked
 // epilogue (LeakyReLU backward + bias sums of the layer that produced x) applies unchanged.  fp32x3 / x1 tensors only.
 constexpr int CV_DGFOLD = 1 << 19;
-// bf16 256-column tile: the K walk in 32-channel HALF-slices.  The haloed A tile becomes two 600 x 64-B buffers (the same
-// LDS as one 128-B slice), one (half-slice, tap) step is one k = 32 MFMA pass, a barrier closes a PAIR of consecutive steps
-// (64 MFMAs per wave, the weight block of a pair is the same 32 KB), and the next-but-one half-slice is DMA'd into the
-// buffer that has just been freed WHILE the other one is being multiplied: one 16-B item per thread and pair, issued from
-// inside the MFMA stream and retired one pair later (`s_waitcnt vmcnt(items of this pair)`).  The synchronous restage of
-// the 128-B kernel (every wave idle for one global round trip per slice: 4.5 % of a 27-tap slice, 21 % of an 8-tap
-// one) is gone.  Row -> source offsets are computed once per workgroup and kept in LDS (thread-private table); rows
-// outside the volume are zeroed once and never written again.  Swizzle of the 64-B rows: chunk ^ ((hy & 1) << 1).
-constexpr int CV_H32 = 1 << 20;
-#ifdef MMR_H32
-constexpr bool kH32 = true;     // bf16 / 256 columns: kernel AND weight image (pack_kernel's half_order) switch together
-#else
-constexpr bool kH32 = false;    // measured 4.5 % slower than the 128-B kernel: not the default
-#endif
 
 #ifdef MMR_DIAG
 int g_diag_stamps = 0;   // host switch of the stamped instantiations (conv and wgrad), set by mmr_debug_set_stamps
@@ -247,10 +233,6 @@ conv3d_k3_kernel(const ConvParams p)
     constexpr bool CINIT = (VAR & CV_CINIT) != 0;
     constexpr bool PART16 = (VAR & CV_PART16) != 0;
     constexpr bool DGF = (VAR & CV_DGFOLD) != 0;
-    constexpr bool H32 = (VAR & CV_H32) != 0;
-    static_assert(!H32 || (DT == MMR_DT_BF16 && MT == 4 && NT == 2 && WN == 4 && ((VAR & CV_M16) != 0) && ((VAR & CV_PIPE) != 0) && !DGF),
-                  "half-slice pipeline: the bf16 256-column tile");
-    constexpr int H_ROWB = 64, H_PADROWS = 640, H_BUF = H_PADROWS * H_ROWB;   // CV_H32: A buffer = 600 rows + pad, 64 B each
     static_assert(!DGF || (!UPF && !CINIT && ((VAR & CV_M16) != 0) && ((VAR & CV_BATCHA) != 0) &&
                            (DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1)), "dgrad fold: fp32x3 / x1, batched staging");
     constexpr int TAPS = (UPF || ((VAR & CV_DGFOLD) != 0)) ? 8 : 27;
@@ -270,7 +252,7 @@ conv3d_k3_kernel(const ConvParams p)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
-    char* sB = smem + (H32 ? 2 * H_BUF : A_BYTES_T);
+    char* sB = smem + A_BYTES_T;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -565,228 +547,6 @@ conv3d_k3_kernel(const ConvParams p)
             _Pragma("unroll") for (int it = 0; it < A_ITERS; ++it) store_a(it, load_a(sl, it)); \
         } \
     } while (0)
-    if constexpr (H32) {
-        // ---- CV_H32: half-slices of 32 channels, two A buffers, a barrier per pair of (half-slice, tap) steps ----
-        constexpr int NIT = H_PADROWS * 4 / CONV_THREADS;        // 16-B DMA items per thread and half-slice, all 8 waves (5)
-        // In the loop the items are issued by waves 4-7 ONLY (10 per lane): they never issue a weight DMA, so nothing newer
-        // than an A item ever has to be waited for (vmcnt retires in order) and the items may stay in flight until the pair
-        // before the buffer's first use -- several pairs of slack instead of one global round trip per pair.
-        constexpr int NITW = 2 * NIT;
-#if defined(MMR_H32_EXP) && MMR_H32_EXP == 8
-        constexpr int NPP = (TAPS == 8) ? 4 : 10;
-#elif defined(MMR_H32_EXP) && MMR_H32_EXP == 9
-        constexpr int NPP = (TAPS == 8) ? 4 : 2;
-#else
-        constexpr int NPP = (TAPS == 8) ? 4 : 1;                 // items per pair and lane (an 8-tap half-slice lasts 4 pairs)
-#endif
-        constexpr int NEVER = 0x7fffffff;
-        static_assert(H_PADROWS * 4 % CONV_THREADS == 0 && H_PADROWS >= HROWS_T, "pad rows");
-        unsigned* tab = reinterpret_cast<unsigned*>(sB + 2 * B_BYTES);   // entry of item i = (row, chunk position) at [i]
-        const int ox = x0 > 0 ? x0 - 1 : 0, oy = y0 > 0 ? y0 - 1 : 0, oz = z0 > 0 ? z0 - 1 : 0;   // first in-volume halo voxel
-        // one input, read directly, and every halo row within a 32-bit byte offset of the tile origin: asynchronous staging
-        const bool simple = p.C1 == 0 && !p.up0 && (long long)HXT * p.Y * p.Z * p.C0 * 2 < (1ll << 32) - 64;
-        // entry of a (row, chunk position) item = byte offset of its SOURCE chunk from the tile origin's channel 0 (the swizzle is
-        // applied to the source, as in dma_stage_a); ~0 = row outside the volume (or a pad row): those are zeroed here, in
-        // both buffers, and never written again
-        const unsigned cs2 = (unsigned)p.C0 * 2u;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * CONV_THREADS;
-            const int row = i >> 2, cpos = i & 3;
-            const int hx = row / (HY * HZ), hy = (row / HZ) % HY, hz = row % HZ;
-            const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
-            const bool ok = row < HROWS_T && gx >= 0 && gx < p.X && gy >= 0 && gy < p.Y && gz >= 0 && gz < p.Z;
-            const unsigned rel = (unsigned)(((gx - ox) * p.Y + (gy - oy)) * p.Z + (gz - oz));
-            tab[i] = ok ? rel * cs2 + (unsigned)((cpos ^ ((hy & 1) << 1)) << 4) : 0xffffffffu;
-            if (!ok) {
-                *reinterpret_cast<uint4*>(sA + i * 16) = make_uint4(0, 0, 0, 0);
-                *reinterpret_cast<uint4*>(sA + H_BUF + i * 16) = make_uint4(0, 0, 0, 0);
-            }
-        }
-        const char* abase = p.in0 + ((((size_t)b * p.X + ox) * p.Y + oy) * p.Z + oz) * (size_t)p.C0 * 2;
-        // one DMA instruction (the lanes whose row is in the volume): wave-uniform source base and LDS destination of lane 0
-        auto stage_item = [&](const char* sbase, unsigned lds_dst, unsigned e) {
-            if (e != 0xffffffffu) {
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep)
-                             : "v"(e), "s"(sbase), "s"(lds_dst)
-                             : "memory");
-            }
-        };
-        // the general form (concat of two inputs, nearest-upsampled first input): addresses from scratch, used synchronously
-        auto stage_sync = [&](int hs) {
-            const int ch0 = hs * 32;
-            const bool first = ch0 < p.C0;
-            const char* src = first ? p.in0 : p.in1;
-            const int Cs = first ? p.C0 : p.C1;
-            const int chs = first ? ch0 : ch0 - p.C0;
-            const bool up = first && p.up0;
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int i = tid + it * CONV_THREADS;
-                const int row = i >> 2, cpos = i & 3;
-                const int hx = row / (HY * HZ), hy = (row / HZ) % HY, hz = row % HZ;
-                const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
-                if (row < HROWS_T && gx >= 0 && gx < p.X && gy >= 0 && gy < p.Y && gz >= 0 && gz < p.Z) {
-                    size_t vox;
-                    if (up) vox = (((size_t)b * X2 + (gx >> 1)) * Y2 + (gy >> 1)) * Z2 + (gz >> 1);
-                    else vox = (((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz;
-                    glds16(src + (vox * Cs + chs) * 2 + ((cpos ^ ((hy & 1) << 1)) << 4),
-                           __builtin_amdgcn_readfirstlane(sA_lds + (hs & 1) * H_BUF + (it * CONV_THREADS + wave * 64) * 16));
-                }
-            }
-        };
-        auto stage = [&](int hs) {   // prologue: every wave its own 5 items
-            if (simple) {
-#pragma unroll
-                for (int it = 0; it < NIT; ++it)
-                    stage_item(abase + (size_t)hs * 64, sA_lds + (hs & 1) * H_BUF + (it * CONV_THREADS + wave * 64) * 16,
-                               tab[it * CONV_THREADS + tid]);
-            } else {
-                stage_sync(hs);
-            }
-        };
-        int hsA = (2 * g0) / TAPS, tapA = (2 * g0) % TAPS;       // step 0 of the current pair
-        const int hs_end = (2 * g1 - 1) / TAPS + 1;              // this block walks the half-slices [hsA, hs_end)
-        stage(hsA);
-        if (hsA + 1 < hs_end) stage(hsA + 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // Staging state (wave-uniform).  Half-slice st_hs goes into the buffer of st_hs - 2, free once every step of that one
-        // lies in an earlier pair: from pair st_first on, NPP items per pair (27 taps: 10 of the >= 12 pairs in front of the
-        // buffer's first use; 8 taps: pairs 0-2 of 4); waves 4-7 wait for them at the end of pair wait_pair, the one in front
-        // of that first use.
-        auto first_pair_of = [&](int hs) { return hs < hs_end ? ((hs - 1) * TAPS + 1) >> 1 : NEVER; };
-        int st_hs = hsA + 2, st_first = first_pair_of(st_hs), st_it = 0, wait_pair = -1;
-        const int li = tid & 255;                                // lane index among waves 4-7
-        // tap table in a VGPR: lane t holds halo byte offset (64-B rows) | dy parity << 16 of tap t, read with v_readlane
-        unsigned tinfo;
-        {
-            const int t = lane < TAPS ? lane : 0;
-            const int dx = UPF ? ((cls >> 2) & 1) + ((t >> 2) & 1) : t / 9;
-            const int dy = UPF ? ((cls >> 1) & 1) + ((t >> 1) & 1) : (t / 3) % 3;
-            const int dz = UPF ? (cls & 1) + (t & 1) : t % 3;
-            tinfo = (unsigned)((dx * (HY * HZ) + dy * HZ + dz) * H_ROWB) | ((unsigned)(dy & 1) << 16);
-        }
-        // this lane's fragment address inside a buffer for M-tile 0 at halo offset 0, for even / odd dy (swizzle (hy & 1) << 1)
-        const int a0h = (((wm * MT >> 1) * HY + (r16 >> 3)) * HZ + (r16 & 7)) * H_ROWB;
-        const int cch = (q16 ^ ((r16 >> 3) << 1)) << 4;
-        const char* pe = sA + a0h + cch;
-        const char* po = sA + a0h + (cch ^ 32);
-
-        for (int g = g0; g < g1; ++g) {
-            const bool more = g + 1 < g1;
-            int tapB = tapA + 1, hsB = hsA;
-            if (tapB == TAPS) { tapB = 0; ++hsB; }
-            const unsigned iA = __builtin_amdgcn_readlane(tinfo, tapA), iB = __builtin_amdgcn_readlane(tinfo, tapB);
-            const char* pa0 = ((iA >> 16) ? po : pe) + ((iA & 0xffffu) + (hsA & 1) * H_BUF);
-            const char* pa1 = ((iB >> 16) ? po : pe) + ((iB & 0xffffu) + (hsB & 1) * H_BUF);
-            const char* pb = sB + cur * B_BYTES + b16_off[0];
-#if defined(MMR_H32_EXP) && MMR_H32_EXP == 6
-            const bool win = false;
-#else
-            const bool win = simple && g >= st_first;
-#endif
-            unsigned en[NPP];
-            if (wave >= 4) {
-#pragma unroll
-                for (int k = 0; k < NPP; ++k) {
-                    const int j = st_it + k < NITW ? st_it + k : NITW - 1;
-                    en[k] = tab[j * 256 + li];                   // consumed at the issue point (no wait here)
-                }
-            }
-            uint4 fa[2][8], fb[2][4];
-            // fragment i in consumption order: B of step 0 (4), A of step 0 (8), B of step 1 (4), A of step 1 (8)
-            auto rd = [&](int i) {
-                if (i < 4) fb[0][i] = *reinterpret_cast<const uint4*>(pb + i * 256);
-                else if (i < 12) { const int mi = i - 4; fa[0][mi] = *reinterpret_cast<const uint4*>(pa0 + (((mi >> 2) * HY + ((mi >> 1) & 1) * 4 + 2 * (mi & 1)) * HZ) * H_ROWB); }
-                else if (i < 16) { const int ni = i - 12; fb[1][ni] = *reinterpret_cast<const uint4*>(pb + ni * 256 + 4 * BN * 16); }
-                else { const int mi = i - 16; fa[1][mi] = *reinterpret_cast<const uint4*>(pa1 + (((mi >> 2) * HY + ((mi >> 1) & 1) * 4 + 2 * (mi & 1)) * HZ) * H_ROWB); }
-            };
-            auto mm = [&](int j) {   // MFMA j: step j / 32, A tile (j / 4) % 8, B fragment j % 4
-                const int ks = j >> 5, mi = (j >> 2) & 7, ni = j & 3;
-                acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8, fb[ks][ni]), __builtin_bit_cast(bf16x8, fa[ks][mi]), acc16[mi][ni], 0, 0, 0);
-            };
-            // the schedule of the 128-B kernel (MIDDMA): MFMA groups 0..3 | waves 0-3 issue their weight pieces, waves 4-7 their
-            // A items | groups 4..9 | waves 0-3 issue the weight pieces of waves 4-7 | groups 10..15
-#pragma unroll
-            for (int i = 0; i < 12; ++i) rd(i);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) mm(j);
-            __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#if defined(MMR_H32_EXP) && MMR_H32_EXP == 7
-            if (more && wave < 4) issue_b(g + 1, cur ^ 1);
-#else
-            if (wave < 4) {
-                if (more) issue_b(g + 1, cur ^ 1);
-            } else if (win) {
-                const char* sb = abase + (size_t)st_hs * 64;
-                const unsigned dst = sA_lds + (st_hs & 1) * H_BUF + (st_it * 256 + (wave - 4) * 64) * 16;
-#pragma unroll
-                for (int k = 0; k < NPP; ++k)
-                    if (st_it + k < NITW) stage_item(sb, dst + k * 4096, en[k]);
-            }
-#endif
-#pragma unroll
-            for (int i = 12; i < 21; ++i) rd(i);
-#pragma unroll
-            for (int j = 16; j < 40; ++j) mm(j);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            if (more && wave < 4) issue_b(g + 1, cur ^ 1, wave + 4);
-#pragma unroll
-            for (int i = 21; i < 24; ++i) rd(i);
-#pragma unroll
-            for (int j = 40; j < 64; ++j) mm(j);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-#if defined(MMR_H32_EXP) && MMR_H32_EXP == 7
-            if (wave >= 4 && win) {
-                const char* sb = abase + (size_t)st_hs * 64;
-                const unsigned dst = sA_lds + (st_hs & 1) * H_BUF + (st_it * 256 + (wave - 4) * 64) * 16;
-#pragma unroll
-                for (int k = 0; k < NPP; ++k)
-                    if (st_it + k < NITW) stage_item(sb, dst + k * 4096, en[k]);
-            }
-#endif
-            // waves 0-3: the weight pieces of pair g + 1 have landed.  Waves 4-7 (A items only) wait in front of the first use
-            if (wave < 4 || g == wait_pair) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            cur ^= 1;
-            if (win) {
-                st_it += NPP;
-                if (st_it >= NITW) {
-                    wait_pair = (st_hs * TAPS) / 2 - 1;
-                    st_it = 0;
-                    ++st_hs;
-                    st_first = first_pair_of(st_hs);
-                }
-            }
-            tapA += 2;
-            if (tapA >= TAPS) { tapA -= TAPS; ++hsA; }
-            if (!simple && more && g + 1 >= st_first) {   // two inputs / upsampled input: synchronous refill of the freed buffer
-                stage_sync(st_hs);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                ++st_hs;
-                st_first = first_pair_of(st_hs);
-            }
-        }
-    } else {
     if constexpr (DMA_A) {
         dma_stage_a(s);
     } else {
@@ -1008,7 +768,6 @@ conv3d_k3_kernel(const ConvParams p)
             }
         }
     }
-    }   // !H32
 #ifdef MMR_DIAG
     if constexpr (STAMP) {
         if (lane == 0) {
@@ -1278,7 +1037,7 @@ __host__ __device__ inline int conv_cout_of_col(int col)
 
 template <int DT>
 __global__ void pack_kernel(const float* __restrict__ w, char* __restrict__ wp, int Cin, int Cout, int BN, int ntiles,
-                            int transpose_flip, int plain_cols, int half_order)
+                            int transpose_flip, int plain_cols)
 {
     constexpr int KC = Elt<DT>::kc;
     constexpr int EPC = (DT == MMR_DT_F32) ? 4 : 8;  // elements per 16-B chunk (fp32x3 chunks hold 8 bf16)
@@ -1287,20 +1046,10 @@ __global__ void pack_kernel(const float* __restrict__ w, char* __restrict__ wp, 
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t r = i;
         const int col = (int)(r % BN); r /= BN;
-        int chunk, tap, s, t;
-        if (half_order) {   // CV_H32: [tile][half-slice][tap][chunk 4][col]: the 32-channel halves of a slice are separate K blocks
-            chunk = (int)(r % 4); r /= 4;
-            tap = (int)(r % 27); r /= 27;
-            const int hs = (int)(r % (2 * nslices));
-            t = (int)(r / (2 * nslices));
-            s = hs >> 1;
-            chunk += (hs & 1) * 4;
-        } else {
-            chunk = (int)(r % 8); r /= 8;
-            tap = (int)(r % 27); r /= 27;
-            s = (int)(r % nslices);
-            t = (int)(r / nslices);
-        }
+        const int chunk = (int)(r % 8); r /= 8;
+        const int tap = (int)(r % 27); r /= 27;
+        const int s = (int)(r % nslices);
+        const int t = (int)(r / nslices);
         const int co = t * BN + ((conv_uses_m16(DT, BN) && !plain_cols) ? conv_cout_of_col(col) : col);
         char* dst = wp + i * 16;
 #pragma unroll
@@ -1328,8 +1077,7 @@ __global__ void pack_kernel(const float* __restrict__ w, char* __restrict__ wp, 
 // then the same bf16 / hi-lo encoding and column permutation as pack_kernel).  w = Keras [27][C0][Cout] of the upsampled
 // channels only.
 template <int DT>
-__global__ void pack_upfold_kernel(const float* __restrict__ w, char* __restrict__ wp, int Cin, int Cout, int BN, int ntiles,
-                                   int half_order)
+__global__ void pack_upfold_kernel(const float* __restrict__ w, char* __restrict__ wp, int Cin, int Cout, int BN, int ntiles)
 {
     constexpr int KC = Elt<DT>::kc;
     constexpr int EPC = 8;
@@ -1338,18 +1086,9 @@ __global__ void pack_upfold_kernel(const float* __restrict__ w, char* __restrict
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t r = i;
         const int col = (int)(r % BN); r /= BN;
-        int chunk, tap, s;
-        if (half_order) {   // CV_H32: [class][tile][half-slice][tap 8][chunk 4][col]
-            chunk = (int)(r % 4); r /= 4;
-            tap = (int)(r % 8); r /= 8;
-            const int hs = (int)(r % (2 * nslices)); r /= 2 * nslices;
-            s = hs >> 1;
-            chunk += (hs & 1) * 4;
-        } else {
-            chunk = (int)(r % 8); r /= 8;
-            tap = (int)(r % 8); r /= 8;
-            s = (int)(r % nslices); r /= nslices;
-        }
+        const int chunk = (int)(r % 8); r /= 8;
+        const int tap = (int)(r % 8); r /= 8;
+        const int s = (int)(r % nslices); r /= nslices;
         const int t = (int)(r % ntiles);
         const int cls = (int)(r / ntiles);
         const int co = t * BN + conv_cout_of_col(col);
@@ -1458,8 +1197,7 @@ int launch_conv(const ConvParams& p, int ntiles_n, hipStream_t st, int64_t* nblk
 {
     constexpr int BN = WN * NT * 32;
     constexpr int TXT = WM * MT * 32 / (TY * TZ);
-    // CV_H32: two 640-row x 64-B A buffers, the weight double buffer, 2 560 table entries
-    constexpr int LDS = (VAR & CV_H32) != 0 ? 2 * 640 * 64 + 2 * BN * 128 + 640 * 4 * 4 : (TXT + 2) * HY * HZ * ROWB + 2 * BN * 128;
+    constexpr int LDS = (TXT + 2) * HY * HZ * ROWB + 2 * BN * 128;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     auto kern = conv3d_k3_kernel<DT, WM, WN, MT, NT, VAR>;
@@ -1512,7 +1250,7 @@ int dispatch_conv(const ConvParams& p, hipStream_t st, int64_t* nblk_out = nullp
     if (stamps && BN == 64) return launch_conv<DT, 8, 1, 2, 2, V_FULL | CV_BATCHA | CV_PRIO_Y | CV_STAMP>(p, nt, st, nblk_out);
 #endif
     switch (BN) {
-        case 256: return launch_conv<DT, 2, 4, 4, 2, V_FULL | (F32T ? CV_BATCHA : 0) | ((kH32 && DT == MMR_DT_BF16) ? CV_H32 : 0)>(p, nt, st, nblk_out);
+        case 256: return launch_conv<DT, 2, 4, 4, 2, V_FULL | (F32T ? CV_BATCHA : 0)>(p, nt, st, nblk_out);
         case 128:
             if (DT == MMR_DT_BF16) return launch_conv<DT, 4, 2, 4, 2, CV_M16>(p, nt, st, nblk_out);
             return launch_conv<DT, 4, 2, 4, 2, V_FULL | CV_BATCHA>(p, nt, st, nblk_out);
@@ -1533,7 +1271,7 @@ int dispatch_conv_fold(const ConvParams& p, hipStream_t st, int64_t* nblk_out = 
     static_assert(!((EXTRA & CV_PART16) != 0 && F32T), "half partial: bf16 layers only");
     constexpr int V_FULL = CV_M16 | CV_PIPE | CV_DMA_A;
     switch (BN) {
-        case 256: return launch_conv<DT, 2, 4, 4, 2, V_FULL | (F32T ? CV_BATCHA : 0) | ((kH32 && DT == MMR_DT_BF16) ? CV_H32 : 0) | EXTRA>(p, nt, st, nblk_out);
+        case 256: return launch_conv<DT, 2, 4, 4, 2, V_FULL | (F32T ? CV_BATCHA : 0) | EXTRA>(p, nt, st, nblk_out);
         case 128:
             if constexpr (DT == MMR_DT_BF16) return launch_conv<DT, 4, 2, 4, 2, CV_M16 | EXTRA>(p, nt, st, nblk_out);
             else return launch_conv<DT, 4, 2, 4, 2, V_FULL | CV_BATCHA | EXTRA>(p, nt, st, nblk_out);
@@ -2331,13 +2069,13 @@ extern "C" int mmr_conv3d_k3_pack(const float* w_keras, void* w_packed, int Cin,
     const int grid = stream_grid(bytes / 16, 256);
     if (dtype == MMR_DT_BF16)
         hipLaunchKernelGGL(pack_kernel<MMR_DT_BF16>, dim3(grid), dim3(256), 0, as_stream(stream), w_keras,
-                           (char*)w_packed, Cin, Cout, BN, nt, transpose_flip, 0, (kH32 && BN == 256) ? 1 : 0);
+                           (char*)w_packed, Cin, Cout, BN, nt, transpose_flip, 0);
     else if (dtype == MMR_DT_F32X3 || dtype == MMR_DT_F32X1)
         hipLaunchKernelGGL(pack_kernel<MMR_DT_F32X3>, dim3(grid), dim3(256), 0, as_stream(stream), w_keras,
-                           (char*)w_packed, Cin, Cout, BN, nt, transpose_flip, 0, 0);
+                           (char*)w_packed, Cin, Cout, BN, nt, transpose_flip, 0);
     else
         hipLaunchKernelGGL(pack_kernel<MMR_DT_F32>, dim3(grid), dim3(256), 0, as_stream(stream), w_keras,
-                           (char*)w_packed, Cin, Cout, BN, nt, transpose_flip, 0, 0);
+                           (char*)w_packed, Cin, Cout, BN, nt, transpose_flip, 0);
     return check_launch();
 }
 
@@ -2410,10 +2148,10 @@ extern "C" int mmr_conv3d_k3_upfold_pack(const float* w_up_keras, void* w_packed
     const int grid = stream_grid(bytes / 16, 256);
     if (dtype == MMR_DT_BF16)
         hipLaunchKernelGGL(pack_upfold_kernel<MMR_DT_BF16>, dim3(grid), dim3(256), 0, as_stream(stream), w_up_keras,
-                           (char*)w_packed, C0, Cout, BN, Cout / BN, (kH32 && BN == 256) ? 1 : 0);
+                           (char*)w_packed, C0, Cout, BN, Cout / BN);
     else
         hipLaunchKernelGGL(pack_upfold_kernel<MMR_DT_F32X3>, dim3(grid), dim3(256), 0, as_stream(stream), w_up_keras,
-                           (char*)w_packed, C0, Cout, BN, Cout / BN, 0);
+                           (char*)w_packed, C0, Cout, BN, Cout / BN);
     return check_launch();
 }
 
