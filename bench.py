@@ -542,6 +542,14 @@ def main():
                "scaling": "weak", "vs_baseline": None, "dtype": w["dtype"], "data": "synthetic",
                "config": {"workload": w["workload"], "parallelism": w["par"]}}
         roof, fam_ms, fam = roofline_from_profile(prof, steps, f"traffic_{w['wl']}.json")
+        # the same K steps once more WITHOUT the per-launch HIP events of the timed region (reported beside `ms_per_step`, never
+        # instead of it): two event records per launch cost a launch-bound step visibly (configs[4]: 5 launches of 4-85 us)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            w["step"]()
+        barrier()
+        res["ms_per_step_without_events"] = (time.perf_counter() - t0) / steps * 1e3
         if w["wl"] == "ncc" and roof:
             roof["whole_step_GBps"] = w["extra"]["algorithmic_bytes_per_step"] / (dt / steps) / 1e9   # incl. finalize launches
         if roof:
