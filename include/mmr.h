@@ -154,7 +154,8 @@ int mmr_conv3d_k3_wgrad_upfold(const float* x_low, int C0, const float* skip, in
                                int B, int X2, int Y2, int Z2, int Cout, int accumulate, int x3mode, void* stream);
 /* First layer: concatenate([moving, fixed]) (2 x 1 channel, fp32) -> Cout.  pool_out (optional, same element type as
  * out, [B,X/2,Y/2,Z/2,Cout]): MaxPooling3D(2) of the activated output from the same kernel (bf16 and fp32x3 kernels;
- * MMR_EUNSUPPORTED with the exact-fp32 kernel).  Saves the 2.5 GB read of a separate pooling pass at C2.        */
+ * MMR_EUNSUPPORTED with the exact-fp32 kernel).  Saves the 2.5 GB read of a separate pooling pass at C2.
+ * leaky != 0: LeakyReLU slope alpha in [0, 1] (the kernels apply max(v, alpha v)); MMR_EINVAL otherwise.          */
 int mmr_conv3d_k3_cin2_fwd(const float* src, const float* trg, const float* w_keras, const float* bias,
                            void* out, void* pool_out, int B, int X, int Y, int Z, int Cout,
                            int leaky, float alpha, int out_dtype, void* stream);

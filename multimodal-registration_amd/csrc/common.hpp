@@ -60,6 +60,15 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f)
     return __builtin_bit_cast(unsigned short, h);
 }
 
+// two fp32 -> packed bf16 pair (low half = a), round-to-nearest-even: ONE v_cvt_pk_bf16_f32
+typedef __attribute__((ext_vector_type(2))) __bf16 mmr_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float mmr_f32x2;
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b)
+{
+    const mmr_f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, mmr_bf16x2));
+}
+
 // Dice ratio top / bottom under the two upstream variants: MMR_DICE_DIVIDE_NO_NAN =
 // tf.math.divide_no_nan (0 where bottom == 0), MMR_DICE_MAX_EPS = top / max(bottom, 1e-5) (older voxelmorph).
 #define MMR_DICE_EPS 1e-5f
