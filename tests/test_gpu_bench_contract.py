@@ -30,6 +30,7 @@ def test_infer_line_small():
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert 0 < d["ms_per_step_without_events"] < 2 * d["ms_per_step"]    # the same K steps without the per-launch events
     roof = d["roofline"]
     assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     cb = d["cpu_baseline"]
