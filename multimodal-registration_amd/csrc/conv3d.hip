@@ -1368,8 +1368,11 @@ conv3d_cin2_kernel(const float* __restrict__ src, const float* __restrict__ trg,
 // N*Cout output write, not by the 136 GFLOP of arithmetic.
 constexpr int M2_THREADS = 256;
 
+// waves_per_eu(2, 3): with the default budget of a 256-thread block (512 registers per lane) hipcc puts the MFMA results
+// in AGPRs and the epilogue pays a v_accvgpr_read per value; held to the occupancy the LDS allows anyway, the accumulators
+// live in VGPRs (no AGPRs, no scratch)
 template <bool X3, bool OUT_BF16>
-__global__ void __launch_bounds__(M2_THREADS)
+__global__ void __launch_bounds__(M2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 3)))
 conv3d_cin2_mfma_kernel(const float* __restrict__ src, const float* __restrict__ trg, const float* __restrict__ w,
                         const float* __restrict__ bias, void* __restrict__ out, void* __restrict__ pool, int B, int X, int Y,
                         int Z, int Cout, int leaky, float alpha, int ntx, int nty, int ntz, int ntiles)
@@ -1385,10 +1388,15 @@ conv3d_cin2_mfma_kernel(const float* __restrict__ src, const float* __restrict__
     float* s_img = reinterpret_cast<float*>(smem);                 // [600][2]
     float* s_bias = s_img + HROWS * 2;                             // [Cout] (<= 512)
     char* s_w = smem + HROWS * 8 + 2048;                           // [NPL][Cout][128 B]
+    constexpr int ES_O = OUT_BF16 ? 2 : 4;
+    constexpr int G = OUT_BF16 ? 2 : 1;                            // 32-cout groups per 128-B line of a voxel (Cout % (32 G) == 0)
+    constexpr int ST_PITCH = 144, ST_ROWS = 72;                    // 64 voxel rows + 8 pooled voxels, per wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
     const size_t nvox = (size_t)X * Y * Z;
+    char* s_st = s_w + NPL * Cout * 128 + wave * (ST_ROWS * ST_PITCH);   // this wave's output staging tile
+    const int fr = lane >> 3, fc = lane & 7;
     // persistent over tiles: the weight image and the bias are built once per block
     // 0 <= alpha <= 1 (checked by the entry point): LeakyReLU(v) = max(v, alpha v), two VALU ops instead of compare + multiply
     // + select -- the epilogue's VALU work, not the 64 MFMAs, is what a tile computes (bf16, C2: 1.044 -> 0.968 ms with this
@@ -1472,11 +1480,26 @@ conv3d_cin2_mfma_kernel(const float* __restrict__ src, const float* __restrict__
             if constexpr (X3) xf[NPL - 1][vt][ks] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
         }
     }
-    int gxv[2], gyv[2], gzv[2];
+    // flush addressing of this tile: store j of a flush covers the wave's voxel rows 8 j .. 8 j + 7, lane = (row & 7, chunk)
+    char* fptr[8];
+    unsigned fok = 0;
 #pragma unroll
-    for (int vt = 0; vt < 2; ++vt) {
-        const int v = wave * 64 + vt * 32 + (lane & 31);
-        gxv[vt] = x0 + vox_x(v); gyv[vt] = y0 + vox_y(v); gzv[vt] = z0 + vox_z(v);
+    for (int j = 0; j < 8; ++j) {
+        const int vv = wave * 64 + 8 * j + fr;
+        const int gx = x0 + vox_x(vv), gy = y0 + vox_y(vv), gz = z0 + vox_z(vv);
+        const bool ok = gx < X && gy < Y && gz < Z;
+        fok |= (ok ? 1u : 0u) << j;
+        const size_t vox = ok ? (size_t)b * nvox + ((size_t)gx * Y + gy) * Z + gz : 0;
+        fptr[j] = reinterpret_cast<char*>(out) + vox * Cout * ES_O + fc * 16;
+    }
+    char* pptr = nullptr;
+    bool pok = false;
+    if (pool) {   // pooled voxel fr of the wave: x pair = the wave's two x planes, y = fr >> 2, z = fr & 3
+        const int X2 = X >> 1, Y2 = Y >> 1, Z2 = Z >> 1;
+        const int px = (x0 >> 1) + (wave >> 1), py = (y0 >> 1) + 2 * (wave & 1) + (fr >> 2), pz = (z0 >> 1) + (fr & 3);
+        pok = px < X2 && py < Y2 && pz < Z2;
+        const size_t vox = pok ? (((size_t)b * X2 + px) * Y2 + py) * Z2 + pz : 0;
+        pptr = reinterpret_cast<char*>(pool) + vox * Cout * ES_O + fc * 16;
     }
     for (int n = 0; n < Cout / 32; ++n) {
         f32x16 acc[2];
@@ -1523,7 +1546,13 @@ conv3d_cin2_mfma_kernel(const float* __restrict__ src, const float* __restrict__
                 }
             }
         }
-        auto store16 = [&](void* base, size_t obase, const float* vals, bool ok) {
+        // Output through a per-wave LDS staging tile so that every store instruction writes whole 128-B lines: the accumulator
+        // layout gives a lane 8 couts (16 B) of ONE voxel per piece, i.e. 32-B runs per voxel and instruction -- stores in that
+        // shape alone take the kernel's whole 1.0 ms at 160x160x192x256 (2.8 TB/s; a fill of the same bytes runs at 6.8).  Staged
+        // as [voxel row][128 B = 64 bf16 / 32 fp32 couts] (pitch 144 B: conflict-free b128 writes), a flush reads lane =
+        // (row & 7, chunk) and stores 8 complete lines per instruction; the pooled voxels (8 per wave) take one more.
+        auto stage = [&](int row, const float* vals, bool wr) {   // every lane takes part in the swaps, `wr` lanes write
+            char* rp = s_st + row * ST_PITCH;
             if constexpr (OUT_BF16) {
                 unsigned pk[4][2];
 #pragma unroll
@@ -1531,7 +1560,7 @@ conv3d_cin2_mfma_kernel(const float* __restrict__ src, const float* __restrict__
                     pk[gq][0] = pack_bf16x2(vals[gq * 4], vals[gq * 4 + 1]);       // one v_cvt_pk_bf16_f32 per pair
                     pk[gq][1] = pack_bf16x2(vals[gq * 4 + 2], vals[gq * 4 + 3]);
                 }
-                // pair cout groups (0,1) and (2,3) across the two half-waves -> 16 contiguous bytes per lane
+                // pair cout groups (0,1) and (2,3) across the two half-waves -> 8 consecutive couts (16 B) per lane
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
 #pragma unroll
@@ -1540,31 +1569,25 @@ conv3d_cin2_mfma_kernel(const float* __restrict__ src, const float* __restrict__
                         pk[2 * pr][d] = rsw[0];
                         pk[2 * pr + 1][d] = rsw[1];
                     }
-                    if (ok) {
-                        bf16_t* o = reinterpret_cast<bf16_t*>(base) + obase + 16 * pr + 8 * h;
-                        *reinterpret_cast<uint4*>(o) = make_uint4(pk[2 * pr][0], pk[2 * pr][1], pk[2 * pr + 1][0], pk[2 * pr + 1][1]);
-                    }
+                    if (wr)
+                        *reinterpret_cast<uint4*>(rp + (((n & 1) * 4 + 2 * pr + h) << 4)) =
+                            make_uint4(pk[2 * pr][0], pk[2 * pr][1], pk[2 * pr + 1][0], pk[2 * pr + 1][1]);
                 }
             } else {
-                if (ok) {
-                    float* o = reinterpret_cast<float*>(base) + obase;
+                if (wr) {
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq)
-                        *reinterpret_cast<float4*>(o + 8 * gq + 4 * h) =
+                        *reinterpret_cast<float4*>(rp + ((2 * gq + h) << 4)) =
                             make_float4(vals[gq * 4], vals[gq * 4 + 1], vals[gq * 4 + 2], vals[gq * 4 + 3]);
                 }
             }
         };
 #pragma unroll
-        for (int vt = 0; vt < 2; ++vt) {
-            const bool ok = gxv[vt] < X && gyv[vt] < Y && gzv[vt] < Z;
-            const size_t obase = ((size_t)b * nvox + ((size_t)gxv[vt] * Y + gyv[vt]) * Z + gzv[vt]) * Cout + n * 32;
-            store16(out, obase, vals2[vt], ok);
-        }
+        for (int vt = 0; vt < 2; ++vt) stage(vt * 32 + (lane & 31), vals2[vt], true);
         if (pool) {
             // MaxPooling3D(2) of the activated output (Keras 'valid': floor on odd sizes): x pair = the two accumulator
             // tiles, z pair = lane ^ 1 (DPP quad_perm [1,0,3,2]), y pair = lane ^ 8 (DPP row_ror:8); every lane ends up
-            // with the window maximum, the lane with even y and z stores it
+            // with the window maximum, the lanes with even y and z stage it (pooled voxel (y >> 1) * 4 + (z >> 1) of the wave)
             float pv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1575,11 +1598,19 @@ conv3d_cin2_mfma_kernel(const float* __restrict__ src, const float* __restrict__
                 asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(m) : "v"(m));
                 pv[r] = m;
             }
-            const int X2 = X >> 1, Y2 = Y >> 1, Z2 = Z >> 1;
-            const int px = gxv[0] >> 1, py = gyv[0] >> 1, pz = gzv[0] >> 1;   // gxv[0] is the even x of the pair
-            const bool pok = !(lane & 1) && !(lane & 8) && px < X2 && py < Y2 && pz < Z2;
-            const size_t pbase = ((((size_t)b * X2 + px) * Y2 + py) * Z2 + pz) * Cout + n * 32;
-            store16(pool, pbase, pv, pok);
+            stage(64 + ((lane >> 4) & 1) * 4 + ((lane & 7) >> 1), pv, !(lane & 1) && !(lane & 8));
+        }
+        if ((n & (G - 1)) == G - 1) {
+            const size_t lo = (size_t)(n / G) * 128;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint4 v = *reinterpret_cast<const uint4*>(s_st + (8 * j + fr) * ST_PITCH + fc * 16);
+                if ((fok >> j) & 1) *reinterpret_cast<uint4*>(fptr[j] + lo) = v;
+            }
+            if (pool) {
+                const uint4 v = *reinterpret_cast<const uint4*>(s_st + (64 + fr) * ST_PITCH + fc * 16);
+                if (pok) *reinterpret_cast<uint4*>(pptr + lo) = v;
+            }
         }
     }
     }  // tile loop
@@ -2334,7 +2365,7 @@ static int launch_cin2_mfma(const float* src, const float* trg, const float* w, 
                             int B, int X, int Y, int Z, int Cout, int leaky, float alpha, hipStream_t st)
 {
     const int npl = X3 ? 2 : 1;
-    const int lds = HROWS * 8 + 2048 + npl * Cout * 128;
+    const int lds = HROWS * 8 + 2048 + npl * Cout * 128 + 4 * 72 * 144;   // + the four waves' output staging tiles
     if (lds > 160 * 1024) return MMR_EUNSUPPORTED;
     static bool attr_set = false;
     auto kern = conv3d_cin2_mfma_kernel<X3, OUT_BF16>;
@@ -2363,7 +2394,7 @@ extern "C" int mmr_conv3d_k3_cin2_fwd(const float* src, const float* trg, const 
     hipStream_t st = as_stream(stream);
     // out_dtype: BF16 -> bf16 MFMA, bf16 out; F32X3 -> bf16 hi/lo split MFMA, fp32 out; F32 -> exact fp32 VALU kernel
     // pool_out (fused MaxPooling3D(2) of the activated output, same element type): the two matrix-core kernels only
-    if (Cout % 32 == 0 && Cout <= 512 && out_dtype == MMR_DT_BF16)
+    if (Cout % 64 == 0 && Cout <= 512 && out_dtype == MMR_DT_BF16)   // a 128-B output line = 64 bf16 couts
         return launch_cin2_mfma<false, true>(src, trg, w_keras, bias, out, pool_out, B, X, Y, Z, Cout, leaky, alpha, st);
     if (Cout % 32 == 0 && Cout <= 320 && out_dtype == MMR_DT_F32X3)
         return launch_cin2_mfma<true, false>(src, trg, w_keras, bias, out, pool_out, B, X, Y, Z, Cout, leaky, alpha, st);

@@ -372,7 +372,8 @@ def conv3d_k3_dgrad_split(dz, wt_packed, C0, C1, y1=None, dbias1=None, alpha=0.2
 def cin2_pool_supported(cout, out_dtype, x3=False):
     """The fused MaxPooling3D(2) epilogue exists in the two matrix-core first-layer kernels (bf16 out / fp32x3)."""
     mode = conv_mode(out_dtype, x3)
-    return (mode == BF16 and cout % 32 == 0 and cout <= 512) or (mode == F32X3 and cout % 32 == 0 and cout <= 320)
+    # bf16: a 128-B output line holds 64 couts (the kernel writes whole lines); fp32x3: 32
+    return (mode == BF16 and cout % 64 == 0 and cout <= 512) or (mode == F32X3 and cout % 32 == 0 and cout <= 320)
 
 
 def conv3d_k3_cin2(src, trg, w_keras, bias, out_dtype, leaky=True, alpha=0.2, x3=False, pool=False):
