@@ -104,7 +104,10 @@ int mmr_conv3d_k3_fwd(const void* in0, int C0, int up0, const void* in1, int C1,
                       int leaky, float alpha, int dtype, int out_f32, void* stream);
 /* Same, with an optional scratch buffer of mmr_conv3d_k3_ksplit_ws_bytes(): launches with too few workgroups to
  * fill the chip (deep U-Net levels, small volumes) then split the K walk over several workgroups per tile and add
- * the partial tiles in a fixed order (bitwise reproducible).  ws == NULL behaves like mmr_conv3d_k3_fwd. */
+ * the partial tiles in a fixed order (bitwise reproducible).  A launch whose tile count leaves a partial round of
+ * workgroups (one per CU: e.g. 300 tiles on 256 CUs) runs only its LAST nblk % CUs tiles that way, in a second launch
+ * (from 4 x 27 tap steps per tile on).  The query returns 0 when neither applies.  ws == NULL behaves like
+ * mmr_conv3d_k3_fwd. */
 int64_t mmr_conv3d_k3_ksplit_ws_bytes(int B, int X, int Y, int Z, int Cin, int Cout, int dtype);
 int mmr_conv3d_k3_fwd_ws(const void* in0, int C0, int up0, const void* in1, int C1,
                          const void* w_packed, const float* bias, void* out, void* pool_out,
@@ -121,7 +124,8 @@ int mmr_conv3d_k3_fwd_ws(const void* in0, int C0, int up0, const void* in1, int 
  *       MMR_DT_BF16 only -- in IEEE half saturated to +-65504 (its 2^-12 rounding is below the layer's bf16 output
  *       rounding; halves the round trip of the partial tensor through HBM);
  *   mmr_conv3d_k3_fwd_init:    out = act(cinit + conv3x3x3(in) + bias) over the skip channels, cinit = that partial
- *       (cinit_half says which of the two formats it holds).
+ *       (cinit_half says which of the two formats it holds); ws: NULL, or mmr_conv3d_k3_ksplit_ws_bytes(B, X, Y, Z, Cin,
+ *       Cout, dtype) bytes of scratch (see there).
  * The pair equals mmr_conv3d_k3_fwd(in_low, C0, up0 = 1, skip, C1, ...) up to the summation order of the weights.
  * bf16 / fp32x3 only, C0 a multiple of the channel slice (64 / 32), Cout a multiple of 64; else MMR_EUNSUPPORTED /
  * MMR_EINVAL. */
@@ -131,7 +135,7 @@ int mmr_conv3d_k3_upfold_fwd(const void* in_low, int C0, const void* w_packed, v
                              int B, int X2, int Y2, int Z2, int Cout, int dtype, void* stream);
 int mmr_conv3d_k3_fwd_init(const void* in, int Cin, const void* w_packed, const float* bias, const void* cinit,
                            int cinit_half, void* out, int B, int X, int Y, int Z, int Cout,
-                           int leaky, float alpha, int dtype, int out_f32, void* stream);
+                           int leaky, float alpha, int dtype, int out_f32, void* ws, void* stream);
 /* Data gradient of the folded half w.r.t. the low-resolution input (training; fp32x3 / x1): replaces the upsampled-channel
  * half of mmr_conv3d_k3_dgrad_split plus the 2x2x2 pooling of mmr_upcat_bwd_masked_f32 -- 64 tap-steps per low-res voxel
  * instead of 216, no full-resolution intermediate.  dz [B,2*X2,2*Y2,2*Z2,Cz] fp32 -> out [B,X2,Y2,Z2,C0] fp32;

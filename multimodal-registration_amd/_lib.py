@@ -34,7 +34,7 @@ SIGNATURES = {
     "mmr_conv3d_k3_upfold_packed_bytes": (c_int64, [I, I, I]),
     "mmr_conv3d_k3_upfold_pack": (I, [P, P, I, I, I, P]),
     "mmr_conv3d_k3_upfold_fwd": (I, [P, I, P, P, I, I, I, I, I, I, I, P]),
-    "mmr_conv3d_k3_fwd_init": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, F, I, I, P]),
+    "mmr_conv3d_k3_fwd_init": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, F, I, I, P, P]),
     "mmr_conv3d_k3_dgrad_upfold_packed_bytes": (c_int64, [I, I, I]),
     "mmr_conv3d_k3_dgrad_upfold_pack": (I, [P, P, I, I, I, P]),
     "mmr_conv3d_k3_dgrad_upfold_ws_bytes": (c_int64, [I, I, I, I, I]),

@@ -76,6 +76,10 @@ struct ConvParams {
     // CV_CINIT: the accumulators start from this fp32 tensor [B,X,Y,Z,Cout] instead of zero -- the second half of a
     // folded-upsample layer (see CV_UPFOLD): out = act(cinit + conv(in) + bias)
     const float* cinit = nullptr;
+    // Tail launch (launch_conv): the workgroups of this launch are the tiles tile0 .. tile0 + gridDim.x - 1; with kcompact the
+    // split-K partials go to a compact buffer kpart[kz][blockIdx.x][tile voxel][Cout] (conv_ktail_finalize_kernel reads it)
+    int tile0 = 0;
+    int kcompact = 0;
 };
 
 template <int N> struct IntTag { static constexpr int value = N; };
@@ -260,7 +264,7 @@ conv3d_k3_kernel(const ConvParams p)
     const int wm = wave / WN, wn = wave % WN;
     const int h = lane >> 5;
 
-    int bid = blockIdx.x;
+    int bid = (int)blockIdx.x + p.tile0;
     const int tzi = bid % p.ntz; bid /= p.ntz;
     const int tyi = bid % p.nty; bid /= p.nty;
     const int txi = bid % p.ntx;
@@ -323,7 +327,7 @@ conv3d_k3_kernel(const ConvParams p)
             for (int mi = 0; mi < 2 * MT; ++mi) {
                 const int mt = wm * MT + (mi >> 1);
                 const int gx = x0 + (mt >> 1), gy = y0 + (mt & 1) * 4 + 2 * (mi & 1) + (r16 >> 3), gz = z0 + (r16 & 7);
-                okv[mi] = co + 15 < p.Cout && gx < p.X && gy < p.Y && gz < p.Z;
+                okv[mi] = co + 15 < p.Cout && gx < p.X && gy < p.Y && gz < p.Z && (!p.kpart || blockIdx.z == 0);   // split K: block 0 carries the init
                 const int cx = gx < p.X ? gx : p.X - 1, cy = gy < p.Y ? gy : p.Y - 1, cz = gz < p.Z ? gz : p.Z - 1;
                 const size_t o = ((((size_t)b * p.X + cx) * p.Y + cy) * p.Z + cz) * p.Cout + cco;
                 if constexpr (PART16) {
@@ -779,6 +783,28 @@ conv3d_k3_kernel(const ConvParams p)
 
     // ---- split-K: raw fp32 partial tile, finalised by conv_ksplit_finalize_kernel ----
     if (p.kpart) {
+        if constexpr (M16) {
+            if (p.kcompact) {
+                float* kc = p.kpart + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * ((size_t)(TXT * TY * TZ) * p.Cout);
+#pragma unroll
+                for (int gi = 0; gi < NT / 2; ++gi) {
+                    const int co = ntile * BN + wn * NT * 32 + gi * 64 + q16 * 16;
+#pragma unroll
+                    for (int mi = 0; mi < 2 * MT; ++mi) {
+                        const int mt = wm * MT + (mi >> 1);
+                        const int lx = mt >> 1, ly = (mt & 1) * 4 + 2 * (mi & 1) + (r16 >> 3), lz = r16 & 7;
+                        if (co + 15 < p.Cout && x0 + lx < p.X && y0 + ly < p.Y && z0 + lz < p.Z) {
+                            float* o = kc + (size_t)((lx * TY + ly) * TZ + lz) * p.Cout + co;
+#pragma unroll
+                            for (int ni = 0; ni < 4; ++ni)
+                                *reinterpret_cast<float4*>(o + ni * 4) = make_float4(acc16[mi][gi * 4 + ni][0], acc16[mi][gi * 4 + ni][1],
+                                                                                   acc16[mi][gi * 4 + ni][2], acc16[mi][gi * 4 + ni][3]);
+                        }
+                    }
+                }
+                return;
+            }
+        }
         float* kp = p.kpart + (size_t)blockIdx.z * ((size_t)p.B * p.X * p.Y * p.Z * p.Cout);
         if constexpr (M16) {
 #pragma unroll
@@ -1181,6 +1207,77 @@ conv_ksplit_finalize_kernel(const float* __restrict__ kpart, int nk, const float
     }
 }
 
+// Tail of a launch whose tile count is not a multiple of the CU count (one workgroup per CU: a launch of 2 400 tiles runs as
+// ten rounds of 256, the last one 37 % full -- 9.4 rounds of work in the time of 10; 300 tiles: 1.2 in the time of 2).  The
+// last nblk % ncu tiles are launched on their own with their K walk split over ncu / R workgroups each (compact fp32 partials,
+// fixed-order sum -> bitwise reproducible), so that the partial round takes 1 / St of a tile time.
+inline int conv_ncu()
+{
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+            n = 256;
+        ncu = n;
+    }
+    return ncu;
+}
+inline bool conv_tail_plan(int64_t nblk, int ntiles_n, int G, int* R_out, int* S_out)
+{
+    const int ncu = conv_ncu();
+    // worth it from four 27-tap slices per tile on (a 64 -> 64 fp32x3 tile, G = 54, is so short that the second launch, the
+    // partials and the per-block A staging cost what the shorter round saves: 2.04 -> 2.07 ms at 160^3), and every block walks
+    // at least one whole slice
+    if (ntiles_n != 1 || nblk <= ncu || G < 108) return false;
+    const int R = (int)(nblk % ncu);
+    if (R == 0 || 2 * R > ncu) return false;
+    int S = ncu / R;
+    if (S > G / 27) S = G / 27;
+    if (S > 16) S = 16;
+    if (S < 2) return false;
+    *R_out = R;
+    *S_out = S;
+    return true;
+}
+
+// out (tiles tile0 ..) = act(sum_k kpart[k][tile][voxel][:] + bias), summed in index order; TV = voxels per tile (TXT x 8 x 8)
+__global__ void __launch_bounds__(256)
+conv_ktail_finalize_kernel(const float* __restrict__ kpart, int nk, int R, int tile0, const float* __restrict__ bias,
+                           void* __restrict__ out, int X, int Y, int Z, int Cout, int ntx, int nty, int ntz, int TXT_,
+                           int leaky, float alpha, int out_bf16)
+{
+    const int TV = TXT_ * TY * TZ, c4n = Cout / 4;
+    const int64_t total = (int64_t)R * TV * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % c4n);
+        const int vloc = (int)((i / c4n) % TV);
+        const int t = (int)(i / ((int64_t)c4n * TV));
+        int bid = tile0 + t;
+        const int tzi = bid % ntz; bid /= ntz;
+        const int tyi = bid % nty; bid /= nty;
+        const int txi = bid % ntx;
+        const int b = bid / ntx;
+        const int gx = txi * TXT_ + vloc / (TY * TZ), gy = tyi * TY + (vloc / TZ) % TY, gz = tzi * TZ + vloc % TZ;
+        if (gx >= X || gy >= Y || gz >= Z) continue;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < nk; ++k) {
+            const float4 a = *reinterpret_cast<const float4*>(kpart + (((size_t)k * R + t) * TV + vloc) * Cout + c4 * 4);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        if (bias) {
+            const float4 bq = *reinterpret_cast<const float4*>(bias + c4 * 4);
+            v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+        }
+        if (leaky) {
+            v.x = v.x < 0.f ? v.x * alpha : v.x; v.y = v.y < 0.f ? v.y * alpha : v.y;
+            v.z = v.z < 0.f ? v.z * alpha : v.z; v.w = v.w < 0.f ? v.w * alpha : v.w;
+        }
+        const size_t o = ((((size_t)b * X + gx) * Y + gy) * Z + gz) * Cout + c4 * 4;
+        if (out_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + o) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        else *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + o) = v;
+    }
+}
+
 // Split the K walk when the launch has fewer workgroups than half the CUs and a scratch buffer is offered.
 inline int conv_ksplit(int64_t nblk, int ntiles_n, int G)
 {
@@ -1222,6 +1319,26 @@ int launch_conv(const ConvParams& p, int ntiles_n, hipStream_t st, int64_t* nblk
         const bool obf = (DT == MMR_DT_BF16) && !p.out_f32;
         hipLaunchKernelGGL(conv_ksplit_finalize_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, st, (const float*)p.kpart, nz,
                            p.bias, (void*)p.out, n, p.Cout, p.leaky, p.alpha, obf ? 1 : 0);
+        return check_launch();
+    }
+    // tail split (see conv_tail_plan): 16x16x32 kernels with the plain epilogue, a workspace offered by the caller
+    constexpr bool TAIL_OK = ((VAR & CV_M16) != 0) && DT != MMR_DT_F32 && NT == 2 && (VAR & (CV_UPFOLD | CV_DGFOLD)) == 0;
+    int R = 0, St = 0;
+    if (TAIL_OK && p.kpart && !p.ymask && !p.csplit && (p.Cout & 15) == 0 && conv_tail_plan(nblk, ntiles_n, G, &R, &St)) {
+        ConvParams m = q;
+        m.kpart = nullptr;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(nblk - R), ntiles_n), dim3(CONV_THREADS), LDS, st, m);
+        ConvParams t = q;
+        t.tile0 = (int)(nblk - R);
+        t.kcompact = 1;
+        t.gsplit = (G + St - 1) / St;
+        const int nz = (G + t.gsplit - 1) / t.gsplit;
+        hipLaunchKernelGGL(kern, dim3((unsigned)R, ntiles_n, nz), dim3(CONV_THREADS), LDS, st, t);
+        const bool obf = (DT == MMR_DT_BF16) && !p.out_f32;
+        const int64_t n4 = (int64_t)R * (TXT * TY * TZ) * (p.Cout / 4);
+        hipLaunchKernelGGL(conv_ktail_finalize_kernel, dim3(stream_grid(n4, 256)), dim3(256), 0, st, (const float*)p.kpart, nz, R,
+                           t.tile0, p.bias, (void*)p.out, p.X, p.Y, p.Z, p.Cout, q.ntx, q.nty, q.ntz, TXT, p.leaky, p.alpha,
+                           obf ? 1 : 0);
         return check_launch();
     }
     q.kpart = nullptr;
@@ -2126,7 +2243,14 @@ extern "C" int64_t mmr_conv3d_k3_ksplit_ws_bytes(int B, int X, int Y, int Z, int
     const int64_t nblk = (int64_t)B * ((X + txt - 1) / txt) * ((Y + TY - 1) / TY) * ((Z + TZ - 1) / TZ);
     const int G = (Cin / ((dtype == MMR_DT_BF16) ? 64 : 32)) * 27;
     const int S = conv_ksplit(nblk, nt, G);
-    return S > 1 ? (int64_t)S * B * X * Y * Z * Cout * (int64_t)sizeof(float) : 0;
+    if (S > 1) return (int64_t)S * B * X * Y * Z * Cout * (int64_t)sizeof(float);
+    // tail split of a launch that leaves a partial round of workgroups (conv_tail_plan): compact partials of the tail tiles
+    int R = 0, St = 0;
+    if (conv_uses_m16(dtype, BN) && BN >= 64 && (Cout & 15) == 0 && conv_tail_plan(nblk, nt, G, &R, &St)) {
+        const int gs = (G + St - 1) / St, nz = (G + gs - 1) / gs;
+        return (int64_t)nz * R * (txt * TY * TZ) * Cout * (int64_t)sizeof(float);
+    }
+    return 0;
 }
 
 extern "C" int mmr_conv3d_k3_fwd_ws(const void* in0, int C0, int up0, const void* in1, int C1, const void* w_packed,
@@ -2217,7 +2341,7 @@ extern "C" int mmr_conv3d_k3_upfold_fwd(const void* in_low, int C0, const void* 
 // otherwise mmr_conv3d_k3_fwd without the concat / split-K options.
 extern "C" int mmr_conv3d_k3_fwd_init(const void* in, int Cin, const void* w_packed, const float* bias, const void* cinit,
                                       int cinit_half, void* out, int B, int X, int Y, int Z, int Cout, int leaky, float alpha,
-                                      int dtype, int out_f32, void* stream)
+                                      int dtype, int out_f32, void* ws, void* stream)
 {
     if (cinit_half && dtype != MMR_DT_BF16) return MMR_EUNSUPPORTED;
     if (!in || !w_packed || !out || !cinit || B < 1 || X < 1 || Y < 1 || Z < 1) return MMR_EINVAL;
@@ -2229,7 +2353,7 @@ extern "C" int mmr_conv3d_k3_fwd_init(const void* in, int Cin, const void* w_pac
     p.out = (char*)out;
     p.B = B; p.X = X; p.Y = Y; p.Z = Z; p.C0 = Cin; p.C1 = 0; p.up0 = 0; p.Cout = Cout;
     p.leaky = leaky; p.alpha = alpha; p.out_f32 = out_f32; p.ymask = nullptr; p.part = nullptr;
-    p.kpart = nullptr; p.gsplit = 0; p.out1 = nullptr; p.csplit = 0; p.cinit = (const float*)cinit;
+    p.kpart = (float*)ws; p.gsplit = 0; p.out1 = nullptr; p.csplit = 0; p.cinit = (const float*)cinit;
     p.ntx = (X + TX - 1) / TX; p.nty = (Y + TY - 1) / TY; p.ntz = (Z + TZ - 1) / TZ;
     if (dtype == MMR_DT_BF16 && cinit_half) return dispatch_conv_fold<MMR_DT_BF16, CV_CINIT | CV_PART16>(p, as_stream(stream));
     if (dtype == MMR_DT_BF16) return dispatch_conv_fold<MMR_DT_BF16, CV_CINIT>(p, as_stream(stream));

@@ -256,10 +256,12 @@ def conv3d_k3_upfold(in_low, skip, w_up, w_skip, bias, cout, leaky=True, alpha=0
         rc = lib.mmr_conv3d_k3_upfold_fwd(in_low.data_ptr(), C0, w_up.data_ptr(), partial.data_ptr(), int(half), B, X2, Y2, Z2,
                                           int(cout), mode, _stream())
     _lib.check(rc, "mmr_conv3d_k3_upfold_fwd")
+    nws = lib.mmr_conv3d_k3_ksplit_ws_bytes(B, X, Y, Z, C1, int(cout), mode)   # > 0: the launch leaves a partial round of workgroups
+    ws = _ws(nws, in_low.device) if nws > 0 else None
     with _Timed(fam + "_cinit", (C1, int(cout), X, Y, Z), 2.0 * 27 * C1 * cout * B * X * Y * Z):
         rc = lib.mmr_conv3d_k3_fwd_init(skip.data_ptr(), C1, w_skip.data_ptr(), bias.data_ptr() if bias is not None else None,
                                         partial.data_ptr(), int(half), out.data_ptr(), B, X, Y, Z, int(cout), int(leaky),
-                                        float(alpha), mode, int(out_f32), _stream())
+                                        float(alpha), mode, int(out_f32), ws.data_ptr() if ws is not None else None, _stream())
     _lib.check(rc, "mmr_conv3d_k3_fwd_init")
     return out
 

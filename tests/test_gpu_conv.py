@@ -201,7 +201,7 @@ def test_split_k_small_launch_matches_unsplit(dev, mode):
     lib = _lib.load()
     m = ops.conv_mode(dt, x3)
     assert lib.mmr_conv3d_k3_ksplit_ws_bytes(1, *shape, Cin, Cout, m) > 0
-    assert lib.mmr_conv3d_k3_ksplit_ws_bytes(1, 160, 160, 160, Cin, Cout, m) == 0
+    assert lib.mmr_conv3d_k3_ksplit_ws_bytes(1, 128, 128, 128, Cin, Cout, m) == 0    # 4096 tiles: whole rounds of workgroups
     y1 = ops.conv3d_k3(x, wp, b, Cout, leaky=True, x3=x3)       # split path (ws allocated by the wrapper)
     y2 = ops.conv3d_k3(x, wp, b, Cout, leaky=True, x3=x3)
     assert torch.equal(y1, y2)
@@ -211,6 +211,40 @@ def test_split_k_small_launch_matches_unsplit(dev, mode):
     assert rc == 0
     tol = 1e-2 if mode == "bf16" else 1e-5  # other summation order over K = 3456 (bf16: output rounding on top)
     assert float((y1.float() - ref.float()).abs().max()) <= tol * float(ref.float().abs().max())
+
+
+@pytest.mark.parametrize("mode,shape,Cin,Cout", [("bf16", (44, 30, 60), 256, 256), ("bf16", (36, 32, 64), 320, 256),
+                                                 ("fp32x3", (72, 60, 40), 128, 64), ("fp32x3", (48, 64, 60), 128, 128)])
+def test_tail_split_matches_unsplit(dev, mode, shape, Cin, Cout):
+    """A launch whose tile count leaves a partial round of workgroups (352 / 288 / 360 / 384 tiles on 256 CUs) runs its last tiles
+    with the K walk split (csrc/conv3d.hip conv_tail_plan): same result as the one-launch form up to the summation order,
+    bitwise reproducible, ragged tiles included."""
+    import mmr
+    from mmr import _lib
+    ops = mmr.ops
+    rng = np.random.default_rng(hash((mode, shape)) % 2 ** 31)
+    dt = torch.bfloat16 if mode == "bf16" else torch.float32
+    x3 = mode == "fp32x3"
+    x = torch.from_numpy(rng.standard_normal((1,) + shape + (Cin,)).astype(np.float32)).to(dev).to(dt)
+    w = torch.from_numpy((rng.standard_normal((3, 3, 3, Cin, Cout)) * 0.05).astype(np.float32)).to(dev)
+    b = torch.from_numpy(rng.standard_normal(Cout).astype(np.float32)).to(dev)
+    wp = ops.pack_conv_weights(w, dt, x3=x3)
+    lib = _lib.load()
+    m = ops.conv_mode(dt, x3)
+    assert lib.mmr_conv3d_k3_ksplit_ws_bytes(1, *shape, Cin, Cout, m) > 0
+    for out_f32 in (False, True):
+        y1 = ops.conv3d_k3(x, wp, b, Cout, leaky=True, x3=x3, out_f32=out_f32)
+        y2 = ops.conv3d_k3(x, wp, b, Cout, leaky=True, x3=x3, out_f32=out_f32)
+        assert torch.equal(y1, y2)
+        ref = torch.empty_like(y1)
+        rc = lib.mmr_conv3d_k3_fwd(x.data_ptr(), Cin, 0, None, 0, wp.data_ptr(), b.data_ptr(), ref.data_ptr(), None, 1, *shape,
+                                   Cout, 1, 0.2, m, int(out_f32), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        tol = 1e-2 if y1.dtype == torch.bfloat16 else 1e-5
+        d = (y1.float() - ref.float()).abs()
+        assert float(d.max()) <= tol * float(ref.float().abs().max())
+        # the tiles of the whole rounds come from the same one-launch code path: bit-identical there
+        assert float(d[:, :4].max()) == 0.0
 
 
 @pytest.mark.parametrize("shape,Cout,odt", [((8, 8, 16), 64, "bf16"), ((6, 10, 12), 256, "bf16"), ((8, 8, 16), 64, "fp32x3"),
