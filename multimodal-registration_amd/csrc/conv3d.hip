@@ -371,7 +371,13 @@ conv3d_k3_kernel(const ConvParams p)
     constexpr int A_ITEMS = X3 ? HROWS_T * 4 : HROWS_T * 8;
     struct AItem { uint4 a, b; };
     auto load_a = [&](int s, int it) -> AItem {
-        const int i = tid + it * CONV_THREADS;
+        // (see dma_stage_a; on this register-staging path the recomputation costs more than the registers it frees -- fp32x3 C2
+        // forward 93.4 -> 99.0 ms, the 256-column _cinit 92.2 -> 95.4 even though it spills -- except for the 64-column _cinit
+        // tile of the training step: 2.75 -> 2.65 ms)
+        constexpr bool UNHOIST = CINIT && BN == 64;
+        int tid_l = tid;
+        if constexpr (UNHOIST) asm volatile("" : "+v"(tid_l));
+        const int i = tid_l + it * CONV_THREADS;
         AItem val;
         val.a = make_uint4(0, 0, 0, 0);
         val.b = make_uint4(0, 0, 0, 0);
@@ -402,7 +408,9 @@ conv3d_k3_kernel(const ConvParams p)
     // (6.7 k cycles per slice on the stamps of tools/conv_stamps.py train).
     struct AItemM { uint4 a, b; unsigned ok; };
     auto load_a_nb = [&](int s, int it) -> AItemM {
-        const int i0 = tid + it * CONV_THREADS;
+        int tid_l = tid;
+        if constexpr (CINIT && BN == 64) asm volatile("" : "+v"(tid_l));   // see load_a
+        const int i0 = tid_l + it * CONV_THREADS;
         const int i = i0 < A_ITEMS ? i0 : A_ITEMS - 1;
         const int scls = DGF ? s / ncs : 0;                     // dgrad fold: parity class of this K block
         const int ch0 = (DGF ? s - scls * ncs : s) * KC;
@@ -433,7 +441,9 @@ conv3d_k3_kernel(const ConvParams p)
     };
     auto and4 = [](uint4 v, unsigned m) { return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m); };
     auto store_a = [&](int it, const AItem& val) {
-        const int i = tid + it * CONV_THREADS;
+        int tid_l = tid;
+        if constexpr (CINIT && BN == 64) asm volatile("" : "+v"(tid_l));   // see load_a
+        const int i = tid_l + it * CONV_THREADS;
         if (i < A_ITEMS) {
             const int row = X3 ? (i >> 2) : (i >> 3), chunk = X3 ? (i & 3) : (i & 7);
             const int hy = (row / HZ) % HY, hz = row % HZ;
@@ -479,7 +489,65 @@ conv3d_k3_kernel(const ConvParams p)
     // tile, so the swizzle is applied to the SOURCE chunk; out-of-volume rows read a zero page.
     constexpr bool DMA_A = !X3 && ((VAR & CV_DMA_A) != 0);
     const unsigned sA_lds = lds_addr(sA);
+    constexpr bool ATAB = DMA_A && MIDDMA && !DGF && TXT == 4;
+    unsigned* atab = reinterpret_cast<unsigned*>(sB + 2 * B_BYTES);      // [A_ITEMS] item -> source byte offset, ~0 = zero row
+    bool atab_ok = false;
+    const char* atab_base = nullptr;
+    if constexpr (ATAB) {
+        atab_ok = p.C1 == 0 && !p.up0 && (long long)HXT * p.Y * p.Z * p.C0 * ES < (1ll << 32) - 128;
+        if (atab_ok) {
+            const int ox = x0 > 0 ? x0 - 1 : 0, oy = y0 > 0 ? y0 - 1 : 0, oz = z0 > 0 ? z0 - 1 : 0;   // first in-volume halo voxel
+            atab_base = p.in0 + ((((size_t)b * p.X + ox) * p.Y + oy) * p.Z + oz) * (size_t)p.C0 * ES;
+            const unsigned rs = (unsigned)p.C0 * ES;
+#pragma unroll
+            for (int it = 0; it < A_ITERS; ++it) {
+                const int i = tid + it * CONV_THREADS;
+                if (i < A_ITEMS) {
+                    const int row = i >> 3, cpos = i & 7;
+                    const int hx = row / (HY * HZ), hy = (row / HZ) % HY, hz = row % HZ;
+                    const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
+                    const bool ok = gx >= 0 && gx < p.X && gy >= 0 && gy < p.Y && gz >= 0 && gz < p.Z;
+                    const unsigned rel = (unsigned)(((gx - ox) * p.Y + (gy - oy)) * p.Z + (gz - oz));
+                    atab[i] = ok ? rel * rs + (unsigned)((cpos ^ (M16 ? swz16(hz) : swz(hy, hz))) << 4) : 0xffffffffu;
+                    if (!ok) *reinterpret_cast<uint4*>(sA + i * 16) = make_uint4(0, 0, 0, 0);
+                }
+            }
+        }
+    }
     auto dma_stage_a = [&](int s) {
+        // The row -> address arithmetic below is invariant across slices and hipcc hoists it out of the tap loop: ~60 VGPRs per
+        // lane stay live through the whole K walk.  The plain kernel just fits (256 VGPRs, 8 B of scratch); the _cinit
+        // instantiation, whose prologue holds the accumulator-init loads on top, spilled 100 B per lane and paid 25 scratch
+        // reloads in EVERY restage -- most of what made it 5.7 % slower than the plain kernel.  Keeping the arithmetic inside
+        // the restage instead (an opaque copy of the thread index) costs the plain kernel 2 % and the folded launch 3 %.
+        // ATAB (bf16 256-column tile, one directly-read input): the byte offset of every (row, chunk) item from the tile
+        // origin is computed ONCE per workgroup into the 19 KB of LDS the tile leaves free; a restage is then one ds_read and
+        // one DMA per item -- no arithmetic, nothing hoisted (~200 VGPRs, no scratch).  Rows outside the volume are zeroed once
+        // and left out of the DMA.
+        if constexpr (ATAB) {
+            if (atab_ok) {
+                const char* sb = atab_base + (size_t)s * (KC * ES);
+#pragma unroll
+                for (int it = 0; it < A_ITERS; ++it) {
+                    const int i = tid + it * CONV_THREADS;
+                    if (i < A_ITEMS) {
+                        const unsigned e = atab[i];
+                        if (e != 0xffffffffu) {
+                            unsigned keep;
+                            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                                         : "=&s"(keep)
+                                         : "v"(e), "s"(sb), "s"(sA_lds + (it * CONV_THREADS + wave * 64) * 16)
+                                         : "memory");
+                        }
+                    }
+                }
+                return;
+            }
+        }
+        // general form (two inputs, nearest-upsampled first input): addresses from scratch.  In the table kernels an opaque
+        // copy of the thread index keeps this arithmetic from being hoisted over the tap loop all the same.
+        int tid_g = tid;
+        if constexpr (ATAB) asm volatile("" : "+v"(tid_g));
         const int ch0 = s * KC;
         const bool first = ch0 < p.C0;
         const char* src = first ? p.in0 : p.in1;
@@ -488,7 +556,7 @@ conv3d_k3_kernel(const ConvParams p)
         const bool up = first && p.up0;
 #pragma unroll
         for (int it = 0; it < A_ITERS; ++it) {
-            const int i = tid + it * CONV_THREADS;
+            const int i = tid_g + it * CONV_THREADS;
             if (i < A_ITEMS) {
                 const int row = i >> 3, cpos = i & 7;
                 const int hx = row / (HY * HZ), hy = (row / HZ) % HY, hz = row % HZ;
@@ -1294,7 +1362,10 @@ int launch_conv(const ConvParams& p, int ntiles_n, hipStream_t st, int64_t* nblk
 {
     constexpr int BN = WN * NT * 32;
     constexpr int TXT = WM * MT * 32 / (TY * TZ);
-    constexpr int LDS = (TXT + 2) * HY * HZ * ROWB + 2 * BN * 128;
+    // + the item -> offset table of the bf16 256-column tile (ATAB in the kernel): 600 rows x 8 chunks x 4 B
+    constexpr bool ATAB_L = DT == MMR_DT_BF16 && MT == 4 && TXT == 4 &&
+                            (VAR & (CV_M16 | CV_PIPE | CV_DMA_A)) == (CV_M16 | CV_PIPE | CV_DMA_A) && (VAR & CV_DGFOLD) == 0;
+    constexpr int LDS = (TXT + 2) * HY * HZ * ROWB + 2 * BN * 128 + (ATAB_L ? (TXT + 2) * HY * HZ * 8 * 4 : 0);
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     auto kern = conv3d_k3_kernel<DT, WM, WN, MT, NT, VAR>;
