@@ -116,13 +116,6 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 // the gradient lands compact at low resolution (no full-resolution intermediate, no 2x2x2 pooling pass), and the masked
 // epilogue (LeakyReLU backward + bias sums of the layer that produced x) applies unchanged.  fp32x3 / x1 tensors only.
 constexpr int CV_DGFOLD = 1 << 19;
-// bf16 256-column tile: weight fragments from L2 straight into registers (no weight LDS, no barrier per tap); see the kernel
-constexpr int CV_BREG = 1 << 20;
-#ifdef MMR_BREG
-constexpr int kBREG = CV_BREG;
-#else
-constexpr int kBREG = 0;
-#endif
 
 #ifdef MMR_DIAG
 int g_diag_stamps = 0;   // host switch of the stamped instantiations (conv and wgrad), set by mmr_debug_set_stamps
@@ -244,8 +237,6 @@ conv3d_k3_kernel(const ConvParams p)
     constexpr bool CINIT = (VAR & CV_CINIT) != 0;
     constexpr bool PART16 = (VAR & CV_PART16) != 0;
     constexpr bool DGF = (VAR & CV_DGFOLD) != 0;
-    constexpr bool BREG = (VAR & CV_BREG) != 0;
-    static_assert(!BREG || (MIDDMA && !DGF && TXT == 4 && ((VAR & CV_DMA_A) != 0)), "register-fed weights: the bf16 256-column tile");
     static_assert(!DGF || (!UPF && !CINIT && ((VAR & CV_M16) != 0) && ((VAR & CV_BATCHA) != 0) &&
                            (DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1)), "dgrad fold: fp32x3 / x1, batched staging");
     constexpr int TAPS = (UPF || ((VAR & CV_DGFOLD) != 0)) ? 8 : 27;
@@ -503,7 +494,7 @@ conv3d_k3_kernel(const ConvParams p)
     bool atab_ok = false;
     const char* atab_base = nullptr;
     if constexpr (ATAB) {
-        atab_ok = BREG || (p.C1 == 0 && !p.up0 && (long long)HXT * p.Y * p.Z * p.C0 * ES < (1ll << 32) - 128);
+        atab_ok = p.C1 == 0 && !p.up0 && (long long)HXT * p.Y * p.Z * p.C0 * ES < (1ll << 32) - 128;
         if (atab_ok) {
             const int ox = x0 > 0 ? x0 - 1 : 0, oy = y0 > 0 ? y0 - 1 : 0, oz = z0 > 0 ? z0 - 1 : 0;   // first in-volume halo voxel
             atab_base = p.in0 + ((((size_t)b * p.X + ox) * p.Y + oy) * p.Z + oz) * (size_t)p.C0 * ES;
@@ -534,21 +525,25 @@ conv3d_k3_kernel(const ConvParams p)
         // one DMA per item -- no arithmetic, nothing hoisted (~200 VGPRs, no scratch).  Rows outside the volume are zeroed once
         // and left out of the DMA.
         if constexpr (ATAB) {
-            if (BREG || atab_ok) {   // CV_BREG kernels are launched for table-eligible inputs only (dispatch_conv)
+            if (atab_ok) {
                 const char* sb = atab_base + (size_t)s * (KC * ES);
 #pragma unroll
                 for (int it = 0; it < A_ITERS; ++it) {
                     const int i = tid + it * CONV_THREADS;
                     if (i < A_ITEMS) {
                         const unsigned e = atab[i];
-                        if (e != 0xffffffffu)
-                            glds16_s(sb, e, __builtin_amdgcn_readfirstlane(sA_lds + (it * CONV_THREADS + wave * 64) * 16));
+                        if (e != 0xffffffffu) {
+                            unsigned keep;
+                            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                                         : "=&s"(keep)
+                                         : "v"(e), "s"(sb), "s"(sA_lds + (it * CONV_THREADS + wave * 64) * 16)
+                                         : "memory");
+                        }
                     }
                 }
                 return;
             }
         }
-        if constexpr (BREG) return;
         // general form (two inputs, nearest-upsampled first input): addresses from scratch.  In the table kernels an opaque
         // copy of the thread index keeps this arithmetic from being hoisted over the tap loop all the same.
         int tid_g = tid;
@@ -582,7 +577,7 @@ conv3d_k3_kernel(const ConvParams p)
     const int g0 = p.kpart ? (int)blockIdx.z * p.gsplit : 0;
     const int g1 = p.kpart ? min(g0 + p.gsplit, G) : G;
     int cur = 0, tap = g0 % TAPS, s = g0 / TAPS;
-    if constexpr (!BREG) issue_b(g0, 0);
+    issue_b(g0, 0);
     // a macro, not a lambda: wrapped in one more closure, hipcc no longer scalarises the by-value kernel argument
     // struct and every instantiation reads ConvParams from scratch (288 B/lane; the bn64 convs ran 1.8x slower)
     // named scalars, not an array: an indexed array of structs stays in scratch here even when unrolled
@@ -624,89 +619,6 @@ conv3d_k3_kernel(const ConvParams p)
             _Pragma("unroll") for (int it = 0; it < A_ITERS; ++it) store_a(it, load_a(sl, it)); \
         } \
     } while (0)
-    if constexpr (BREG) {
-        // ---- CV_BREG: weight fragments straight from L2 into registers, no weight LDS, no barrier per tap ----
-        // Every wave loads ITS fragments of the next tap (8 x 16 B per lane: the same [chunk][col][16 B] image, the same lane ->
-        // (col, chunk) map the LDS reads used) while it multiplies the current one out of a second register set; the compiler's
-        // own vmcnt bookkeeping waits for them where the next tap first uses them.  The workgroup meets only to swap the A tile
-        // (twice per 27-tap slice instead of a barrier after every tap), so the two waves of a SIMD drift apart freely and the
-        // LDS serves the 16 A fragments of a tap only.
-        // Registers: k-step 0 of the NEXT tap is prefetched into a second set (it is the first thing that tap needs); k-step 1 of
-        // the CURRENT tap is loaded at the top of the tap and first used 32 MFMAs later -- 48 fragment registers instead of 64
-        // (with all of a tap double-buffered the kernel spilled inside the loop and every reload's vmcnt(0) drained the prefetch)
-        uint4 fb0[2][4], fb1[4];   // fb0[set][N tile], fb1[N tile]; indexed with compile-time constants only, or they land in scratch
-        auto ldb0 = [&](int g, auto ST) {
-            constexpr int S_ = decltype(ST)::value;
-            const char* wt = wtile + (size_t)g * B_BYTES + b16_off[0];
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) fb0[S_][ni] = *reinterpret_cast<const uint4*>(wt + ni * 256);
-        };
-        auto ldb1 = [&](int g) {
-            const char* wt = wtile + (size_t)g * B_BYTES + b16_off[0] + 4 * BN * 16;
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) fb1[ni] = *reinterpret_cast<const uint4*>(wt + ni * 256);
-        };
-        ldb0(g0, IntTag<0>{});
-        dma_stage_a(s);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int g = g0;
-        // a macro, not a lambda: one more closure level and hipcc stops scalarising ConvParams / the accumulators (880 B of scratch)
-#define MMR_BREG_TAP(C_) \
-        do { \
-            const bool more = g + 1 < g1; \
-            ldb1(g); \
-            ldb0(more ? g + 1 : g, IntTag<(C_) ^ 1>{}); \
-            const int dx = UPF ? ((cls >> 2) & 1) + ((tap >> 2) & 1) : tap / 9; \
-            const int dy = UPF ? ((cls >> 1) & 1) + ((tap >> 1) & 1) : (tap / 3) % 3; \
-            const int dz = UPF ? (cls & 1) + (tap & 1) : tap % 3; \
-            const int sw16 = swz16((r16 & 7) + dz); \
-            const char* bA = sA + (dx * (HY * HZ) + dy * HZ + dz) * ROWB + a16_off[0]; \
-            const char* pa0 = bA + ((q16 ^ sw16) << 4); \
-            const char* pa1 = bA + (((4 + q16) ^ sw16) << 4); \
-            uint4 fa[2][8]; \
-            auto rd = [&](int i) { \
-                const int mi = i & 7; \
-                fa[i >> 3][mi] = *reinterpret_cast<const uint4*>((i < 8 ? pa0 : pa1) + (((mi >> 2) * HY + ((mi >> 1) & 1) * 4 + 2 * (mi & 1)) * HZ) * ROWB); \
-            }; \
-            auto mm = [&](int j) { \
-                const int ks = j >> 5, mi = (j >> 2) & 7, ni = j & 3; \
-                acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16( \
-                    __builtin_bit_cast(bf16x8, ks ? fb1[ni] : fb0[C_][ni]), __builtin_bit_cast(bf16x8, fa[ks][mi]), acc16[mi][ni], 0, 0, 0); \
-            }; \
-_Pragma("unroll") \
-            for (int i = 0; i < 16; ++i) rd(i); \
-_Pragma("unroll") \
-            for (int j = 0; j < 64; ++j) mm(j); \
-            __builtin_amdgcn_sched_group_barrier(0x020, 8, 0); \
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0); \
-_Pragma("unroll") \
-            for (int k = 0; k < 12; ++k) { \
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); \
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
-            } \
-_Pragma("unroll") \
-            for (int k = 0; k < 4; ++k) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); \
-            ++g; \
-            ++tap; \
-            if (tap == TAPS) { \
-                tap = 0; \
-                ++s; \
-                if (s < nslices && more) { \
-                    __syncthreads(); \
-                    dma_stage_a(s); \
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
-                    __syncthreads(); \
-                } \
-            } \
-        } while (0)
-        while (g + 1 < g1) {   // one exit: with a break between the two taps hipcc stops accumulating in place
-            MMR_BREG_TAP(0);
-            MMR_BREG_TAP(1);
-        }
-        if (g < g1) MMR_BREG_TAP(0);
-#undef MMR_BREG_TAP
-    } else {
     if constexpr (DMA_A) {
         dma_stage_a(s);
     } else {
@@ -928,7 +840,6 @@ _Pragma("unroll") \
             }
         }
     }
-    }   // !BREG
 #ifdef MMR_DIAG
     if constexpr (STAMP) {
         if (lane == 0) {
@@ -1527,12 +1438,7 @@ int dispatch_conv(const ConvParams& p, hipStream_t st, int64_t* nblk_out = nullp
     if (stamps && BN == 64) return launch_conv<DT, 8, 1, 2, 2, V_FULL | CV_BATCHA | CV_PRIO_Y | CV_STAMP>(p, nt, st, nblk_out);
 #endif
     switch (BN) {
-        case 256:
-            if constexpr (DT == MMR_DT_BF16 && kBREG != 0) {
-                if (p.C1 == 0 && !p.up0 && 6ll * p.Y * p.Z * p.C0 * 2 < (1ll << 32) - 128)
-                    return launch_conv<DT, 2, 4, 4, 2, V_FULL | kBREG>(p, nt, st, nblk_out);
-            }
-            return launch_conv<DT, 2, 4, 4, 2, V_FULL | (F32T ? CV_BATCHA : 0)>(p, nt, st, nblk_out);
+        case 256: return launch_conv<DT, 2, 4, 4, 2, V_FULL | (F32T ? CV_BATCHA : 0)>(p, nt, st, nblk_out);
         case 128:
             if (DT == MMR_DT_BF16) return launch_conv<DT, 4, 2, 4, 2, CV_M16>(p, nt, st, nblk_out);
             return launch_conv<DT, 4, 2, 4, 2, V_FULL | CV_BATCHA>(p, nt, st, nblk_out);
@@ -1553,12 +1459,7 @@ int dispatch_conv_fold(const ConvParams& p, hipStream_t st, int64_t* nblk_out = 
     static_assert(!((EXTRA & CV_PART16) != 0 && F32T), "half partial: bf16 layers only");
     constexpr int V_FULL = CV_M16 | CV_PIPE | CV_DMA_A;
     switch (BN) {
-        case 256:
-            if constexpr (DT == MMR_DT_BF16 && kBREG != 0) {
-                if (6ll * p.Y * p.Z * p.C0 * 2 < (1ll << 32) - 128)   // (one input, read directly)
-                    return launch_conv<DT, 2, 4, 4, 2, V_FULL | kBREG | EXTRA>(p, nt, st, nblk_out);
-            }
-            return launch_conv<DT, 2, 4, 4, 2, V_FULL | (F32T ? CV_BATCHA : 0) | EXTRA>(p, nt, st, nblk_out);
+        case 256: return launch_conv<DT, 2, 4, 4, 2, V_FULL | (F32T ? CV_BATCHA : 0) | EXTRA>(p, nt, st, nblk_out);
         case 128:
             if constexpr (DT == MMR_DT_BF16) return launch_conv<DT, 4, 2, 4, 2, CV_M16 | EXTRA>(p, nt, st, nblk_out);
             else return launch_conv<DT, 4, 2, 4, 2, V_FULL | CV_BATCHA | EXTRA>(p, nt, st, nblk_out);
