@@ -15,5 +15,9 @@ python bench.py --workload cascade --steps 5 --warmup 1 > gpurun_out/${tag}_benc
 MMR_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 3 --warmup 1 > gpurun_out/${tag}_bench_2ranks_gloo.json
 python tools/time_upfold.py > gpurun_out/${tag}_time_upfold.txt 2>&1
 python tools/time_c2_layers.py > gpurun_out/${tag}_time_c2_layers.txt 2>&1
+python tools/time_tail_layers.py > gpurun_out/${tag}_time_tail_layers.txt 2>&1
+python tools/hbm_ceiling.py > gpurun_out/${tag}_hbm_ceiling.txt 2>&1
+python tools/time_ncc_overlap.py > gpurun_out/${tag}_time_ncc_overlap.txt 2>&1
+MMR_BENCH_BACKEND=gloo python bench.py --gpus 4 --steps 3 --warmup 1 > gpurun_out/${tag}_bench_4ranks_gloo.json
 [ -x tools/ubench/mfma_ceiling ] && ./tools/ubench/mfma_ceiling > gpurun_out/${tag}_mfma_ceiling.txt 2>&1
 echo done
