@@ -26,6 +26,7 @@ CASES = [
     ((4, 8, 16), 256, 256, True, 256),      # the dec_final_0 shape class
     ((5, 9, 7), 64, 0, False, 3),           # flow head (Cout padded to 32), odd sizes
     ((2, 2, 2), 64, 0, False, 64),          # deepest level of a 32^3 volume
+    ((5, 9, 11), 128, 0, False, 256),       # 256-column tile, batch of 2, ragged on every axis: the restage's LDS offset table
 ]
 
 
