@@ -499,6 +499,10 @@ conv3d_k3_kernel(const ConvParams p)
             const int ox = x0 > 0 ? x0 - 1 : 0, oy = y0 > 0 ? y0 - 1 : 0, oz = z0 > 0 ? z0 - 1 : 0;   // first in-volume halo voxel
             atab_base = p.in0 + ((((size_t)b * p.X + ox) * p.Y + oy) * p.Z + oz) * (size_t)p.C0 * ES;
             const unsigned rs = (unsigned)p.C0 * ES;
+            // the first slice of this block's K range goes out from the registers while the table is being written: its DMAs
+            // overlap the arithmetic of the items behind them instead of waiting for the whole table (1.6 k cycles per tile)
+            const int s_first = (p.kpart ? (int)blockIdx.z * p.gsplit : 0) / TAPS;
+            const char* sb_first = atab_base + (size_t)s_first * (KC * ES);
 #pragma unroll
             for (int it = 0; it < A_ITERS; ++it) {
                 const int i = tid + it * CONV_THREADS;
@@ -508,8 +512,17 @@ conv3d_k3_kernel(const ConvParams p)
                     const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
                     const bool ok = gx >= 0 && gx < p.X && gy >= 0 && gy < p.Y && gz >= 0 && gz < p.Z;
                     const unsigned rel = (unsigned)(((gx - ox) * p.Y + (gy - oy)) * p.Z + (gz - oz));
-                    atab[i] = ok ? rel * rs + (unsigned)((cpos ^ (M16 ? swz16(hz) : swz(hy, hz))) << 4) : 0xffffffffu;
-                    if (!ok) *reinterpret_cast<uint4*>(sA + i * 16) = make_uint4(0, 0, 0, 0);
+                    const unsigned e = rel * rs + (unsigned)((cpos ^ (M16 ? swz16(hz) : swz(hy, hz))) << 4);
+                    atab[i] = ok ? e : 0xffffffffu;
+                    if (ok) {
+                        unsigned keep;
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                                     : "=&s"(keep)
+                                     : "v"(e), "s"(sb_first), "s"(sA_lds + (it * CONV_THREADS + wave * 64) * 16)
+                                     : "memory");
+                    } else {
+                        *reinterpret_cast<uint4*>(sA + i * 16) = make_uint4(0, 0, 0, 0);
+                    }
                 }
             }
         }
@@ -620,7 +633,7 @@ conv3d_k3_kernel(const ConvParams p)
         } \
     } while (0)
     if constexpr (DMA_A) {
-        dma_stage_a(s);
+        if (!(ATAB && atab_ok)) dma_stage_a(s);   // table kernels: already issued while the table was written
     } else {
         MMR_STAGE_A_REGS(s);
     }
