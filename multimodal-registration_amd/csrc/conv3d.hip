@@ -495,6 +495,7 @@ conv3d_k3_kernel(const ConvParams p)
     const char* atab_base = nullptr;
     if constexpr (ATAB) {
         atab_ok = p.C1 == 0 && !p.up0 && (long long)HXT * p.Y * p.Z * p.C0 * ES < (1ll << 32) - 128;
+        issue_b(p.kpart ? (int)blockIdx.z * p.gsplit : 0, 0);   // the first weight block is under way before the table arithmetic
         if (atab_ok) {
             const int ox = x0 > 0 ? x0 - 1 : 0, oy = y0 > 0 ? y0 - 1 : 0, oz = z0 > 0 ? z0 - 1 : 0;   // first in-volume halo voxel
             atab_base = p.in0 + ((((size_t)b * p.X + ox) * p.Y + oy) * p.Z + oz) * (size_t)p.C0 * ES;
@@ -590,7 +591,7 @@ conv3d_k3_kernel(const ConvParams p)
     const int g0 = p.kpart ? (int)blockIdx.z * p.gsplit : 0;
     const int g1 = p.kpart ? min(g0 + p.gsplit, G) : G;
     int cur = 0, tap = g0 % TAPS, s = g0 / TAPS;
-    issue_b(g0, 0);
+    if constexpr (!ATAB) issue_b(g0, 0);
     // a macro, not a lambda: wrapped in one more closure, hipcc no longer scalarises the by-value kernel argument
     // struct and every instantiation reads ConvParams from scratch (288 B/lane; the bn64 convs ran 1.8x slower)
     // named scalars, not an array: an indexed array of structs stays in scratch here even when unrolled
