@@ -587,6 +587,14 @@ conv3d_k3_kernel(const ConvParams p)
         }
     };
 
+    // the epilogue's 16 bias values per lane, loaded here in the table kernels (they have the registers): their round trip
+    // is then not the first thing a finished tile waits for
+    float bias_pre[16];
+    if constexpr (ATAB && !UPF) {
+        const int cop = (int)blockIdx.y * BN + wn * 64 + q16 * 16;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bias_pre[e] = (p.bias && cop + e < p.Cout) ? p.bias[cop + e] : 0.f;
+    }
     // ---- prologue: first slice of A, first tap of B of this block's step range ----
     const int g0 = p.kpart ? (int)blockIdx.z * p.gsplit : 0;
     const int g1 = p.kpart ? min(g0 + p.gsplit, G) : G;
@@ -978,7 +986,8 @@ conv3d_k3_kernel(const ConvParams p)
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                bv[ni][r] = (p.bias && co + ni * 4 + r < p.Cout) ? p.bias[co + ni * 4 + r] : 0.f;
+                if constexpr (ATAB && !UPF) bv[ni][r] = bias_pre[ni * 4 + r];
+                else bv[ni][r] = (p.bias && co + ni * 4 + r < p.Cout) ? p.bias[co + ni * 4 + r] : 0.f;
                 csum[ni][r] = 0.f;
             }
 #pragma unroll
