@@ -589,8 +589,9 @@ conv3d_k3_kernel(const ConvParams p)
 
     // the epilogue's 16 bias values per lane, loaded here in the table kernels (they have the registers): their round trip
     // is then not the first thing a finished tile waits for
+    constexpr bool BIAS_PRE = !UPF && !DGF && (ATAB || (X3 && BN == 64 && M16));
     float bias_pre[16];
-    if constexpr (ATAB && !UPF) {
+    if constexpr (BIAS_PRE) {
         const int cop = (int)blockIdx.y * BN + wn * 64 + q16 * 16;
 #pragma unroll
         for (int e = 0; e < 16; ++e) bias_pre[e] = (p.bias && cop + e < p.Cout) ? p.bias[cop + e] : 0.f;
@@ -986,7 +987,7 @@ conv3d_k3_kernel(const ConvParams p)
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if constexpr (ATAB && !UPF) bv[ni][r] = bias_pre[ni * 4 + r];
+                if constexpr (BIAS_PRE) bv[ni][r] = bias_pre[ni * 4 + r];
                 else bv[ni][r] = (p.bias && co + ni * 4 + r < p.Cout) ? p.bias[co + ni * 4 + r] : 0.f;
                 csum[ni][r] = 0.f;
             }
