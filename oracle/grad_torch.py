@@ -74,9 +74,23 @@ def grad_l2(y, loss_mult):
     return torch.stack(terms).mean(0) * loss_mult
 
 
+# torch-CPU float64 conv3d is an im2col GEMM: its column buffer is 27 * Cin * 8 bytes PER OUTPUT VOXEL (26 GB for a 128-channel
+# layer at 96 x 96 x 128).  Above this many output voxels per call the conv runs slab by slab along x (same arithmetic, autograd
+# differentiates each slab on its own), so that the gradient oracle can be asked for volumes where the folded kernels engage.
+SLAB_VOXELS = 1 << 17
+
+
 def conv(x, w, b, leaky=True):
     """x [B,X,Y,Z,Cin], keras w [3,3,3,Cin,Cout]."""
-    y = F.conv3d(x.permute(0, 4, 1, 2, 3), w.permute(4, 3, 0, 1, 2), b, padding=1).permute(0, 2, 3, 4, 1)
+    xc, wc = x.permute(0, 4, 1, 2, 3), w.permute(4, 3, 0, 1, 2)
+    B, X, Y, Z, _ = x.shape
+    if SLAB_VOXELS is None or x.dtype != torch.float64 or B * X * Y * Z <= SLAB_VOXELS:
+        y = F.conv3d(xc, wc, b, padding=1)
+    else:
+        step = max(SLAB_VOXELS // (B * Y * Z), 1)
+        xp = F.pad(xc, (0, 0, 0, 0, 1, 1))
+        y = torch.cat([F.conv3d(xp[:, :, x0:min(x0 + step, X) + 2], wc, b, padding=(0, 1, 1)) for x0 in range(0, X, step)], 2)
+    y = y.permute(0, 2, 3, 4, 1)
     return F.leaky_relu(y, 0.2) if leaky else y
 
 

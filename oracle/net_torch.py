@@ -54,28 +54,41 @@ def vecint(v, nsteps):
     return v
 
 
-def prepare_weights(weights, dtype=torch.float32):
-    """Keras [3,3,3,Cin,Cout] kernels -> torch [Cout,Cin,3,3,3] in channels-last-3d (done once, outside the timing)."""
+def bf16_round(t):
+    """Round-to-nearest-even to bf16 and back (the same values as oracle/net_np.bf16_round)."""
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def prepare_weights(weights, dtype=torch.float32, quant=None):
+    """Keras [3,3,3,Cin,Cout] kernels -> torch [Cout,Cin,3,3,3] in channels-last-3d (done once, outside the timing).
+    ``quant`` (e.g. bf16_round) is applied to the kernels, not to the biases, as oracle/net_np.vxm_dense_forward does."""
     out = []
     for i in range(0, len(weights), 2):
-        w = torch.as_tensor(weights[i], dtype=dtype).permute(4, 3, 0, 1, 2).contiguous(memory_format=torch.channels_last_3d)
+        w = torch.as_tensor(weights[i], dtype=dtype)
+        if quant is not None:
+            w = quant(w)
+        w = w.permute(4, 3, 0, 1, 2).contiguous(memory_format=torch.channels_last_3d)
         out.append((w, torch.as_tensor(weights[i + 1], dtype=dtype)))
     return out
 
 
 @torch.no_grad()
-def vxm_dense_forward(moving, fixed, tw, enc, dec, int_steps=5, int_resolution=2, svf_resolution=2):
-    """moving / fixed: torch [B,X,Y,Z,1]; tw = prepare_weights(...) -> dict(moved, preint_flow, pos_flow) (NDHWC)."""
+def vxm_dense_forward(moving, fixed, tw, enc, dec, int_steps=5, int_resolution=2, svf_resolution=2, quant=None):
+    """moving / fixed: torch [B,X,Y,Z,1]; tw = prepare_weights(...) -> dict(moved, preint_flow, pos_flow) (NDHWC).
+    ``quant`` (e.g. bf16_round; pass the same to prepare_weights) rounds every conv's input and every LeakyReLU conv's
+    output -- the rounding points of a reduced-precision HIP path, exactly those of oracle/net_np.vxm_dense_forward(quant=)."""
     if int_resolution != svf_resolution:
         raise NotImplementedError("int_resolution == svf_resolution (every configuration the reference ships)")
     nlev = len(enc)
     x = torch.cat([moving, fixed], -1).permute(0, 4, 1, 2, 3).contiguous(memory_format=torch.channels_last_3d)
     it = iter(tw)
 
+    q = (lambda a: a) if quant is None else quant
+
     def conv(a, leaky=True):
         w, b = next(it)
-        y = F.conv3d(a, w, b, padding=1)
-        return F.leaky_relu_(y, 0.2) if leaky else y
+        y = F.conv3d(q(a), w, b, padding=1)
+        return q(F.leaky_relu_(y, 0.2)) if leaky else y
     skips = []
     last = x
     for _ in range(nlev):

@@ -271,3 +271,48 @@ def test_first_layer_fused_maxpool(dev, shape, Cout, odt):
     assert torch.equal(pooled, ref)
     from oracle import ops_np as O
     np.testing.assert_array_equal(pooled.float().cpu().numpy(), O.maxpool2(plain.float().cpu().numpy()))
+
+
+def test_half_partial_of_folded_pair_saturates_at_the_half_range(dev):
+    """include/mmr.h (mmr_conv3d_k3_upfold_fwd, partial_half): the tensor between the two launches of a bf16 layer is IEEE
+    half SATURATED to +-65504.  Drive the upsampled half's sums past that (activations 512, output channel co sums co input
+    channels with weight +-1/4: +-27 * 128 * co in the interior, fewer taps on the border): the half partial holds exactly
+    the clamped sums (every unsaturated one is a multiple of 128 below 2^16: exact in half; never inf / NaN), the fp32 partial
+    the true sums, and the second launch adds the skip half to the clamped value -- the documented behaviour for weights far
+    outside the He-init range; ``half_partial=False`` / ``fold_upsampling=False`` are the exact ways to run such a layer."""
+    import mmr
+    from oracle.cbind import conv3d_same
+    from oracle.net_np import bf16_round
+    from oracle import ops_np as O
+    ops = mmr.ops
+    rng = np.random.default_rng(41)
+    B, X, Y, Z, C0, C1, Cout = 1, 8, 16, 16, 64, 64, 64
+    a0 = np.full((B, X // 2, Y // 2, Z // 2, C0), 512.0, np.float32)
+    a1 = bf16_round(rng.standard_normal((B, X, Y, Z, C1)).astype(np.float32))
+    w = rng.choice([-0.25, 0.25], size=(3, 3, 3, C0 + C1, Cout)).astype(np.float32)
+    sgn = np.where(np.arange(Cout) % 2 == 0, 0.25, -0.25).astype(np.float32)
+    w[:, :, :, :C0, :] = np.where(np.arange(C0)[:, None] < np.arange(Cout)[None, :], sgn[None, :], 0.0)
+    wd = torch.from_numpy(w).to(dev)
+    w_up, w_skip = ops.pack_upfold_weights(wd, C0, torch.bfloat16)
+    t0, t1 = torch.from_numpy(a0).to(dev).bfloat16(), torch.from_numpy(a1).to(dev).bfloat16()
+    lib = mmr._lib.load()
+    ref_up = conv3d_same(O.upsample2(a0), np.ascontiguousarray(w[:, :, :, :C0]), None, leaky=False)
+    ref_skip = conv3d_same(a1, np.ascontiguousarray(w[:, :, :, C0:]), None, leaky=False)
+    sat = np.abs(ref_up) > 65504
+    assert sat.mean() > 0.2 and (~sat).mean() > 0.2 and np.abs(ref_up).max() > 2e5
+    parts = {}
+    for half in (True, False):
+        part = torch.full((B, X, Y, Z, Cout), float("nan"), dtype=torch.float16 if half else torch.float32, device=dev)
+        rc = lib.mmr_conv3d_k3_upfold_fwd(t0.data_ptr(), C0, w_up.data_ptr(), part.data_ptr(), int(half), B, X // 2, Y // 2, Z // 2,
+                                          Cout, ops.conv_mode(torch.bfloat16), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        parts[half] = part.float().cpu().numpy()
+    assert np.array_equal(parts[False], ref_up)                      # integers x 128 below 2^24: exact in fp32
+    assert np.isfinite(parts[True]).all()
+    clamped = np.clip(ref_up, -65504.0, 65504.0)
+    assert np.array_equal(parts[True], clamped)
+    out = ops.conv3d_k3_upfold(t0, t1, w_up, w_skip, None, Cout, leaky=False, out_f32=True).cpu().numpy()
+    assert np.isfinite(out).all()
+    assert np.abs(out - (clamped + ref_skip)).max() < 1e-5 * 65504      # fp32 accumulation on a 65504 base (ulp 2^-8)
+    exact = ops.conv3d_k3_upfold(t0, t1, w_up, w_skip, None, Cout, leaky=False, out_f32=True, half_partial=False).cpu().numpy()
+    assert np.abs(exact - (ref_up + ref_skip)).max() < 1e-5 * np.abs(ref_up).max()

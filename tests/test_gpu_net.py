@@ -163,6 +163,45 @@ def test_vxmdense_256_features_80x80x96_matches_torch_oracle(dev):
         assert err < 1e-4, f"{name}: rel-to-scale err {err:.3e} >= 1e-4"
 
 
+def test_vxmdense_256_features_80x80x96_bf16_folded_matches_rounding_oracle(dev):
+    """The arithmetic the benchmark line is quoted in -- bf16, enc/dec = 256 (3d_reg.py:297-305 with
+    config_inference.json:8-9) -- as a WHOLE forward at a size where networks.py::_conv folds decoder layers (asserted
+    through ops.PROFILE: the `_upfold` and `_cinit` launches with the half partial ran), against oracle/net_torch with
+    bf16 rounding at the same points (conv inputs, kernels, LeakyReLU outputs; checked against oracle/net_np's on CPU).
+    Gate 2e-2 of each output's scale over the 10-conv-deep network, as for the unfolded 32x32x48 case."""
+    import mmr
+    from oracle import net_np, net_torch
+    shape, enc, dec = (80, 80, 96), [256] * 4, [256] * 6
+    rng = np.random.default_rng(21)
+    mov, fix = _pair(rng, shape)
+    weights = net_np.init_weights(enc, dec, seed=7, flow_std=1e-2)
+    for i in range(1, len(weights), 2):
+        weights[i] = (rng.standard_normal(weights[i].shape) * 0.05).astype(np.float32)
+    model = mmr.networks.VxmDense(shape, nb_unet_features=(enc, dec), int_steps=5, int_resolution=2,
+                                  svf_resolution=2, compute_dtype="bf16")
+    model.set_weights(weights)
+    mmr.ops.PROFILE = []
+    try:
+        moved, preint = model.predict([mov, fix])
+        fams = [f for f, *_ in mmr.ops.PROFILE]
+    finally:
+        mmr.ops.PROFILE = None
+    assert sum(f.endswith("bf16_bn256_upfold") for f in fams) >= 1 and sum(f.endswith("bf16_bn256_cinit") for f in fams) >= 1, fams
+    pos = model.references.pos_flow.cpu().numpy()
+    q = net_torch.bf16_round
+    ref = net_torch.vxm_dense_forward(torch.from_numpy(mov), torch.from_numpy(fix), net_torch.prepare_weights(weights, quant=q),
+                                      enc, dec, 5, 2, 2, quant=q)
+    ref = {k: v.numpy() for k, v in ref.items()}
+    assert np.abs(ref["pos_flow"]).max() > 0.5, "test flow too small to be meaningful"
+    errs = {}
+    for name, got, exp in (("preint_flow", preint, ref["preint_flow"]), ("pos_flow", pos, ref["pos_flow"]),
+                           ("moved", moved, ref["moved"])):
+        errs[name] = np.abs(got - exp).max() / np.abs(exp).max()
+    print("80x80x96 / 256-feature whole-net parity [bf16, folded]: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    for name, err in errs.items():
+        assert err < 2e-2, f"{name}: rel-to-scale err {err:.3e} >= 2e-2"
+
+
 def test_input_model_wires_the_generator_pair(dev):
     """train_synthmorph.py:288-296: ``VxmDense(..., input_model=Model(labels -> (ima_1, ima_2)))`` -- the model's inputs are
     the two label maps, its source / target the generators' images.  Same seeds, same draws: predicting through the

@@ -295,20 +295,26 @@ def test_full_training_step_gradients(dev, cdt, kinks, tol, enc, dec):
     (oracle/grad_torch.py::unet), i.e. differentiates the same linear piece of the piecewise-linear net; both
     arithmetic modes -- fp32x3 is the API default and the only one with the split-store dgrad -- must then meet
     north_star's 1e-4 on EVERY gradient tensor."""
+    _check_step_gradients(dev, cdt, kinks, tol, enc, dec)
+
+
+def _check_step_gradients(dev, cdt, kinks, tol, enc, dec, shape=(16, 16, 32), L=5, B=2, block=4, int_steps=3, families=()):
+    """Every gradient tensor of one SynthMorph step (train_synthmorph.py:296-308) against oracle/grad_torch.synthmorph_loss;
+    ``families``: kernel-family suffixes that must have run (ops.PROFILE) -- the folded launches at sizes where they engage."""
     import mmr
     from mmr import synth, training
     from oracle import grad_torch as G
     from oracle import net_np
-    shape, L, B = (16, 16, 32), 5, 2
     rng = np.random.default_rng(7)
-    coarse = rng.integers(0, L, (B, 4, 4, 8))
-    lab_s = np.repeat(np.repeat(np.repeat(coarse, 4, 1), 4, 2), 4, 3).astype(np.uint8)[..., None]
-    coarse = rng.integers(0, L, (B, 4, 4, 8))
-    lab_t = np.repeat(np.repeat(np.repeat(coarse, 4, 1), 4, 2), 4, 3).astype(np.uint8)[..., None]
+    cs = tuple(s // block for s in shape)
+    coarse = rng.integers(0, L, (B,) + cs)
+    lab_s = np.repeat(np.repeat(np.repeat(coarse, block, 1), block, 2), block, 3).astype(np.uint8)[..., None]
+    coarse = rng.integers(0, L, (B,) + cs)
+    lab_t = np.repeat(np.repeat(np.repeat(coarse, block, 1), block, 2), block, 3).astype(np.uint8)[..., None]
     kw = dict(in_shape=shape, in_label_list=np.arange(L), out_label_list=np.arange(L), warp_std=2, warp_res=8, blur_std=1,
               bias_std=0.3, bias_res=8, gamma_std=0.25)
     g1, g2 = synth.labels_to_image(**kw, id=0, seed=1), synth.labels_to_image(**kw, id=1, seed=2)
-    model = mmr.networks.VxmDense(shape, nb_unet_features=(enc, dec), int_steps=3, int_resolution=2, svf_resolution=2,
+    model = mmr.networks.VxmDense(shape, nb_unet_features=(enc, dec), int_steps=int_steps, int_resolution=2, svf_resolution=2,
                                   compute_dtype=cdt)
     ws = net_np.init_weights(enc, dec, seed=3, flow_std=3e-2)
     for i in range(1, len(ws), 2):
@@ -324,28 +330,46 @@ def test_full_training_step_gradients(dev, cdt, kinks, tol, enc, dec):
     lab1, lab2 = gen1["labels"], gen2["labels"]
     tape = []
     tr.gflat.zero_()
-    flow = tr._forward(ima1, ima2, tape)
-    svf, steps, pos_lo, pos = tr._tail_forward(flow)
-    dice, tb = mmr.ops.dice_labels_fwd(lab1, lab2, pos, L)
-    gl = mmr.ops.grad_l2_loss(pos, 0.8)
-    dpos = mmr.ops.dice_labels_bwd(lab1, lab2, pos, tb, L, scale=float(B))
-    mmr.ops.grad_l2_bwd(pos, 0.8, 1.0, out=dpos)
-    tr._backward(tape, tr._tail_backward(dpos, svf, steps))
+    mmr.ops.PROFILE = [] if families else None
+    try:
+        flow = tr._forward(ima1, ima2, tape)
+        svf, steps, pos_lo, pos = tr._tail_forward(flow)
+        dice, tb = mmr.ops.dice_labels_fwd(lab1, lab2, pos, L)
+        gl = mmr.ops.grad_l2_loss(pos, 0.8)
+        dpos = mmr.ops.dice_labels_bwd(lab1, lab2, pos, tb, L, scale=float(B))
+        mmr.ops.grad_l2_bwd(pos, 0.8, 1.0, out=dpos)
+        tr._backward(tape, tr._tail_backward(dpos, svf, steps))
+        ran = {f for f, *_ in (mmr.ops.PROFILE or [])}
+    finally:
+        mmr.ops.PROFILE = None
+    for suffix in families:
+        assert any(f.endswith(suffix) for f in ran), (suffix, sorted(ran))
     wt = [torch.from_numpy(w).double().requires_grad_(True) for w in ws]
     kk = None
     if kinks:  # activated outputs of the LeakyReLU layers, execution order (tape: conv0 / conv records)
         kk = [(r[4] if r[0] == "conv0" else r[5]).cpu().double() for r in tape
               if r[0] == "conv0" or (r[0] == "conv" and r[6])]
     total, rdice, rgl, rpos, rflow = G.synthmorph_loss(ima1.cpu().double(), ima2.cpu().double(), gen1["onehot"].cpu().double(),
-                                                      gen2["onehot"].cpu().double(), wt, enc, dec, 3, 0.8, kinks=kk)
+                                                      gen2["onehot"].cpu().double(), wt, enc, dec, int_steps, 0.8, kinks=kk)
     total.backward()
     assert np.abs(rpos.detach().numpy()).max() > 0.3, "flow too small to exercise the warp"
     assert _rel(flow, rflow) < 1e-4 and _rel(pos, rpos) < 1e-4
     assert abs(float(dice) - float(rdice.detach())) < 1e-5 and _rel(gl, rgl) < 1e-4
     names = [p[0] for p in model.plan]
-    for i, (g, w) in enumerate(zip(tr.g, wt)):
-        err = _rel(g, w.grad)
+    errs = [_rel(g, w.grad) for g, w in zip(tr.g, wt)]
+    if families:
+        print(f"step gradients at {shape} [{cdt}]: worst {max(errs):.2e} ({names[int(np.argmax(errs)) // 2]})")
+    for i, err in enumerate(errs):
         assert err < tol, f"{names[i // 2]} {'bias' if i % 2 else 'kernel'}: {err:.2e}"
+
+
+def test_folded_training_step_gradients_vs_oracle(dev):
+    """BASELINE configs[2]'s architecture (config/config.json:44-45) at 96 x 96 x 128, where all three folded kernels of the
+    training step engage for dec_final_0 (forward upfold + cinit, folded data gradient, folded weight gradient -- asserted):
+    all 22 gradient tensors against the float64 gradient oracle on the HIP forward's linear piece at north_star's 1e-4.
+    (The unfolded-vs-folded self-comparison below stays; this one is the oracle gate.)"""
+    _check_step_gradients(dev, "fp32x3", True, 1e-4, [64] * 4, [64] * 6, shape=(96, 96, 128), L=6, B=1, block=8, int_steps=5,
+                          families=("_upfold", "_cinit", "_dgfold", "wgrad_mfma_f32x3_upfold"))
 
 
 def test_training_lowers_loss_and_is_reproducible(dev):

@@ -256,6 +256,54 @@ def test_torch_cpu_baseline_graph_equals_numpy_oracle():
         assert np.abs(got[k].numpy() - ref[k]).max() < 2e-5 * max(np.abs(ref[k]).max(), 1), k
 
 
+def test_torch_cpu_graph_with_bf16_rounding_points_equals_numpy_oracle():
+    """net_torch's ``quant`` hooks (what the 80x80x96 bf16 whole-network GPU test compares with) round at the same points as
+    net_np's: same bf16 values in, fp32-vs-double accumulation apart, so the two agree far inside one bf16 step except where a
+    pre-rounding value sits within that accumulation difference of a rounding boundary (rare; bounded by one bf16 ulp)."""
+    from oracle import net_torch
+    enc, dec = [8, 8, 8], [8, 8, 8, 8]
+    r = np.random.default_rng(4)
+    w = net_np.init_weights(enc, dec, seed=3, flow_std=0.05)
+    for i in range(1, len(w), 2):
+        w[i] = (r.standard_normal(w[i].shape) * 0.05).astype(np.float32)
+    x = r.standard_normal((3, 5, 7)).astype(np.float32)
+    assert np.array_equal(net_torch.bf16_round(torch.from_numpy(x)).numpy(), net_np.bf16_round(x))
+    mov = r.random((1, 16, 16, 24, 1)).astype(np.float32)
+    fix = r.random((1, 16, 16, 24, 1)).astype(np.float32)
+    ref = net_np.vxm_dense_forward(mov, fix, w, enc, dec, 5, 2, 2, quant=net_np.bf16_round)
+    plain = net_np.vxm_dense_forward(mov, fix, w, enc, dec, 5, 2, 2)
+    got = net_torch.vxm_dense_forward(torch.from_numpy(mov), torch.from_numpy(fix),
+                                      net_torch.prepare_weights(w, quant=net_torch.bf16_round), enc, dec, 5, 2, 2,
+                                      quant=net_torch.bf16_round)
+    for k in ("moved", "preint_flow", "pos_flow"):
+        sc = max(np.abs(ref[k]).max(), 1)
+        assert np.abs(got[k].numpy() - ref[k]).max() < 2e-3 * sc, k
+        assert np.abs(plain[k] - ref[k]).max() > 1e-4 * sc, k     # the hooks do something
+
+
+def test_slab_conv_of_the_gradient_oracle_equals_the_plain_conv():
+    """oracle/grad_torch.conv splits large float64 convs into x slabs (bounded im2col memory); values and gradients equal the
+    one-call form."""
+    from oracle import grad_torch as G
+    r = np.random.default_rng(2)
+    x = torch.from_numpy(r.standard_normal((2, 11, 6, 5, 3))).requires_grad_(True)
+    w = torch.from_numpy(r.standard_normal((3, 3, 3, 3, 4))).requires_grad_(True)
+    b = torch.from_numpy(r.standard_normal(4)).requires_grad_(True)
+    g = torch.from_numpy(r.standard_normal((2, 11, 6, 5, 4)))
+    outs = []
+    for slab in (None, 4):
+        keep = G.SLAB_VOXELS
+        G.SLAB_VOXELS = None if slab is None else slab * 6 * 5
+        try:
+            y = G.conv(x, w, b, leaky=True)
+        finally:
+            G.SLAB_VOXELS = keep
+        gr = torch.autograd.grad((y * g).sum(), (x, w, b))
+        outs.append((y.detach(), *gr))
+    for a, c in zip(*outs):
+        assert torch.allclose(a, c, rtol=1e-12, atol=1e-12)
+
+
 def test_cpu_training_step_restatement_runs_and_learns():
     """oracle/train_torch.CpuStep (bench.py's training cpu_baseline): generators + fwd + bwd + Adam in fp32 on torch-CPU;
     its loss equals the float64 gradient oracle's on the same generated pair and Adam moves the weights."""
