@@ -42,12 +42,16 @@ class SynthMorphTrainer:
     """model: fp32 VxmDense; gen_1/gen_2: synth.LabelsToImage (sharing the label list)."""
 
     def __init__(self, model, gen_1=None, gen_2=None, reg_param=1.0, optimizer=None, zero_pad_dice=False,
-                 process_group=None, world_size=1, rank=0, backward_precision=None):
+                 process_group=None, world_size=1, rank=0, backward_precision=None, overlap_wgrad=True):
         """gen_1 / gen_2 default to the generator pair of ``model.input_model`` (a model built the reference's way,
         ``VxmDense(..., input_model=InputModel(gen_1, gen_2))``, train_synthmorph.py:294-296).
         backward_precision: None = same arithmetic as the forward (fp32 / fp32x3); 'bf16' = dgrad and wgrad
         products on the bf16 hi halves only (one MFMA instead of three, fp32 accumulate) -- an opt-in
-        mixed-precision backward; the forward (and therefore every output and loss) keeps fp32-grade accuracy."""
+        mixed-precision backward; the forward (and therefore every output and loss) keeps fp32-grade accuracy.
+        overlap_wgrad: the weight-gradient kernels run on a second HIP stream.  Nothing on the backward's critical path
+        (the data-gradient chain) reads a weight gradient before Adam, so the HBM-bound kernels of that chain (pooling /
+        concat / VecInt / resize adjoints, thin-layer gradients) run beside matrix-core wgrad kernels instead of between
+        them, and each stream fills the partial last round of the other's launches.  Same kernels, same results."""
         if model.dtype != torch.float32:
             raise NotImplementedError("training runs the fp32 path (the reference trains in fp32)")
         im = getattr(model, "input_model", None)
@@ -66,6 +70,7 @@ class SynthMorphTrainer:
             raise ValueError("backward_precision must be None or 'bf16'")
         self.bwd_x3 = "hi" if backward_precision == "bf16" else model.x3
         self.pg, self.world, self.rank = process_group, int(world_size), int(rank)
+        self.wstream = torch.cuda.Stream(device=model._flat.device) if (overlap_wgrad and model._flat.is_cuda) else None
         self.gflat = torch.zeros_like(model._flat)
         self.g, off = [], 0
         for w in model._w:
@@ -179,6 +184,21 @@ class SynthMorphTrainer:
             else:
                 grads[id(t)] = g
 
+        side = self.wstream
+
+        def wgrad(fn, dz):
+            """Run the weight-gradient launch ``fn`` behind everything enqueued so far, on the side stream when there is one.
+            ``dz`` is a temporary of the main stream that the side stream reads: the allocator must not hand its block out again
+            before that read has run (record_stream); activations live on the tape until the streams have been joined."""
+            if side is None:
+                return fn()
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                fn()
+            dz.record_stream(side)
+
         for rec in reversed(tape):
             kind = rec[0]
             if kind == "conv":
@@ -190,9 +210,10 @@ class SynthMorphTrainer:
                     dz = ops.leaky_bwd_bias_(y if leaky else None, dy, self.g[2 * li + 1], leaky=leaky)
                 if (up0 and in1 is not None and m.fold_upsampling
                         and ops.wgrad_upfold_supported(x.shape[-1], in1.shape[-1], dz.shape[-1], self.bwd_x3, *dz.shape[:4])):
-                    ops.conv3d_k3_wgrad_upfold(x, in1, dz, self.g[2 * li], x3=self.bwd_x3)   # upsampled rows on the low-res grid
+                    # upsampled rows on the low-res grid
+                    wgrad(lambda: ops.conv3d_k3_wgrad_upfold(x, in1, dz, self.g[2 * li], x3=self.bwd_x3), dz)
                 else:
-                    ops.conv3d_k3_wgrad(x, dz, self.g[2 * li], in1=in1, up0=up0, x3=self.bwd_x3)
+                    wgrad(lambda: ops.conv3d_k3_wgrad(x, dz, self.g[2 * li], in1=in1, up0=up0, x3=self.bwd_x3), dz)
                 C0 = x.shape[-1]
                 C1 = in1.shape[-1] if in1 is not None else 0
                 plain = in1 is None and not up0
@@ -284,7 +305,11 @@ class SynthMorphTrainer:
                 _, li, src, trg, y = rec
                 dy = grads.pop(id(y))
                 dz = dy if id(y) in premasked else ops.leaky_bwd_bias_(y, dy, self.g[1], leaky=True)
-                ops.conv3d_k3_cin2_wgrad(src, trg, dz, self.g[0], x3=bool(self.bwd_x3))
+                wgrad(lambda: ops.conv3d_k3_cin2_wgrad(src, trg, dz, self.g[0], x3=bool(self.bwd_x3)), dz)
+        if side is not None:   # join: Adam / the all-reduce read every weight gradient
+            done = torch.cuda.Event()
+            done.record(side)
+            torch.cuda.current_stream().wait_event(done)
         return grads
 
     # ------------------------------------------------------------------ one step

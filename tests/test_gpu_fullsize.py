@@ -88,13 +88,14 @@ def test_c2_largest_conv_seams_linearity_and_window_vs_oracle(dev, path):
     del in0, in1, y, inner
 
     # (2) random inputs: linearity under a power-of-two scale -- exact with the fp32 partial (and for the one-launch kernel);
-    #     with the half partial exact except where a partial sum falls into the half subnormals (|v| < 2^-14, spacing 2^-24)
+    #     with the half partial exact except where a partial sum falls into the half subnormals (|v| < 2^-14, spacing 2^-24:
+    #     the skip half's fp32 accumulation then starts one subnormal step apart and may round differently a few times)
     in0 = _bf16_randn((1,) + half + (C,), dev, 2)
     in1 = _bf16_randn((1,) + C2 + (C,), dev, 3)
     y = conv(in0, in1, None, leaky=False, out_f32=True)
     y2 = conv(in0 * 2, in1 * 2, None, leaky=False, out_f32=True)
     if fold:
-        assert float((y2 - 2 * y).abs().max()) <= 2.0 ** -22
+        assert float((y2 - 2 * y).abs().max()) <= 4 * 2.0 ** -23 * float(y2.abs().max())
         assert float(((y2 - 2 * y) != 0).float().mean()) < 1e-3
         del y2
         y32 = conv(in0, in1, None, leaky=False, out_f32=True, half_partial=False)
