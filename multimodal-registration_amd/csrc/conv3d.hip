@@ -91,15 +91,6 @@ constexpr int CV_DMA_A = 1 << 8;    // bf16 / exact fp32: the haloed A tile goes
 constexpr int CV_STAMP = 1 << 10;   // cycle stamps (only with -DMMR_DIAG; never the measured build)
 constexpr int CV_BATCHA = 1 << 12;  // fp32x3 / x1: all staging loads of a slice issued branch-free, masked when stored
 constexpr int CV_PRIO_Y = 1 << 15;  // static s_setprio 1 for waves 4-7
-// fp32x3 / x1, 64 columns per wave (16x16x32): every wave reads ITS OWN weight fragments of the next tap straight from L2 / L1
-// into a second register set while it multiplies the current one -- no weight tile in LDS, so the workgroup meets only to
-// swap the A tile (two barriers per 27 taps instead of one per tap) and the two waves of a SIMD drift apart and fill each
-// other's fragment round trips.  8 x 16 B per lane and tap; all eight waves of the 64-column tile read the same 8 KB (L1).
-constexpr int CV_BREG = 1 << 20;
-// fp32x3 / x1 with the INPUT tensors stored pre-split: per voxel and 32-channel group 128 B = [32 hi bf16 | 32 lo bf16] (the
-// bytes of 32 fp32 values, the LDS row image itself) -> the haloed A tile is staged by LDS-DMA like a bf16 tile: no staging
-// registers, no VALU split, no vmcnt chain.
-constexpr int CV_PRESPLIT = 1 << 21;
 // Folded upsampling.  A decoder layer convolves concat([UpSampling3D(2)(x) | skip]).  For the upsampled channels the 27
 // taps at a full-resolution voxel g = 2 i + p touch only a 2x2x2 block of x: per axis, parity p = 0 reads x[i-1] with
 // W[-1] and x[i] with W[0] + W[+1]; p = 1 reads x[i] with W[-1] + W[0] and x[i+1] with W[+1] (zero padding of the
@@ -128,7 +119,6 @@ constexpr int CV_DGFOLD = 1 << 19;
 
 #ifdef MMR_DIAG
 int g_diag_stamps = 0;   // host switch of the stamped instantiations (conv and wgrad), set by mmr_debug_set_stamps
-int g_diag_variant = 0;  // host switch of the experimental instantiations (mmr_debug_set_variant): bit 0 = CV_BREG on the fp32x3 64-column tile
 // Diagnostic build only (CV_STAMP): where a tap's cycles go.  Per wave slot w (0..7) the sums over all workgroups of:
 // [0] tap top -> weight DMA issued, [1] -> last MFMA issued (fragment reads + MFMAs), [2] -> own DMA landed (vmcnt 0),
 // [3] -> barrier passed, [4] A restage (per slice), [5] number of taps.  s_memtime ticks.  Read the SHARES, never the
@@ -262,8 +252,7 @@ conv3d_k3_kernel(const ConvParams p)
     constexpr int KC = Elt<DT>::kc;
     constexpr int B_BYTES = BN * 128;
     constexpr int B_ITERS = B_BYTES / (CONV_THREADS * 16);
-    constexpr bool PRESPLIT = (DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) && ((VAR & CV_PRESPLIT) != 0);
-    constexpr int A_ITERS = ((((DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) && !PRESPLIT) ? HROWS_T * 4 : HROWS_T * 8) + CONV_THREADS - 1) / CONV_THREADS;
+    constexpr int A_ITERS = (((DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) ? HROWS_T * 4 : HROWS_T * 8) + CONV_THREADS - 1) / CONV_THREADS;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
@@ -379,8 +368,7 @@ conv3d_k3_kernel(const ConvParams p)
     // global load of item `it` of this thread's share of the haloed tile of channel slice s.
     // bf16 / fp32: item = (row, 16-B chunk); fp32x3: item = (row, 8-channel group) = 32 B of fp32.
     constexpr bool X3 = (DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1);  // fp32 in HBM, [hi | lo] LDS rows
-    constexpr bool BREG = X3 && M16 && NT == 2 && ((VAR & CV_BREG) != 0);
-    constexpr int A_ITEMS = (X3 && !PRESPLIT) ? HROWS_T * 4 : HROWS_T * 8;
+    constexpr int A_ITEMS = X3 ? HROWS_T * 4 : HROWS_T * 8;
     struct AItem { uint4 a, b; };
     auto load_a = [&](int s, int it) -> AItem {
         // (see dma_stage_a; on this register-staging path the recomputation costs more than the registers it frees -- fp32x3 C2
@@ -499,7 +487,7 @@ conv3d_k3_kernel(const ConvParams p)
     // CV_DMA_A (bf16 / exact fp32, no conversion on the way): the haloed A tile goes global -> LDS by DMA as well.
     // Lane i of an instruction lands at base + 16 i, i.e. at (row, chunk position) = (i >> 3, i & 7) of the swizzled
     // tile, so the swizzle is applied to the SOURCE chunk; out-of-volume rows read a zero page.
-    constexpr bool DMA_A = (!X3 || PRESPLIT) && ((VAR & CV_DMA_A) != 0);
+    constexpr bool DMA_A = !X3 && ((VAR & CV_DMA_A) != 0);
     const unsigned sA_lds = lds_addr(sA);
     constexpr bool ATAB = DMA_A && MIDDMA && !DGF && TXT == 4;
     unsigned* atab = reinterpret_cast<unsigned*>(sB + 2 * B_BYTES);      // [A_ITEMS] item -> source byte offset, ~0 = zero row
@@ -573,7 +561,7 @@ conv3d_k3_kernel(const ConvParams p)
         // general form (two inputs, nearest-upsampled first input): addresses from scratch.  In the table kernels an opaque
         // copy of the thread index keeps this arithmetic from being hoisted over the tap loop all the same.
         int tid_g = tid;
-        if constexpr (ATAB || PRESPLIT) asm volatile("" : "+v"(tid_g));
+        if constexpr (ATAB) asm volatile("" : "+v"(tid_g));
         const int ch0 = s * KC;
         const bool first = ch0 < p.C0;
         const char* src = first ? p.in0 : p.in1;
@@ -612,7 +600,7 @@ conv3d_k3_kernel(const ConvParams p)
     const int g0 = p.kpart ? (int)blockIdx.z * p.gsplit : 0;
     const int g1 = p.kpart ? min(g0 + p.gsplit, G) : G;
     int cur = 0, tap = g0 % TAPS, s = g0 / TAPS;
-    if constexpr (!ATAB && !BREG) issue_b(g0, 0);
+    if constexpr (!ATAB) issue_b(g0, 0);
     // a macro, not a lambda: wrapped in one more closure, hipcc no longer scalarises the by-value kernel argument
     // struct and every instantiation reads ConvParams from scratch (288 B/lane; the bn64 convs ran 1.8x slower)
     // named scalars, not an array: an indexed array of structs stays in scratch here even when unrolled
@@ -665,88 +653,7 @@ conv3d_k3_kernel(const ConvParams p)
         if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     }
 
-    if constexpr (BREG) {
-        uint4 wq0[8], wq1[8];
-        const unsigned wlane = (unsigned)b16_off[0];      // this lane's first fragment inside a tap's block; ni stride 256 B
-        auto ldw = [&](int g, uint4 (&d)[8]) {
-            const char* w = wtile + (size_t)g * B_BYTES + wlane;
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) d[ni] = *reinterpret_cast<const uint4*>(w + ni * 256);
-            if constexpr (LO) {
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) d[4 + ni] = *reinterpret_cast<const uint4*>(w + ni * 256 + 4 * BN * 16);
-            }
-        };
-        auto tapc = [&](const uint4 (&bw)[8]) {
-            const int kcls = DGF ? s / ncs : cls;
-            const int dx = UPF ? ((cls >> 2) & 1) + ((tap >> 2) & 1) : DGF ? 2 - ((kcls >> 2) & 1) - ((tap >> 2) & 1) : tap / 9;
-            const int dy = UPF ? ((cls >> 1) & 1) + ((tap >> 1) & 1) : DGF ? 2 - ((kcls >> 1) & 1) - ((tap >> 1) & 1) : (tap / 3) % 3;
-            const int dz = UPF ? (cls & 1) + (tap & 1) : DGF ? 2 - (kcls & 1) - (tap & 1) : tap % 3;
-            const char* bA = sA + (dx * (HY * HZ) + dy * HZ + dz) * ROWB;
-            const int sw16 = swz16((r16 & 7) + dz);
-            uint4 ah16[2 * MT], al16[2 * MT];
-#pragma unroll
-            for (int mi = 0; mi < 2 * MT; ++mi) {
-                ah16[mi] = *reinterpret_cast<const uint4*>(bA + a16_off[mi] + ((q16 ^ sw16) << 4));
-                if constexpr (LO) al16[mi] = *reinterpret_cast<const uint4*>(bA + a16_off[mi] + (((4 + q16) ^ sw16) << 4));
-            }
-#pragma unroll
-            for (int mi = 0; mi < 2 * MT; ++mi) {
-                if constexpr (LO) {
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
-                        acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, bw[ni]), __builtin_bit_cast(bf16x8, al16[mi]), acc16[mi][ni], 0, 0, 0);
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
-                        acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, bw[4 + ni]), __builtin_bit_cast(bf16x8, ah16[mi]), acc16[mi][ni], 0, 0, 0);
-                }
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, bw[ni]), __builtin_bit_cast(bf16x8, ah16[mi]), acc16[mi][ni], 0, 0, 0);
-            }
-            constexpr int NA = LO ? 2 : 1, NM = LO ? 12 : 4;
-#define MMR_GRP3(rd) __builtin_amdgcn_sched_group_barrier(0x008, NM, 0); if (rd) __builtin_amdgcn_sched_group_barrier(0x100, NA, 0)
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * NA, 0);
-            if constexpr (MT == 4) { MMR_GRP3(1); MMR_GRP3(1); MMR_GRP3(1); MMR_GRP3(1); }
-            MMR_GRP3(1); MMR_GRP3(1); MMR_GRP3(0); MMR_GRP3(0);
-#undef MMR_GRP3
-        };
-        // the tap body as a macro with the two register sets named: a register ring indexed by a loop variable would be copied
-#define MMR_TAP_BREG(BC, BX, gg) \
-        do { \
-            const bool more_ = (gg) + 1 < g1; \
-            if (more_) ldw((gg) + 1, BX); \
-            __builtin_amdgcn_sched_barrier(0); /* the next tap's loads stay in FRONT of this tap's MFMAs */ \
-            tapc(BC); \
-            ++tap; \
-            if (tap == TAPS) { \
-                tap = 0; \
-                ++s; \
-                if (s < nslices && more_) { \
-                    __syncthreads(); /* every wave is past its last read of sA */ \
-                    if constexpr (DMA_A) { \
-                        dma_stage_a(s); \
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
-                    } else { \
-                        MMR_STAGE_A_REGS(s); \
-                    } \
-                    __syncthreads(); \
-                } \
-            } \
-        } while (0)
-        ldw(g0, wq0);
-        int g = g0;
-        for (; g + 1 < g1; g += 2) {
-            MMR_TAP_BREG(wq0, wq1, g);
-            MMR_TAP_BREG(wq1, wq0, g + 1);
-        }
-        if (g < g1) MMR_TAP_BREG(wq0, wq1, g);
-#undef MMR_TAP_BREG
-    }
-    for (int g = g0; !BREG && g < g1; ++g) {
+    for (int g = g0; g < g1; ++g) {
         const bool more = g + 1 < g1;
 #ifdef MMR_DIAG
         if constexpr (STAMP) st_t = stamp_now();
@@ -1553,13 +1460,6 @@ int dispatch_conv(const ConvParams& p, hipStream_t st, int64_t* nblk_out = nullp
     const bool stamps = g_diag_stamps != 0;   // mmr_debug_set_stamps(1), tools/conv_stamps.py; not in the default build
     if (stamps && BN == 256) return launch_conv<DT, 2, 4, 4, 2, V_FULL | (F32T ? CV_BATCHA : 0) | CV_STAMP>(p, nt, st, nblk_out);
     if (stamps && BN == 64) return launch_conv<DT, 8, 1, 2, 2, V_FULL | CV_BATCHA | CV_PRIO_Y | CV_STAMP>(p, nt, st, nblk_out);
-    if constexpr (F32T) {
-        if ((g_diag_variant & 1) && BN == 64) return launch_conv<DT, 8, 1, 2, 2, V_FULL | CV_BATCHA | CV_PRIO_Y | CV_BREG>(p, nt, st, nblk_out);
-        if ((g_diag_variant & 2) && BN == 64) return launch_conv<DT, 8, 1, 2, 2, V_FULL | CV_BATCHA | CV_BREG>(p, nt, st, nblk_out);
-        if ((g_diag_variant & 4) && BN == 64) return launch_conv<DT, 8, 1, 2, 2, V_FULL | CV_PRIO_Y | CV_PRESPLIT>(p, nt, st, nblk_out);
-        if ((g_diag_variant & 8) && BN == 64) return launch_conv<DT, 8, 1, 2, 2, V_FULL | CV_PRIO_Y | CV_PRESPLIT | CV_BREG>(p, nt, st, nblk_out);
-        if ((g_diag_variant & 16) && BN == 64) return launch_conv<DT, 8, 1, 2, 2, V_FULL | CV_PRESPLIT | CV_BREG>(p, nt, st, nblk_out);
-    }
 #endif
     switch (BN) {
         case 256: return launch_conv<DT, 2, 4, 4, 2, V_FULL | (F32T ? CV_BATCHA : 0)>(p, nt, st, nblk_out);
@@ -1596,7 +1496,6 @@ int dispatch_conv_fold(const ConvParams& p, hipStream_t st, int64_t* nblk_out = 
 // Diagnostic (-DMMR_DIAG builds only, not in mmr.h): switch the stamped instantiations on / off; copy out and clear
 // the cycle stamps (tools/conv_stamps.py).
 extern "C" int mmr_debug_set_stamps(int on) { g_diag_stamps = on; return MMR_OK; }
-extern "C" int mmr_debug_set_variant(int v) { g_diag_variant = v; return MMR_OK; }
 extern "C" int mmr_debug_conv_stamps(unsigned long long* out64)
 {
     unsigned long long z[64] = {0};

@@ -42,16 +42,17 @@ class SynthMorphTrainer:
     """model: fp32 VxmDense; gen_1/gen_2: synth.LabelsToImage (sharing the label list)."""
 
     def __init__(self, model, gen_1=None, gen_2=None, reg_param=1.0, optimizer=None, zero_pad_dice=False,
-                 process_group=None, world_size=1, rank=0, backward_precision=None, overlap_wgrad=True):
+                 process_group=None, world_size=1, rank=0, backward_precision=None, overlap_wgrad=False):
         """gen_1 / gen_2 default to the generator pair of ``model.input_model`` (a model built the reference's way,
         ``VxmDense(..., input_model=InputModel(gen_1, gen_2))``, train_synthmorph.py:294-296).
         backward_precision: None = same arithmetic as the forward (fp32 / fp32x3); 'bf16' = dgrad and wgrad
         products on the bf16 hi halves only (one MFMA instead of three, fp32 accumulate) -- an opt-in
         mixed-precision backward; the forward (and therefore every output and loss) keeps fp32-grade accuracy.
-        overlap_wgrad: the weight-gradient kernels run on a second HIP stream.  Nothing on the backward's critical path
-        (the data-gradient chain) reads a weight gradient before Adam, so the HBM-bound kernels of that chain (pooling /
-        concat / VecInt / resize adjoints, thin-layer gradients) run beside matrix-core wgrad kernels instead of between
-        them, and each stream fills the partial last round of the other's launches.  Same kernels, same results."""
+        overlap_wgrad (opt-in): the weight-gradient kernels run on a second HIP stream (nothing on the data-gradient chain
+        reads a weight gradient before Adam).  Measured at C3: 26.0 -> 25.9 ms -- the matrix-core kernels hold every CU's LDS
+        and both waves' full register budget per SIMD, so the HBM-bound kernels of the chain cannot run beside them and only
+        the partial last rounds of launches fill; off by default so that per-kernel timings stay those of a kernel alone on
+        the chip.  Same kernels, same results."""
         if model.dtype != torch.float32:
             raise NotImplementedError("training runs the fp32 path (the reference trains in fp32)")
         im = getattr(model, "input_model", None)

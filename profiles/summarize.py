@@ -53,7 +53,9 @@ def sq(counter_csv, out_json, sub=None):
        clock_GHz        = GRBM_GUI_ACTIVE / 8 / duration          (rocprofv3 sums GUI_ACTIVE over the 8 XCDs)
        mfma_busy_frac   = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)
        lds_conflict_frac= SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
-       wait_frac        = SQ_WAIT_ANY / SQ_WAVE_CYCLES   (waves parked at s_waitcnt / barriers)"""
+       wait_frac        = SQ_WAIT_ANY / SQ_WAVE_CYCLES   (waves parked at s_waitcnt / barriers)
+       valu_active_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES   (both in quad-cycles: share of a wave's life spent executing VALU)
+       valu_insts_per_wave_cycle, lds_insts_per_valu_inst: instruction mix of the VALU / LDS kernels (NCC, bending)"""
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     dur = defaultdict(lambda: [0.0, 0])
     seen = set()
@@ -83,6 +85,14 @@ def sq(counter_csv, out_json, sub=None):
             e["lds_conflict_frac"] = m.get("SQ_LDS_BANK_CONFLICT", 0.0) / m["SQ_LDS_IDX_ACTIVE"]
         if m.get("SQ_WAVE_CYCLES"):
             e["wait_frac"] = m.get("SQ_WAIT_ANY", 0.0) / m["SQ_WAVE_CYCLES"]
+            if "SQ_WAIT_INST_ANY" in m:
+                e["issue_stall_frac"] = m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]
+            if "SQ_ACTIVE_INST_VALU" in m:
+                e["valu_active_frac"] = m["SQ_ACTIVE_INST_VALU"] / m["SQ_WAVE_CYCLES"]
+        if m.get("SQ_INSTS_VALU"):
+            e["valu_insts_per_launch"] = m["SQ_INSTS_VALU"]
+            if "SQ_INSTS_LDS" in m:
+                e["lds_insts_per_valu_inst"] = m["SQ_INSTS_LDS"] / m["SQ_INSTS_VALU"]
         out[k] = e
     json.dump(out, open(out_json, "w"), indent=1)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["avg_launch_us"] * kv[1]["launches"])[:6]:

@@ -11,11 +11,27 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def test_launcher_refuses_more_nccl_ranks_than_devices():
+    """`--gpus N` with fewer than N visible devices: a clear message and exit code 2 before any rank starts (two nccl ranks on one
+    device would sit in their first collective until the launch timeout)."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a machine with fewer than two GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MMR_BENCH_BACKEND")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 2 and r.stdout.strip() == ""
+    assert "needs 2 visible GPUs" in r.stderr and "device_count() = " in r.stderr
+    assert time.time() - t0 < 120
+
+
 def test_launcher_gives_up_when_a_rank_dies():
     import torch
     if torch.cuda.is_available():
         pytest.skip("needs a machine without a GPU: there every rank dies in torch.cuda.set_device")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["MMR_BENCH_BACKEND"] = "gloo"       # past the device-count gate of the nccl form: the ranks start, and die
     t0 = time.time()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, env=env)
@@ -41,6 +57,7 @@ def test_rank_environment_of_the_children(monkeypatch, tmp_path):
     def fake_popen(cmd, **kw):           # run the stub in place of `python bench.py ...`, same env / pipes
         return real_popen([sys.executable, str(stub)], **kw)
     monkeypatch.setattr(bench.subprocess, "Popen", fake_popen)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 3)
     monkeypatch.setattr(bench.sys, "stdout", open(tmp_path / "stdout.txt", "w"))
     rc = bench.launch_ranks(3, ["--gpus", "3"])
     bench.sys.stdout.close()

@@ -48,6 +48,12 @@ def test_default_line_carries_both_halves_of_the_metric():
     for leg in (d, sec):
         assert leg["roofline"]["frac"] > 0 and leg["cpu_baseline"]["value"] > 0 and leg["cpu_baseline"]["kind"] == "port"
     assert "whole SynthMorph step" in sec["cpu_baseline"]["sample"]
+    # the exact-fp32 step (the reference's arithmetic, train_synthmorph.py:308) is driver-timed beside the fp32x3 one, the
+    # data-parallel leg is lifted to the top level, and the line says where every rank sits
+    assert sec["same_workload_fp32"]["dtype"] == "fp32" and sec["same_workload_fp32"]["ms_per_step"] > 0
+    dp = d["dp_training"]
+    assert dp["value"] == sec["value"] and dp["n_gpus"] == 1 and dp["ms_per_step"] == sec["ms_per_step"]
+    assert d["dist"]["visible_devices"] >= 1 and d["dist"]["rank_devices"]
 
 
 def test_gpus_2_starts_two_ranks():
@@ -63,6 +69,9 @@ def test_gpus_2_starts_two_ranks():
              env={"MMR_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["dist"]["world_size"] == 2 and d["secondary"]["n_gpus"] == 2
     assert d["secondary"]["dist"]["allreduce_ms_per_step"] > 0 and "cpu_baseline" not in d
+    dp = d["dp_training"]
+    assert dp["n_gpus"] == 2 and dp["allreduce_ms_per_step"] > 0 and dp["allreduce_bytes"] > 0 and dp["backend"] == "gloo"
+    assert [r["rank"] for r in d["dist"]["rank_devices"]] == [0, 1]
 
 
 def test_train_and_ncc_lines_small():

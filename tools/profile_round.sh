@@ -33,4 +33,7 @@ for wl in infer train; do
   step "pmc SQ: $wl"
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/${tag}_pmc_${wl}_SQ -- python3 bench.py --workload $wl --steps 3 --warmup 1 $extra > /dev/null 2> $out/${tag}_pmc_${wl}_SQ.err || exit 1
 done
+# 4. the NCC / bending kernels are VALU / LDS machines, not matrix-core ones: instruction counts and VALU-active cycles
+step "pmc SQ: ncc"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/${tag}_pmc_ncc_SQ -- python3 bench.py --workload ncc --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/${tag}_pmc_ncc_SQ.err || exit 1
 step done
