@@ -376,8 +376,8 @@ def roofline_from_profile(prof, steps, traffic_file):
     tpath = os.path.join(ROOT, "profiles", traffic_file)
     if os.path.exists(tpath):
         try:
-            tj = json.load(open(tpath))
-            roof["traffic"] = tj.get(name, {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath)).get(name, {})
+            roof["traffic"] = tj.get("hbm_bytes_per_launch")
             # the counters come from a rocprofv3 --pmc pass of an earlier run of this same command (profiles/summarize.py),
             # not from this process: say which commit that was
             roof["traffic_source"] = f"profiles/{traffic_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass at git {tj.get('git', 'unknown')})"
