@@ -91,15 +91,6 @@ constexpr int CV_DMA_A = 1 << 8;    // bf16 / exact fp32: the haloed A tile goes
 constexpr int CV_STAMP = 1 << 10;   // cycle stamps (only with -DMMR_DIAG; never the measured build)
 constexpr int CV_BATCHA = 1 << 12;  // fp32x3 / x1: all staging loads of a slice issued branch-free, masked when stored
 constexpr int CV_PRIO_Y = 1 << 15;  // static s_setprio 1 for waves 4-7
-// Staggered halves (fp32x3 / x1 pipelined kernels).  The two waves of a SIMD (w and w + 4) run the same program and meet at
-// one barrier per tap, so they move in lockstep: right after every barrier all eight waves burst their up-front fragment
-// reads (12 ds_read_b128 each = 96 KB, ~400 cycles of the LDS at 256 B/clk) with the matrix pipe empty, then contend for it.
-// With CV_STAG waves 4-7 run HALF A TAP behind: between barriers k-1 and k waves 0-3 multiply tap k (both halves of their A
-// tiles), waves 4-7 the second half of tap k-1 and then the first half of tap k -- one half's read burst lands beside the other
-// half's MFMAs (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  Tap k-1's weights stay live one interval longer: three
-// weight buffers instead of two.  A channel slice is one staggered segment: at its end waves 4-7 finish their second half
-// before the A tile is swapped.
-constexpr int CV_STAG = 1 << 22;
 // Folded upsampling.  A decoder layer convolves concat([UpSampling3D(2)(x) | skip]).  For the upsampled channels the 27
 // taps at a full-resolution voxel g = 2 i + p touch only a 2x2x2 block of x: per axis, parity p = 0 reads x[i-1] with
 // W[-1] and x[i] with W[0] + W[+1]; p = 1 reads x[i] with W[-1] + W[0] and x[i+1] with W[+1] (zero padding of the
@@ -128,7 +119,6 @@ constexpr int CV_DGFOLD = 1 << 19;
 
 #ifdef MMR_DIAG
 int g_diag_stamps = 0;   // host switch of the stamped instantiations (conv and wgrad), set by mmr_debug_set_stamps
-int g_diag_variant = 0;  // host switch of experimental instantiations (mmr_debug_set_variant)
 // Diagnostic build only (CV_STAMP): where a tap's cycles go.  Per wave slot w (0..7) the sums over all workgroups of:
 // [0] tap top -> weight DMA issued, [1] -> last MFMA issued (fragment reads + MFMAs), [2] -> own DMA landed (vmcnt 0),
 // [3] -> barrier passed, [4] A restage (per slice), [5] number of taps.  s_memtime ticks.  Read the SHARES, never the
@@ -243,7 +233,6 @@ conv3d_k3_kernel(const ConvParams p)
     // static priority for the younger half of the workgroup (-1 % on the 64-column fp32x3 tile, +14 % on the 256-column
     // bf16 tile whose DMA issue needs waves 0-3 to be the arbitration winners)
     constexpr bool PRIO_Y = (VAR & CV_PRIO_Y) != 0;
-    constexpr bool STAG = PIPE3 && NT == 2 && ((VAR & CV_STAG) != 0);
     constexpr bool UPF = (VAR & CV_UPFOLD) != 0;
     constexpr bool CINIT = (VAR & CV_CINIT) != 0;
     constexpr bool PART16 = (VAR & CV_PART16) != 0;
@@ -385,7 +374,7 @@ conv3d_k3_kernel(const ConvParams p)
         // (see dma_stage_a; on this register-staging path the recomputation costs more than the registers it frees -- fp32x3 C2
         // forward 93.4 -> 99.0 ms, the 256-column _cinit 92.2 -> 95.4 even though it spills -- except for the 64-column _cinit
         // tile of the training step: 2.75 -> 2.65 ms)
-        constexpr bool UNHOIST = (CINIT && BN == 64) || ((VAR & CV_STAG) != 0);
+        constexpr bool UNHOIST = CINIT && BN == 64;
         int tid_l = tid;
         if constexpr (UNHOIST) asm volatile("" : "+v"(tid_l));
         const int i = tid_l + it * CONV_THREADS;
@@ -420,7 +409,7 @@ conv3d_k3_kernel(const ConvParams p)
     struct AItemM { uint4 a, b; unsigned ok; };
     auto load_a_nb = [&](int s, int it) -> AItemM {
         int tid_l = tid;
-        if constexpr ((CINIT && BN == 64) || ((VAR & CV_STAG) != 0)) asm volatile("" : "+v"(tid_l));   // see load_a
+        if constexpr (CINIT && BN == 64) asm volatile("" : "+v"(tid_l));   // see load_a
         const int i0 = tid_l + it * CONV_THREADS;
         const int i = i0 < A_ITEMS ? i0 : A_ITEMS - 1;
         const int scls = DGF ? s / ncs : 0;                     // dgrad fold: parity class of this K block
@@ -453,7 +442,7 @@ conv3d_k3_kernel(const ConvParams p)
     auto and4 = [](uint4 v, unsigned m) { return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m); };
     auto store_a = [&](int it, const AItem& val) {
         int tid_l = tid;
-        if constexpr ((CINIT && BN == 64) || ((VAR & CV_STAG) != 0)) asm volatile("" : "+v"(tid_l));   // see load_a
+        if constexpr (CINIT && BN == 64) asm volatile("" : "+v"(tid_l));   // see load_a
         const int i = tid_l + it * CONV_THREADS;
         if (i < A_ITEMS) {
             const int row = X3 ? (i >> 2) : (i >> 3), chunk = X3 ? (i & 3) : (i & 7);
@@ -664,99 +653,7 @@ conv3d_k3_kernel(const ConvParams p)
         if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     }
 
-    if constexpr (STAG) {
-        const bool late = wave >= 4;
-        uint4 bh16[4], bl16[4];            // weight fragments of the tap in flight: loaded in the first half, reused in the second
-        // half `HF` (A tiles HF*MT .. HF*MT+MT-1 of this wave) of tap `tp` against the weight block in buffer `bsel`
-        auto hstep = [&](int tp, int bsel, auto hf_tag) {
-            constexpr int HF = decltype(hf_tag)::value;
-            const int kcls = DGF ? s / ncs : cls;
-            const int dx = UPF ? ((cls >> 2) & 1) + ((tp >> 2) & 1) : DGF ? 2 - ((kcls >> 2) & 1) - ((tp >> 2) & 1) : tp / 9;
-            const int dy = UPF ? ((cls >> 1) & 1) + ((tp >> 1) & 1) : DGF ? 2 - ((kcls >> 1) & 1) - ((tp >> 1) & 1) : (tp / 3) % 3;
-            const int dz = UPF ? (cls & 1) + (tp & 1) : DGF ? 2 - (kcls & 1) - (tp & 1) : tp % 3;
-            const char* bA = sA + (dx * (HY * HZ) + dy * HZ + dz) * ROWB;
-            const char* bB = sB + bsel * B_BYTES;
-            const int sw16 = swz16((r16 & 7) + dz);
-            if constexpr (HF == 0) {
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) bh16[ni] = *reinterpret_cast<const uint4*>(bB + b16_off[ni]);
-                if constexpr (LO) {
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) bl16[ni] = *reinterpret_cast<const uint4*>(bB + b16_off[ni] + 4 * BN * 16);
-                }
-            }
-            uint4 ah16[MT], al16[MT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int mi = HF * MT + m;
-                ah16[m] = *reinterpret_cast<const uint4*>(bA + a16_off[mi] + ((q16 ^ sw16) << 4));
-                if constexpr (LO) al16[m] = *reinterpret_cast<const uint4*>(bA + a16_off[mi] + (((4 + q16) ^ sw16) << 4));
-            }
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int mi = HF * MT + m;
-                if constexpr (LO) {
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
-                        acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, bh16[ni]), __builtin_bit_cast(bf16x8, al16[m]), acc16[mi][ni], 0, 0, 0);
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
-                        acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, bl16[ni]), __builtin_bit_cast(bf16x8, ah16[m]), acc16[mi][ni], 0, 0, 0);
-                }
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, bh16[ni]), __builtin_bit_cast(bf16x8, ah16[m]), acc16[mi][ni], 0, 0, 0);
-            }
-            constexpr int NA = LO ? 2 : 1, NM = LO ? 12 : 4;
-            // weights (first half only) and two A tiles up front, then a tile's MFMAs while the tile two ahead loads
-            __builtin_amdgcn_sched_group_barrier(0x100, (HF == 0 ? 4 * NA : 0) + 2 * NA, 0);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
-                if (m + 2 < MT) __builtin_amdgcn_sched_group_barrier(0x100, NA, 0);
-            }
-        };
-        int bc = 0;                              // buffer of the tap the early waves multiply next
-        int g = g0;
-        while (g < g1) {
-            const int seg0 = g;
-            int seg1 = g + (TAPS - tap);         // this channel slice's taps (a split-K block may start / end inside one)
-            if (seg1 > g1) seg1 = g1;
-            for (; g < seg1; ++g, ++tap) {
-                const int bn = bc == 2 ? 0 : bc + 1;
-                if (g + 1 < g1) issue_b(g + 1, bn);      // buffer bn held tap g - 2: every wave is past it since the last barrier
-                if (!late) {
-                    hstep(tap, bc, IntTag<0>{});
-                    hstep(tap, bc, IntTag<1>{});
-                } else {
-                    if (g > seg0) hstep(tap - 1, bc == 0 ? 2 : bc - 1, IntTag<1>{});
-                    hstep(tap, bc, IntTag<0>{});
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                bc = bn;
-            }
-            if (late) hstep(tap - 1, bc == 0 ? 2 : bc - 1, IntTag<1>{});   // the segment's last second half
-            if (tap == TAPS) {
-                tap = 0;
-                ++s;
-                if (s < nslices && g < g1) {
-                    __syncthreads();             // waves 4-7 are past their last read of the A tile
-                    if constexpr (DMA_A) {
-                        dma_stage_a(s);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    } else {
-                        MMR_STAGE_A_REGS(s);
-                    }
-                    __syncthreads();
-                }
-            }
-        }
-    }
-    for (int g = g0; !STAG && g < g1; ++g) {
+    for (int g = g0; g < g1; ++g) {
         const bool more = g + 1 < g1;
 #ifdef MMR_DIAG
         if constexpr (STAMP) st_t = stamp_now();
@@ -1492,8 +1389,7 @@ int launch_conv(const ConvParams& p, int ntiles_n, hipStream_t st, int64_t* nblk
     // + the item -> offset table of the bf16 256-column tile (ATAB in the kernel): 600 rows x 8 chunks x 4 B
     constexpr bool ATAB_L = DT == MMR_DT_BF16 && MT == 4 && TXT == 4 &&
                             (VAR & (CV_M16 | CV_PIPE | CV_DMA_A)) == (CV_M16 | CV_PIPE | CV_DMA_A) && (VAR & CV_DGFOLD) == 0;
-    constexpr bool STAG_L = (VAR & CV_STAG) != 0;     // staggered halves: a third weight buffer
-    constexpr int LDS = (TXT + 2) * HY * HZ * ROWB + (STAG_L ? 3 : 2) * BN * 128 + (ATAB_L ? (TXT + 2) * HY * HZ * 8 * 4 : 0);
+    constexpr int LDS = (TXT + 2) * HY * HZ * ROWB + 2 * BN * 128 + (ATAB_L ? (TXT + 2) * HY * HZ * 8 * 4 : 0);
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     auto kern = conv3d_k3_kernel<DT, WM, WN, MT, NT, VAR>;
@@ -1564,10 +1460,6 @@ int dispatch_conv(const ConvParams& p, hipStream_t st, int64_t* nblk_out = nullp
     const bool stamps = g_diag_stamps != 0;   // mmr_debug_set_stamps(1), tools/conv_stamps.py; not in the default build
     if (stamps && BN == 256) return launch_conv<DT, 2, 4, 4, 2, V_FULL | (F32T ? CV_BATCHA : 0) | CV_STAMP>(p, nt, st, nblk_out);
     if (stamps && BN == 64) return launch_conv<DT, 8, 1, 2, 2, V_FULL | CV_BATCHA | CV_PRIO_Y | CV_STAMP>(p, nt, st, nblk_out);
-    if constexpr (F32T) {
-        if ((g_diag_variant & 1) && BN == 64) return launch_conv<DT, 8, 1, 2, 2, V_FULL | CV_BATCHA | CV_PRIO_Y | CV_STAG>(p, nt, st, nblk_out);
-        if ((g_diag_variant & 2) && BN == 64) return launch_conv<DT, 8, 1, 2, 2, V_FULL | CV_BATCHA | CV_STAG>(p, nt, st, nblk_out);
-    }
 #endif
     switch (BN) {
         case 256: return launch_conv<DT, 2, 4, 4, 2, V_FULL | (F32T ? CV_BATCHA : 0)>(p, nt, st, nblk_out);
@@ -1604,7 +1496,6 @@ int dispatch_conv_fold(const ConvParams& p, hipStream_t st, int64_t* nblk_out = 
 // Diagnostic (-DMMR_DIAG builds only, not in mmr.h): switch the stamped instantiations on / off; copy out and clear
 // the cycle stamps (tools/conv_stamps.py).
 extern "C" int mmr_debug_set_stamps(int on) { g_diag_stamps = on; return MMR_OK; }
-extern "C" int mmr_debug_set_variant(int v) { g_diag_variant = v; return MMR_OK; }
 extern "C" int mmr_debug_conv_stamps(unsigned long long* out64)
 {
     unsigned long long z[64] = {0};
