@@ -60,17 +60,29 @@ def resample_from_to(vol, to_shape, to_affine, order=1, mode="constant", cval=0.
     return Volume(out, to_affine)
 
 
-def resample_mm(vol, new_mm=(1, 1, 1), interpolation="linear", mode="constant"):
-    """``resample_nib(..., new_size=[1,1,1], new_size_type='mm')`` (3d_reg.py:19-117)."""
-    zooms = np.sqrt((vol.affine[:3, :3] ** 2).sum(0))
-    shape = vol.shape[:3]
+def resample_grid_mm(shape, affine, new_mm=(1, 1, 1)):
+    """Target grid of ``resample_nib(..., new_size=new_mm, new_size_type='mm')`` (3d_reg.py:56-90): ``shape_r = round(shape *
+    zoom / new_mm)`` with the zooms the header reports (the column norms of the affine), ``affine_r = affine . diag(shape /
+    shape_r)``; one value = isotropic.  Pinned by tests/golden/resample_nib_grid.npz (the reference's own function, recorded)."""
+    affine = np.asarray(affine, dtype=np.float64)
+    zooms = np.sqrt((affine[:3, :3] ** 2).sum(0))
+    new_mm = tuple(new_mm)
+    if len(new_mm) == 1:
+        new_mm = new_mm * 3
+    shape = tuple(shape[:3])
     shape_r = tuple(int(np.round(shape[i] * float(zooms[i]) / float(new_mm[i]))) for i in range(3))
     if min(shape_r) < 1:
         raise ZeroDivisionError("Destination size is zero; check the NIfTI pixdim values")
     R = np.eye(4)
     for i in range(3):
         R[i, i] = shape[i] / float(shape_r[i])
-    return resample_from_to(vol, shape_r, vol.affine @ R, order=_ORDER[interpolation], mode=mode)
+    return shape_r, affine @ R
+
+
+def resample_mm(vol, new_mm=(1, 1, 1), interpolation="linear", mode="constant"):
+    """``resample_nib(..., new_size=[1,1,1], new_size_type='mm')`` (3d_reg.py:19-117)."""
+    shape_r, affine_r = resample_grid_mm(vol.shape, vol.affine, new_mm)
+    return resample_from_to(vol, shape_r, affine_r, order=_ORDER[interpolation], mode=mode)
 
 
 def resample_img(vol, target_affine, target_shape, order=3):

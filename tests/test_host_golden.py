@@ -120,3 +120,23 @@ def test_preprocess_and_rai_warp_match_reference_register():
         assert bool(g[f"c{i}_moved_saved_equals_moving_proc"])
         seen_orient.add("".join(R.axcodes(-fa)))
     assert len(seen_orient) >= 5   # RAS, LPS, LPI and three axis permutations
+
+
+def test_resample_grid_matches_reference_resample_nib():
+    """registration.resample_grid_mm / the interpolation-order table against the reference's own ``resample_nib``
+    (3d_reg.py:19-117; recorded by tests/golden/make_golden_resample.py with ``resample_from_to`` stubbed): anisotropic,
+    permuted / flipped and oblique affines, 1 mm and other target resolutions, one-value (isotropic) form."""
+    from mmr import registration as R
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "resample_nib_grid.npz"))
+    for i in range(int(g["n_cases"])):
+        shape, aff, new = tuple(g[f"c{i}_shape"]), g[f"c{i}_affine"], tuple(g[f"c{i}_new_size"])
+        shape_r, affine_r = R.resample_grid_mm(shape, aff, new)
+        assert tuple(shape_r) == tuple(int(v) for v in g[f"c{i}_shape_r"]), i
+        np.testing.assert_allclose(affine_r, g[f"c{i}_affine_r"], rtol=1e-13, atol=1e-13)
+        assert R._ORDER[str(g[f"c{i}_interp"])] == int(g[f"c{i}_order"])
+        assert str(g[f"c{i}_mode_passed"]) == str(g[f"c{i}_mode"]) and float(g[f"c{i}_cval"]) == 0.0
+    assert bool(g["dest_is_passed_through"]) and int(g["dest_order"]) == 1
+    # and the resampling call built on that grid lands on it
+    v = R.Volume(np.random.default_rng(0).random(tuple(g["c0_shape"])), g["c0_affine"])
+    r = R.resample_mm(v, tuple(g["c0_new_size"]), "linear")
+    assert r.shape == tuple(int(x) for x in g["c0_shape_r"]) and np.allclose(r.affine, g["c0_affine_r"])
