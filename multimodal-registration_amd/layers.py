@@ -57,7 +57,7 @@ def to_device(a, dtype=torch.float32, device="cuda"):
 # bytes, which at C2 adds ~36 ms to a 45 ms forward.  A few cached pinned staging buffers (keyed by shape) take the
 # dtype conversion on the host (torch's threaded copy) and move at PCIe speed.
 _PINNED = {}
-_PINNED_MAX = 8
+_PINNED_MAX = 16
 
 
 def _pinned(shape, dtype, tag):

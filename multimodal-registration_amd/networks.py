@@ -444,11 +444,16 @@ class VxmDense:
     __call__ = forward
 
     def predict(self, inputs, batch_size=None, verbose=0):
-        """``model.predict([moving, fixed])`` -> [moved, preint_flow] as NumPy fp32 (3d_reg.py:310-314)."""
+        """``model.predict([moving, fixed])`` -> [moved, preint_flow] as NumPy fp32 (3d_reg.py:310-314).  Keras predicts in
+        batches; here one pair at a time bounds the activation memory, and for more than one pair the host <-> device copies
+        of neighbouring pairs run on a second stream beside the forward (``_predict_overlapped``)."""
         src, trg = inputs
-        out_m, out_f = [], []
         n = np.asarray(src).shape[0] if not isinstance(src, torch.Tensor) else src.shape[0]
-        for b in range(n):  # Keras predicts in batches; one pair at a time bounds activation memory
+        host_in = not (isinstance(src, torch.Tensor) and src.is_cuda)
+        if n > 1 and self.input_model is None and host_in and self.device.type == "cuda":
+            return self._predict_overlapped(src, trg, n)
+        out_m, out_f = [], []
+        for b in range(n):
             if self.input_model is not None:   # label maps in: the generators take NumPy uint8 or device tensors as they are
                 s, t = src[b:b + 1], trg[b:b + 1]
             else:
@@ -459,6 +464,71 @@ class VxmDense:
             out_f.append(d2h_volume(o["preint_flow"], tag=1))
         if n == 1:
             return [out_m[0], out_f[0]]
+        return [np.concatenate(out_m), np.concatenate(out_f)]
+
+    def _predict_overlapped(self, src, trg, n):
+        """Pairs b - 1 / b / b + 1 in flight at once: while pair b is in the forward, pair b + 1 is converted to fp32 into a
+        pinned buffer and copied in, and pair b - 1's outputs are copied out, both on a side stream (two pinned slots per
+        direction; events order every hand-over).  Same kernels on the same inputs: results identical to the one-pair path."""
+        from .layers import _pinned
+        dev = self.device
+        main = torch.cuda.current_stream(dev)
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream(device=dev)
+        cs = self._copy_stream
+        as_t = lambda a: a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+        in_done = [None, None]      # H2D events of the two input slots (the pinned buffers are rewritten by the host)
+
+        def stage_in(b):
+            slot = b & 1
+            if in_done[slot] is not None:
+                in_done[slot].synchronize()          # the copy that last read this slot's pinned buffers has finished
+            devs = []
+            for k, a in enumerate((src, trg)):
+                t = as_t(a[b:b + 1])
+                pin = _pinned(t.shape, torch.float32, ("in2", slot, k))
+                pin.copy_(t)                          # fp64 -> fp32 conversion on the host, while the GPU works on pair b - 1
+                with torch.cuda.stream(cs):
+                    d = pin.to(dev, non_blocking=True)
+                d.record_stream(main)
+                devs.append(d)
+            ev = torch.cuda.Event()
+            ev.record(cs)
+            in_done[slot] = ev
+            return devs[0], devs[1], ev
+        out_m, out_f, pending = [None] * n, [None] * n, [None, None]
+
+        def collect(slot):
+            if pending[slot] is not None:
+                b, ev, pm, pf = pending[slot]
+                ev.synchronize()
+                out_m[b], out_f[b] = pm.numpy().copy(), pf.numpy().copy()
+                pending[slot] = None
+        nxt = stage_in(0)
+        for b in range(n):
+            s, t, ev_in = nxt
+            main.wait_event(ev_in)
+            if b + 1 < n:
+                nxt = stage_in(b + 1)
+            o = self.forward(s, t)
+            ev_c = torch.cuda.Event()
+            ev_c.record(main)
+            slot = b & 1
+            collect(slot)                            # pair b - 2 used this output slot
+            ym, yf = o["y_source"], o["preint_flow"]
+            pm = _pinned(ym.shape, ym.dtype, ("out2", slot, 0))
+            pf = _pinned(yf.shape, yf.dtype, ("out2", slot, 1))
+            with torch.cuda.stream(cs):
+                cs.wait_event(ev_c)
+                pm.copy_(ym.detach(), non_blocking=True)
+                pf.copy_(yf.detach(), non_blocking=True)
+                ev_o = torch.cuda.Event()
+                ev_o.record(cs)
+            ym.record_stream(cs)
+            yf.record_stream(cs)
+            pending[slot] = (b, ev_o, pm, pf)
+        collect(0)
+        collect(1)
         return [np.concatenate(out_m), np.concatenate(out_f)]
 
 

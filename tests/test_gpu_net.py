@@ -60,6 +60,28 @@ def test_weight_transplant_is_shape_agnostic(dev):
     assert moved.dtype == np.float32
 
 
+def test_predict_batch_overlaps_copies_and_equals_single_pairs(dev):
+    """``predict`` on a batch of pairs (Keras semantics, 3d_reg.py:310-314 calls it with one): pairs are forwarded one at a time
+    with the neighbouring pairs' host <-> device copies on a side stream; every pair's outputs equal the one-pair call's bit
+    for bit, float64 inputs included."""
+    import mmr
+    shape, feats = (16, 32, 16), ([32, 32], [32, 32, 32])
+    m = mmr.networks.VxmDense(shape, nb_unet_features=feats, int_steps=5, int_resolution=2, svf_resolution=2, compute_dtype="fp32x3", seed=2)
+    w = m.get_weights()
+    w[-2] = (np.random.default_rng(1).standard_normal(w[-2].shape) * 3e-2).astype(np.float32)
+    m.set_weights(w)
+    rng = np.random.default_rng(0)
+    mov, fix = rng.random((5,) + shape + (1,)), rng.random((5,) + shape + (1,))       # float64, as nibabel hands them over
+    moved, warp = m.predict([mov, fix])
+    assert moved.shape == (5,) + shape + (1,) and warp.shape == (5, 8, 16, 8, 3) and moved.dtype == np.float32
+    for b in range(5):
+        m1, w1 = m.predict([mov[b:b + 1], fix[b:b + 1]])
+        assert np.array_equal(moved[b:b + 1], m1) and np.array_equal(warp[b:b + 1], w1), b
+    again = m.predict([mov, fix])
+    assert np.array_equal(again[0], moved) and np.array_equal(again[1], warp)
+    assert np.abs(warp).max() > 0.05 and not np.array_equal(moved[0], moved[1])
+
+
 def test_transform_network(dev):
     import mmr
     from oracle import ops_np as O

@@ -21,3 +21,10 @@ for _ in range(5):
     m.forward(a, b)
 torch.cuda.synchronize()
 print("device-resident forward: %.1f ms/pair" % ((time.perf_counter() - t) / 5 * 1e3))
+# a batch of pairs: the copies of neighbouring pairs overlap the forward (VxmDense._predict_overlapped)
+n = 6
+movb, fixb = np.repeat(mov, n, 0), np.repeat(fix, n, 0)
+m.predict([movb, fixb])
+t = time.perf_counter()
+m.predict([movb, fixb])
+print("predict on a batch of %d pairs (copies overlapped): %.1f ms/pair" % (n, (time.perf_counter() - t) / n * 1e3))
