@@ -539,25 +539,26 @@ __device__ __forceinline__ float wave_shl1(float v)   // lane l <- lane l+1, lan
 }
 
 // ------------------------------ local NCC, single pass, four z per lane ------------------------------ //
-// Same three mechanisms as ncc_fused_kernel (x: raw 9-plane ring in registers with sliding sums and an exact re-sum every
-// 9th plane; y: LDS exchange; z: DPP), re-balanced around the z window, which was 45 % of that kernel (140 half-rate
-// v_add_f32_dpp per plane step and wave).  A lane owns FOUR consecutive z (one 16-B load per row and plane, all plain
-// arithmetic as packed v_pk_*), so a row of up to 256 voxels is one wave and the centred 9-window of a lane's four
-// outputs needs its neighbours' values only from lanes l - 1 and l + 1:
+// Three mechanisms (x: sliding sums over the 9-plane window; y: LDS exchange; z: DPP).  A lane owns FOUR consecutive z (one
+// 16-B load per row and plane, all plain arithmetic as packed v_pk_*), so a row of up to 256 voxels is one wave and the centred
+// 9-window of a lane's four outputs needs its neighbours' values only from lanes l - 1 and l + 1:
 //   out0 = P[l-1] + P + v0[l+1]      out1 = (v1+v2+v3)[l-1] + P + (v0+v1)[l+1]
 //   out2 = (v2+v3)[l-1] + P + (v0+v1+v2)[l+1]      out3 = v3[l-1] + P + P[l+1]        (P = v0+v1+v2+v3)
-// = 5 plain + 8 DPP additions per field for four outputs (2 DPP per output instead of 8); whole rows also mean no z
-// halo.  The ring costs 72 VGPRs per row, so a wave holds 2 haloed rows, the tile is 16 rows -> 8 outputs and every
-// wave sums the 9-row y window of ONE output row from LDS -- as four published row PAIRS + one single row, 25
-// ds_read_b128 instead of 45 (80 KB tile, single buffer, two barriers per plane).  The next plane is loaded straight into the ring slot of the plane that leaves the window (its
-// contribution is subtracted right after the sums are published), one plane step ahead of its use.
+// = 5 plain + 8 DPP additions per field for four outputs (2 DPP per output instead of 8); whole rows also mean no z halo.  A wave
+// holds 2 haloed rows, the tile is 16 rows -> 8 outputs and every wave sums the 9-row y window of ONE output row from LDS -- as
+// four published row PAIRS + one single row, 25 ds_read_b128 instead of 45 (80 KB tile, single buffer, two barriers per plane).
 // Requires Z % 4 == 0 and Z <= 256 (else the one-z-per-lane kernel runs).
+//
+// Round 4: NO register ring.  Until round 3 the raw 9-plane x window of the wave's two rows lived in registers (144 of 255
+// VGPRs, plane loop unrolled by nine, exact re-sum every ninth plane): two waves per SIMD, one workgroup per CU, and the
+// counters said it waited (waves parked 44 % of their cycles, VALU active 24 %; profiles/r04a_ncc_pmc_sq.json).  Now the plane
+// that LEAVES the window is simply loaded again, eight steps after it joined (from the Infinity Cache: both volumes are 134 MB):
+// no ring, no parked sums, 128 VGPRs and exactly 80 KB of LDS -> two workgroups = four waves per SIMD on every CU; 512 workgroups
+// of 16-plane x segments instead of 256 of 32 (x warm-up 1.5x instead of 1.25x).  83 -> 73 us at 256^3 (same-box A/B, same value to
+// the last printed digit).  The sums slide for at most xseg + 8 <= 72 steps without a re-sum: the drift of a 9-term fp32 sum
+// over that many add / subtract pairs stays two orders below the rounding of the 729-term window sum it feeds.
 constexpr int N4_WAVES = 8, N4_RPW = 2, N4_ROWS = N4_WAVES * N4_RPW, N4_YOUT = N4_ROWS - 8;
 constexpr int N4_TILE_BYTES = N4_ROWS * 5 * 64 * 16;                  // 81,920: the published x-sums
-// window-sum vectors (of 10) parked in LDS during the y / z phase: 0 spills 20 B per lane, 2 fits in 256 VGPRs with none
-// (97 us at 256^3), 10 leaves 22 VGPRs unused and costs 16 more LDS operations per plane (108 us)
-constexpr int N4_WSAVE = 3;
-constexpr int N4_LDS_BYTES = N4_TILE_BYTES + N4_WSAVE * N4_WAVES * 64 * 16;   // 98,304
 typedef float f4_t __attribute__((ext_vector_type(4)));
 // y + x[lane - 1] / y + x[lane + 1] (0 beyond the wave's ends) as ONE v_add_f32_dpp.  Written out because hipcc kept the
 // shifts of this kernel as v_mov_b32_dpp + a separate add (40 extra VALU per plane step); the s_nop covers the two wait
@@ -575,19 +576,40 @@ __device__ __forceinline__ float add_shl1(float x, float y)
     return d;
 }
 
-__global__ void __launch_bounds__(N4_WAVES * 64)
-ncc_fused4_kernel(const float* __restrict__ I, const float* __restrict__ J, double* __restrict__ part, int X, int Y, int Z,
-                  int xseg, int nxs, int nyt, float eps, int form)
+constexpr int N4_LDS_BYTES = N4_TILE_BYTES;
+
+// the centred 9-window of a lane's four z outputs from the lane's four y-summed values v and its two neighbours' (see above):
+// eight DPP-fused additions in ONE asm block -- every DPP-read source (P, s123, s23, v.w, then v.x, p01, p012, P) is computed
+// before the block, so one s_nop 1 covers the two wait states a DPP read needs after a VALU write (each add_shr1 / add_shl1 on
+// its own carries that nop: 40 per plane step)
+__device__ __forceinline__ void zwin4(const f4_t v, float& o0, float& o1, float& o2, float& o3)
 {
+    const float p01 = v.x + v.y, p012 = p01 + v.z, P = p012 + v.w, s23 = v.z + v.w, s123 = v.y + s23;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %5, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %6, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %7, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %8, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %9, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %10, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %4, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+        : "v"(P), "v"(s123), "v"(s23), "v"(v.w), "v"(v.x), "v"(p01), "v"(p012));
+}
+
+template <int FORM>
+__global__ void __launch_bounds__(N4_WAVES * 64, 4)
+ncc_fused4_kernel(const float* __restrict__ I, const float* __restrict__ J, double* __restrict__ part, int X, int Y, int Z,
+                   int xseg, int nxs, int nyt, float eps)
+{
+    constexpr int form = FORM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f4_t* buf = reinterpret_cast<f4_t*>(smem);             // [N4_ROWS][5][64]
-    // The sliding sums are not needed between their publication and the next plane: N4_WSAVE of their ten vectors wait in a
-    // private LDS area so that the y / z phase has their registers.
-    f4_t* wsave = reinterpret_cast<f4_t*>(smem + N4_TILE_BYTES) + threadIdx.x;   // [N4_WSAVE][512]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one L2): every XCD takes a contiguous run of
-    // logical workgroups, so that y-neighbouring tiles, which share 8 of their 16 haloed rows, read them through one L2
     int t = blockIdx.x;
+    // workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one L2): every XCD takes a contiguous run of logical
+    // workgroups, so that y-neighbouring tiles, which share 8 of their 16 haloed rows, read them through one L2
     {
         const int nwg = gridDim.x, xcd = t & 7, qd = nwg >> 3, rm = nwg & 7;
         t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (t >> 3);
@@ -602,10 +624,7 @@ ncc_fused4_kernel(const float* __restrict__ I, const float* __restrict__ J, doub
     const size_t nvox = (size_t)X * Y * Z;
     const float* Ib = I + (size_t)b * nvox;
     const float* Jb = J + (size_t)b * nvox;
-    // Loads go through buffer descriptors (one batch item = at most 64 MB): a row or plane outside the volume gets the
-    // offset 0xF0000000, beyond num_records, and the hardware returns zeros -- 'SAME' zero padding with no masks, no clamps
-    // and 32-bit offsets.
-    unsigned rofs[N4_RPW];                                 // byte offset of this lane's 4 z in row r of a plane, or out of range
+    unsigned rofs[N4_RPW];
 #pragma unroll
     for (int r = 0; r < N4_RPW; ++r) {
         const int y = yt * N4_YOUT - 4 + w * N4_RPW + r;
@@ -615,125 +634,80 @@ ncc_fused4_kernel(const float* __restrict__ I, const float* __restrict__ J, doub
     const unsigned vol_bytes = (unsigned)(nvox * 4);
     const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ib), 0, (int)vol_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsJ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Jb), 0, (int)vol_bytes, 0x00020000);
-    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-    auto ldp = [&](const __amdgpu_buffer_rsrc_t& rs, int xq, int r) -> f4_t {   // plane xq (wave-uniform), row r
-        const bool xin = xq >= 0 && xq < X;
+    // plane xq (wave-uniform), row r; `use` false or a plane outside the volume -> offset beyond num_records -> hardware zeros
+    auto ldp = [&](const __amdgpu_buffer_rsrc_t& rs, int xq, int r, bool use) -> f4_t {
+        const bool xin = use && xq >= 0 && xq < X;
         const unsigned soff = xin ? (unsigned)xq * (unsigned)(Y * Z) * 4u : 0u;
         const unsigned voff = xin ? rofs[r] : 0xF0000000u;
         return __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
     };
     const f4_t zero4 = {0.f, 0.f, 0.f, 0.f};
-    f4_t ra[9][N4_RPW], rc[9][N4_RPW];                     // raw ring: plane s sits in slot s % 9
-#pragma unroll
-    for (int k = 0; k < 9; ++k)
-#pragma unroll
-        for (int r = 0; r < N4_RPW; ++r) ra[k][r] = rc[k][r] = zero4;
     f4_t W[N4_RPW][5];
 #pragma unroll
     for (int r = 0; r < N4_RPW; ++r)
 #pragma unroll
         for (int q = 0; q < 5; ++q) W[r][q] = zero4;
-    const bool oval = zin && (yt * N4_YOUT + w) < Y;       // this wave's output row / this lane's four z are in the volume
+    const bool oval = zin && (yt * N4_YOUT + w) < Y;
     const float ws = 729.f;
     float acc = 0.f;
     const int xi0 = x0 - 4, nstep = (x1 - x0) + 8;
+    f4_t na[N4_RPW], nc[N4_RPW], oa[N4_RPW], oc[N4_RPW];   // the plane that joins the window at this step / the one that leaves after it
 #pragma unroll
-    for (int r = 0; r < N4_RPW; ++r) {                     // plane xi0 -> slot 0
-        ra[0][r] = ldp(rsI, xi0, r);
-        rc[0][r] = ldp(rsJ, xi0, r);
+    for (int r = 0; r < N4_RPW; ++r) {
+        na[r] = ldp(rsI, xi0, r, true);
+        nc[r] = ldp(rsJ, xi0, r, true);
+        oa[r] = oc[r] = zero4;
     }
-    // The plane loop is unrolled by nine with the ring slot as the unroll index: every access names its registers
-    // statically and the ring never moves.  (A uniform `switch (slot)` around the two ring accesses of one loop body
-    // compiled to PHI copies of the whole ring and 250 B of spills per lane.)
-    for (int s0 = 0; s0 < nstep; s0 += 9) {
+    for (int s = 0; s < nstep; ++s) {
 #pragma unroll
-        for (int K = 0; K < 9; ++K) {
-            const int s = s0 + K;
-            if (s >= nstep) break;
-            // the plane in ring slot K (loaded one step ago) joins the window now
-            if (s > 0) {
-#pragma unroll
-                for (int i = 0; i < N4_WSAVE; ++i) W[i / 5][i % 5] = wsave[i * (N4_WAVES * 64)];
-            }
-#pragma unroll
-            for (int r = 0; r < N4_RPW; ++r) {
-                const f4_t a = ra[K][r], c = rc[K][r];
-                W[r][0] += a; W[r][1] += c; W[r][2] += a * a; W[r][3] += c * c; W[r][4] += a * c;
-            }
-            if (K == 8) {                                   // s = 8, 17, 26, ...: exact re-sum (no drift along x)
-#pragma unroll
-                for (int r = 0; r < N4_RPW; ++r) {
-                    f4_t sI = zero4, sJ = zero4, sII = zero4, sJJ = zero4, sIJ = zero4;
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) {
-                        const f4_t a = ra[k][r], c = rc[k][r];
-                        sI += a; sJ += c; sII += a * a; sJJ += c * c; sIJ += a * c;
-                    }
-                    W[r][0] = sI; W[r][1] = sJ; W[r][2] = sII; W[r][3] = sJJ; W[r][4] = sIJ;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const bool full = s >= 8;                       // window complete (uniform)
-            if (full) {
-#pragma unroll
-                for (int q = 0; q < 5; ++q) {
-                    // tile slot w = the SUM of this wave's two rows, slot 8 + w = the one row some window needs alone: a 9-row
-                    // window is four aligned row pairs + one single row (odd rows 1..7 from waves 0..3, even rows 8..14
-                    // from waves 4..7), so a window costs 5 reads per field instead of 9
-                    buf[(w * 5 + q) * 64 + lane] = W[0][q] + W[1][q];
-                    buf[((8 + w) * 5 + q) * 64 + lane] = (w < 4) ? W[1][q] : W[0][q];
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // the plane that leaves the window at the next step gives up its slot now: subtract it, load plane s + 1 there
-            {
-                constexpr int dummy = 0; (void)dummy;
-                const int KN = (K + 1) % 9;
-                const int xn = xi0 + s + 1;                 // the plane after the last step is loaded but never used
-#pragma unroll
-                for (int r = 0; r < N4_RPW; ++r) {
-                    const f4_t a = ra[KN][r], c = rc[KN][r];
-                    W[r][0] -= a; W[r][1] -= c; W[r][2] -= a * a; W[r][3] -= c * c; W[r][4] -= a * c;
-                }
-                __builtin_amdgcn_sched_barrier(0);          // subtract first: the loads then land in the freed registers
-#pragma unroll
-                for (int r = 0; r < N4_RPW; ++r) {
-                    ra[KN][r] = ldp(rsI, xn, r);
-                    rc[KN][r] = ldp(rsJ, xn, r);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < N4_WSAVE; ++i) wsave[i * (N4_WAVES * 64)] = W[i / 5][i % 5];
-            if (!full) continue;
-            __syncthreads();
-            // y window of this wave's output row (haloed rows w .. w + 8), then the centred z window from lanes l - 1, l + 1
-            // window of output row w = haloed rows w .. w + 8: pairs ((w + 1) >> 1) .. + 3 and the single row w (odd w) or
-            // w + 8 (even w); one field at a time (5 reads in flight: more spill)
-            const int p0 = (w + 1) >> 1;
-            const int s1 = 8 + ((w & 1) ? (w >> 1) : (w >> 1) + 4);
-            float S[4][5];
+        for (int r = 0; r < N4_RPW; ++r) {
+            const f4_t a = na[r], c = nc[r];
+            W[r][0] += a; W[r][1] += c; W[r][2] += a * a; W[r][3] += c * c; W[r][4] += a * c;
+        }
+        const bool full = s >= 8;                           // window complete (uniform)
+        if (full) {
 #pragma unroll
             for (int q = 0; q < 5; ++q) {
-                f4_t v = buf[(s1 * 5 + q) * 64 + lane];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v += buf[((p0 + k) * 5 + q) * 64 + lane];
-                const float p01 = v.x + v.y, p012 = p01 + v.z, P = p012 + v.w, s23 = v.z + v.w, s123 = v.y + s23;
-                S[0][q] = add_shl1(v.x, add_shr1(P, P));
-                S[1][q] = add_shl1(p01, add_shr1(s123, P));
-                S[2][q] = add_shl1(p012, add_shr1(s23, P));
-                S[3][q] = add_shl1(P, add_shr1(v.w, P));
-                __builtin_amdgcn_sched_barrier(0);
+                buf[(w * 5 + q) * 64 + lane] = W[0][q] + W[1][q];
+                buf[((8 + w) * 5 + q) * 64 + lane] = (w < 4) ? W[1][q] : W[0][q];
             }
-            if (oval) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) acc += ncc_terms<true>(S[k], ws, eps, form).cc;
-            }
-            __syncthreads();                                // the tile is rewritten by the next plane
         }
+        // plane s - 8 leaves the window before the next step; then the next step's two planes are requested (a step ahead)
+#pragma unroll
+        for (int r = 0; r < N4_RPW; ++r) {
+            const f4_t a = oa[r], c = oc[r];
+            W[r][0] -= a; W[r][1] -= c; W[r][2] -= a * a; W[r][3] -= c * c; W[r][4] -= a * c;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < N4_RPW; ++r) {
+            na[r] = ldp(rsI, xi0 + s + 1, r, true);
+            nc[r] = ldp(rsJ, xi0 + s + 1, r, true);
+            oa[r] = ldp(rsI, xi0 + s - 7, r, s >= 7);       // joined at step s - 7 >= 0, else nothing to take out
+            oc[r] = ldp(rsJ, xi0 + s - 7, r, s >= 7);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!full) continue;
+        __syncthreads();
+        const int p0 = (w + 1) >> 1;
+        const int s1 = 8 + ((w & 1) ? (w >> 1) : (w >> 1) + 4);
+        float S[4][5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            f4_t v = buf[(s1 * 5 + q) * 64 + lane];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v += buf[((p0 + k) * 5 + q) * 64 + lane];
+            zwin4(v, S[0][q], S[1][q], S[2][q], S[3][q]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (oval) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc += ncc_terms<true>(S[k], ws, eps, form).cc;
+        }
+        __syncthreads();                                    // the tile is rewritten by the next plane
     }
     double v = wave_sum((double)acc);
-    double* sh = reinterpret_cast<double*>(smem);           // the tile is free: every wave is past the last barrier
+    double* sh = reinterpret_cast<double*>(smem);
     if (lane == 0) sh[w] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1163,16 +1137,18 @@ inline void ncc_fused_geom(int B, int X, int Y, int Z, int& nzt, int& nyt, int& 
 }  // namespace
 
 namespace {
-// four-z-per-lane kernel: whole rows per wave (Z <= 256, Z % 4 == 0), 8 output rows per tile, x segments >= 16 planes
+// four-z-per-lane kernel: whole rows per wave (Z <= 256, Z % 4 == 0), 8 output rows per tile, two workgroups per CU; x segments
+// of 16 .. 64 planes (shorter ones only repeat the 8-plane warm-up; longer ones would let the sliding sums drift)
 inline bool ncc_fused4_ok(int64_t nvox, int Z) { return Z % 4 == 0 && Z <= 256 && nvox * 4 < 0xF0000000ll; }
-inline void ncc_fused4_geom(int B, int X, int Y, int& nyt, int& nxs, int& xseg)
+inline void ncc_fused4_geom(int B, int X, int Y, int& nyt, int& nxs, int& xseg, int wgs = 512)
 {
     nyt = (Y + N4_YOUT - 1) / N4_YOUT;
     const int64_t tiles = (int64_t)B * nyt;
-    int want = (int)((256 + tiles - 1) / tiles);
-    if (tiles * want > 256 && want > 1) --want;
+    int want = (int)((wgs + tiles - 1) / tiles);
+    if (tiles * want > wgs && want > 1) --want;
     const int max_by_len = X / 16 > 0 ? X / 16 : 1;
     nxs = want < 1 ? 1 : (want > max_by_len ? max_by_len : want);
+    if ((X + nxs - 1) / nxs > 64) nxs = (X + 63) / 64;
     xseg = (X + nxs - 1) / nxs;
     nxs = (X + xseg - 1) / xseg;
 }
@@ -1207,14 +1183,20 @@ extern "C" int mmr_ncc_fwd_f32(const float* I, const float* J, float* out, void*
         if ((int64_t)B * nblk4 > 0x7fffffff) return MMR_EINVAL;
         static bool attr4 = false;
         if (!attr4) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ncc_fused4_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
-            if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
+            for (const void* k : {reinterpret_cast<const void*>(ncc_fused4_kernel<MMR_NCC_CLASSIC>),
+                                  reinterpret_cast<const void*>(ncc_fused4_kernel<MMR_NCC_CLAMPED>)}) {
+                hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, N4_LDS_BYTES);
+                if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
+            }
             attr4 = true;
         }
         double* part4 = (double*)ws;
-        hipLaunchKernelGGL(ncc_fused4_kernel, dim3((unsigned)(B * nblk4)), dim3(N4_WAVES * 64), N4_LDS_BYTES, as_stream(stream),
-                           I, J, part4, X, Y, Z, xseg, nxs, nyt, eps, ncc_form);
+        if (ncc_form == MMR_NCC_CLAMPED)
+            hipLaunchKernelGGL(ncc_fused4_kernel<MMR_NCC_CLAMPED>, dim3((unsigned)(B * nblk4)), dim3(N4_WAVES * 64), N4_LDS_BYTES,
+                               as_stream(stream), I, J, part4, X, Y, Z, xseg, nxs, nyt, eps);
+        else
+            hipLaunchKernelGGL(ncc_fused4_kernel<MMR_NCC_CLASSIC>, dim3((unsigned)(B * nblk4)), dim3(N4_WAVES * 64), N4_LDS_BYTES,
+                               as_stream(stream), I, J, part4, X, Y, Z, xseg, nxs, nyt, eps);
         int rc4 = check_launch();
         if (rc4) return rc4;
         hipLaunchKernelGGL(mean_final_kernel, dim3(B), dim3(RED_BLOCK), 0, as_stream(stream), (const double*)part4, out, B,
