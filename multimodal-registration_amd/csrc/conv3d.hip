@@ -1073,7 +1073,7 @@ conv3d_k3_kernel(const ConvParams p)
                 double t = 0.0;
 #pragma unroll
                 for (int k = 0; k < WM; ++k) t += (double)s_col[k * BN + tid];
-                p.part[(size_t)blockIdx.x * (p.Cout - p.csplit) + (col - p.csplit)] = t;
+                p.part[(size_t)(col - p.csplit) * gridDim.x + blockIdx.x] = t;   // [column][tile]: colsum_final_kernel reads rows
             }
         }
         return;
@@ -1115,18 +1115,27 @@ conv3d_k3_kernel(const ConvParams p)
             double t = 0.0;
 #pragma unroll
             for (int k = 0; k < WM; ++k) t += (double)s_col[k * BN + tid];
-            p.part[(size_t)blockIdx.x * p.Cout + ntile * BN + tid] = t;
+            p.part[(size_t)(ntile * BN + tid) * gridDim.x + blockIdx.x] = t;
         }
     }
 }
 
-// one wave per channel: ordered strided partial sums, then a wave reduction (fixed order -> reproducible)
+// one wave per channel over part[channel][tile] (the conv epilogues store their column sums transposed, so that a channel's
+// partials are one contiguous row: whole 512-B lines per wave load; with [tile][channel] every load touched 64 lines and the
+// 4 MB of a full-resolution launch took 27 us per call, 6 calls per training step): strided partial sums in a fixed order, then
+// a wave reduction -> reproducible
 __global__ void __launch_bounds__(64)
 colsum_final_kernel(const double* __restrict__ part, float* __restrict__ db, int C, int nblk, int accumulate)
 {
     const int c = blockIdx.x;
-    double r = 0.0;
-    for (int k = threadIdx.x; k < nblk; k += 64) r += part[(size_t)k * C + c];
+    const double* row = part + (size_t)c * nblk;
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;      // four loads in flight per lane, combined in a fixed order
+    int k = threadIdx.x;
+    for (; k + 192 < nblk; k += 256) {
+        r0 += row[k]; r1 += row[k + 64]; r2 += row[k + 128]; r3 += row[k + 192];
+    }
+    for (; k < nblk; k += 64) r0 += row[k];
+    double r = (r0 + r1) + (r2 + r3);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o);
     if (threadIdx.x == 0) {
