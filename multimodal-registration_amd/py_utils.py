@@ -3,7 +3,9 @@
 
 nibabel is not available here, so NIfTI-1 (.nii / .nii.gz) is read and written directly: 348-byte header,
 little- or big-endian, scl_slope/scl_inter applied on load, sform (or qform / pixdim fallback) as the 4x4
-affine.  .npy / .npz are supported as in upstream ``load_volfile``.
+affine.  FreeSurfer .mgh / .mgz (the format of the public SynthMorph label maps that ``load_labels`` is pointed at,
+train_synthmorph.py:207) is read and written from its published layout as well.  .npy / .npz are supported as in
+upstream ``load_volfile``.
 """
 import gzip
 import os
@@ -103,9 +105,77 @@ def write_nifti(arr, path, affine=None, intent_code=0):
         f.write(np.asfortranarray(arr.astype(arr.dtype.newbyteorder("<"))).tobytes(order="F"))
 
 
+# ---- FreeSurfer MGH / MGZ (version 1): big-endian; int32 version, width, height, depth, nframes, type, dof; int16 goodRASFlag;
+# float32 spacing[3], x_ras[3], y_ras[3], z_ras[3] (direction cosines, column by column), c_ras[3] (world position of the
+# volume centre); voxel data from byte 284, x fastest, frames last.  type: 0 uint8, 1 int32, 3 float32, 4 int16.
+_MGH_DT = {0: ">u1", 1: ">i4", 3: ">f4", 4: ">i2"}
+_MGH_CODE = {"u1": 0, "i4": 1, "f4": 3, "i2": 4}
+
+
+def read_mgh(path):
+    """-> (data ndarray [width, height, depth(, frames)], vox2ras affine 4x4, header dict)."""
+    with (gzip.open(path, "rb") if path.endswith((".mgz", ".gz")) else open(path, "rb")) as f:
+        raw = f.read()
+    if len(raw) < 284:
+        raise ValueError(f"{path}: not an MGH file")
+    version, w, h, d, nf, typ, dof = struct.unpack(">7i", raw[:28])
+    if version != 1 or typ not in _MGH_DT or min(w, h, d, nf) < 1:
+        raise ValueError(f"{path}: unsupported MGH header (version {version}, type {typ}, dims {(w, h, d, nf)})")
+    good = struct.unpack(">h", raw[28:30])[0]
+    if good > 0:
+        delta = np.array(struct.unpack(">3f", raw[30:42]), dtype=np.float64)
+        mdc = np.array(struct.unpack(">9f", raw[42:78]), dtype=np.float64).reshape(3, 3).T   # columns x_ras, y_ras, z_ras
+        c_ras = np.array(struct.unpack(">3f", raw[78:90]), dtype=np.float64)
+    else:   # FreeSurfer's default orientation (coronal, LIA) when the flag is not set
+        delta = np.ones(3)
+        mdc = np.array([[-1.0, 0, 0], [0, 0, 1.0], [0, -1.0, 0]])
+        c_ras = np.zeros(3)
+    dt = np.dtype(_MGH_DT[typ])
+    n = w * h * d * nf
+    if len(raw) < 284 + n * dt.itemsize:
+        raise ValueError(f"{path}: truncated MGH data ({len(raw) - 284} of {n * dt.itemsize} bytes)")
+    data = np.frombuffer(raw, dtype=dt, count=n, offset=284).reshape((w, h, d, nf), order="F").astype(dt.newbyteorder("="))
+    if nf == 1:
+        data = data[..., 0]
+    M = mdc * delta
+    aff = np.eye(4)
+    aff[:3, :3] = M
+    aff[:3, 3] = c_ras - M @ (np.array([w, h, d], dtype=np.float64) / 2.0)
+    return data, aff, dict(dims=(w, h, d, nf), type=typ, dof=dof, goodRASFlag=good, delta=delta, Mdc=mdc, c_ras=c_ras)
+
+
+def write_mgh(arr, path, affine=None):
+    arr = np.asarray(arr)
+    if arr.dtype == np.bool_:
+        arr = arr.astype(np.uint8)
+    key = arr.dtype.str[1:]
+    if key not in _MGH_CODE:
+        arr = arr.astype(np.int32 if np.issubdtype(arr.dtype, np.integer) else np.float32)
+        key = arr.dtype.str[1:]
+    if arr.ndim == 3:
+        arr = arr[..., None]
+    if arr.ndim != 4:
+        raise ValueError("MGH volumes are 3-D (+ frames)")
+    w, h, d, nf = arr.shape
+    affine = np.eye(4) if affine is None else np.asarray(affine, dtype=np.float64)
+    M = affine[:3, :3]
+    delta = np.sqrt((M ** 2).sum(0))
+    mdc = M / delta
+    c_ras = affine[:3, 3] + M @ (np.array([w, h, d], dtype=np.float64) / 2.0)
+    hd = bytearray(284)
+    struct.pack_into(">7i", hd, 0, 1, w, h, d, nf, _MGH_CODE[key], 0)
+    struct.pack_into(">h", hd, 28, 1)
+    struct.pack_into(">3f", hd, 30, *delta)
+    struct.pack_into(">9f", hd, 42, *mdc.T.reshape(-1))
+    struct.pack_into(">3f", hd, 78, *c_ras)
+    with (gzip.open(path, "wb") if path.endswith((".mgz", ".gz")) else open(path, "wb")) as f:
+        f.write(bytes(hd))
+        f.write(np.asfortranarray(arr.astype(arr.dtype.newbyteorder(">"))).tobytes(order="F"))
+
+
 def load_volfile(filename, np_var="vol", add_batch_axis=False, add_feat_axis=False, pad_shape=None, resize_factor=1,
                  ret_affine=False):
-    """``vxm.py.utils.load_volfile``: .nii / .nii.gz / .npy / .npz; squeezed; optional batch / feature axes."""
+    """``vxm.py.utils.load_volfile``: .nii / .nii.gz / .mgz / .mgh / .npy / .npz; squeezed; optional batch / feature axes."""
     if isinstance(filename, str) and not os.path.isfile(filename):
         raise ValueError("'%s' is not a file." % filename)
     affine = None
@@ -114,13 +184,16 @@ def load_volfile(filename, np_var="vol", add_batch_axis=False, add_feat_axis=Fal
     elif filename.endswith((".nii", ".nii.gz")):
         vol, affine, _ = read_nifti(filename)
         vol = vol.squeeze()
+    elif filename.endswith((".mgz", ".mgh", ".mgh.gz")):
+        vol, affine, _ = read_mgh(filename)
+        vol = vol.squeeze()
     elif filename.endswith(".npy"):
         vol = np.load(filename)
     elif filename.endswith(".npz"):
         npz = np.load(filename)
         vol = next(iter(npz.values())) if len(npz.keys()) == 1 else npz[np_var]
     else:
-        raise ValueError("unknown filetype for %s (.mgz needs nibabel, which is not available here)" % filename)
+        raise ValueError("unknown filetype for %s" % filename)
     if pad_shape is not None or resize_factor != 1:
         raise NotImplementedError("pad_shape / resize_factor are not used by the reference")
     if add_feat_axis:
@@ -138,6 +211,8 @@ def save_volfile(array, filename, affine=None):
             pcrs = np.append(np.array(array.shape[:3]) / 2, 1)
             affine[:3, 3] = -np.matmul(affine, pcrs)[:3]
         write_nifti(array, filename, affine)
+    elif filename.endswith((".mgz", ".mgh")):
+        write_mgh(array, filename, affine)
     elif filename.endswith(".npz"):
         np.savez_compressed(filename, vol=array)
     elif filename.endswith(".npy"):
@@ -146,7 +221,7 @@ def save_volfile(array, filename, affine=None):
         raise ValueError("unknown filetype for %s" % filename)
 
 
-def load_labels(arg, ext=(".nii.gz", ".nii", ".npz", ".npy")):
+def load_labels(arg, ext=(".nii.gz", ".nii", ".mgz", ".npz", ".npy")):
     """``vxm.py.utils.load_labels``: every label map in a folder (or list / glob-free path) ->
     (sorted unique labels, list of uint arrays); shapes must agree."""
     if isinstance(arg, (tuple, list)):

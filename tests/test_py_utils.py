@@ -1,5 +1,6 @@
 """NIfTI / volume file helpers (host side, no GPU)."""
 import gzip
+import os
 import struct
 
 import numpy as np
@@ -66,3 +67,56 @@ def test_load_labels_and_setup_device(tmp_path):
         U.setup_device("-1")
     dev, nb = U.setup_device("0")
     assert dev == "cuda:0" and nb == 1
+
+
+def test_mgz_label_maps(tmp_path):
+    """FreeSurfer .mgz (what ``vxm.py.utils.load_labels`` reads the public SynthMorph label maps from, train_synthmorph.py:207):
+    the reader against a byte stream assembled here field by field from the published MGH layout (big-endian; 284-byte
+    header: version, dims, type, dof, goodRASFlag, spacing, direction cosines column by column, centre; x-fastest data) -- not
+    only against this package's own writer -- including the vox2ras affine nibabel derives (M = Mdc * spacing,
+    P0 = c_ras - M . dims / 2).  No FreeSurfer-written file exists in this image; the layout is the format's definition."""
+    import gzip
+    import struct
+    from mmr import py_utils as U
+    rng = np.random.default_rng(0)
+    lab = rng.integers(0, 26, (5, 7, 3)).astype(np.uint8)
+    spacing = (0.5, 2.0, 1.25)
+    mdc_cols = np.array([[0.0, 0.0, -1.0], [-1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])     # x_ras, y_ras, z_ras
+    c_ras = (10.0, -4.5, 3.0)
+    hd = bytearray(284)
+    struct.pack_into(">7i", hd, 0, 1, 5, 7, 3, 1, 0, 0)
+    struct.pack_into(">h", hd, 28, 1)
+    struct.pack_into(">3f", hd, 30, *spacing)
+    struct.pack_into(">9f", hd, 42, *mdc_cols.reshape(-1))
+    struct.pack_into(">3f", hd, 78, *c_ras)
+    path = str(tmp_path / "seg_01.mgz")
+    with gzip.open(path, "wb") as f:
+        f.write(bytes(hd) + lab.tobytes(order="F"))
+    vol, aff = U.load_volfile(path, ret_affine=True)
+    assert vol.dtype == np.uint8 and np.array_equal(vol, lab)
+    M = mdc_cols.T * np.array(spacing)
+    assert np.allclose(aff[:3, :3], M) and np.allclose(aff[:3, 3], np.array(c_ras) - M @ (np.array([5, 7, 3]) / 2)) and aff[3, 3] == 1
+    # every MGH voxel type, the writer / reader pair, frames, and the unflagged default orientation
+    for dt in (np.uint8, np.int16, np.int32, np.float32):
+        a = (rng.standard_normal((4, 3, 6)) * 50).astype(dt)
+        p = str(tmp_path / f"v_{np.dtype(dt).name}.mgz")
+        U.save_volfile(a, p, aff)
+        b, aff2 = U.load_volfile(p, ret_affine=True)
+        assert b.dtype == dt and np.array_equal(a, b) and np.allclose(aff2, aff, atol=1e-5)
+    four = rng.integers(0, 9, (3, 4, 5, 2)).astype(np.int32)
+    U.write_mgh(four, str(tmp_path / "f.mgh"))
+    assert np.array_equal(U.read_mgh(str(tmp_path / "f.mgh"))[0], four)
+    struct.pack_into(">h", hd, 28, 0)
+    with open(str(tmp_path / "noras.mgh"), "wb") as f:
+        f.write(bytes(hd) + lab.tobytes(order="F"))
+    _, aff0, h0 = U.read_mgh(str(tmp_path / "noras.mgh"))
+    assert np.allclose(aff0[:3, :3], [[-1, 0, 0], [0, 0, 1], [0, -1, 0]]) and h0["goodRASFlag"] == 0
+    # load_labels over a folder of .mgz maps, like the reference's label_dir
+    U.save_volfile(lab, str(tmp_path / "seg_02.mgz"))
+    os.remove(str(tmp_path / "f.mgh")); os.remove(str(tmp_path / "noras.mgh"))
+    for dt in ("uint8", "int16", "int32", "float32"):
+        os.remove(str(tmp_path / f"v_{dt}.mgz"))
+    labels, maps = U.load_labels(str(tmp_path))
+    assert len(maps) == 2 and np.array_equal(maps[0], lab) and np.array_equal(labels, np.unique(lab))
+    with pytest.raises(ValueError):
+        U.read_nifti(path)   # an .mgz is not a NIfTI file
