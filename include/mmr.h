@@ -247,6 +247,11 @@ int mmr_grad_l2_bwd_f32(const float* flow, float* dflow, int B, int X, int Y, in
 /* adjoint of mmr_resize_trilinear_f32 (din is overwritten); same grid_mode / zoom as the forward */
 int mmr_resize_trilinear_bwd_f32(const float* dout, float* din, int B, int X, int Y, int Z, int C,
                                  int Xo, int Yo, int Zo, float mul, int grid_mode, float zoom, void* stream);
+/* the same adjoint as three per-axis passes (the resize is separable) through a work space of
+ * mmr_resize_trilinear_bwd_ws_bytes: 2 - 6 gathers per element and pass instead of their product; what the trainer uses */
+int64_t mmr_resize_trilinear_bwd_ws_bytes(int B, int X, int Y, int Z, int C, int Xo, int Yo, int Zo);
+int mmr_resize_trilinear_bwd_ws_f32(const float* dout, float* din, void* ws, int B, int X, int Y, int Z, int C,
+                                    int Xo, int Yo, int Zo, float mul, int grid_mode, float zoom, void* stream);
 /* adjoint of mmr_compose_f32: da, db overwritten (da == db allowed when a == b) */
 int mmr_compose_bwd_f32(const float* a, const float* b, const float* dout, float* da, float* db,
                         int B, int X, int Y, int Z, void* stream);

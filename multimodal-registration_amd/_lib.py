@@ -68,6 +68,8 @@ SIGNATURES = {
     "mmr_dice_labels_zeropad_bwd": (I, [P, P, P, P, P, I, I, I, I, I, F, I, I, P]),
     "mmr_grad_l2_bwd_f32": (I, [P, P, I, I, I, I, I, F, F, I, P]),
     "mmr_resize_trilinear_bwd_f32": (I, [P, P, I, I, I, I, I, I, I, I, F, I, F, P]),
+    "mmr_resize_trilinear_bwd_ws_bytes": (c_int64, [I, I, I, I, I, I, I, I]),
+    "mmr_resize_trilinear_bwd_ws_f32": (I, [P, P, P, I, I, I, I, I, I, I, I, F, I, F, P]),
     "mmr_compose_bwd_f32": (I, [P, P, P, P, P, I, I, I, I, P]),
     "mmr_vecint_save_f32": (I, [P, P, P, I, I, I, I, I, P]),
     "mmr_vecint_bwd_f32": (I, [P, P, P, P, P, I, I, I, I, I, P]),

@@ -326,6 +326,32 @@ resize_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int B
     }
 }
 
+// The resize is separable (the weight of output i on input j is a product of one weight per axis), so its adjoint is the three
+// per-axis adjoints one after the other: 2 .. 6 candidates per element and pass instead of their product (125 .. 216 gathers per
+// element for the x2 resize in resize_bwd_kernel: 163 us for the 49 MB field gradient of a 160^3 step).  View of a pass:
+// [outer][n][inner] with the contracted axis in the middle; every thread owns one element of the result and reads its candidates
+// `inner` elements apart (coalesced along inner).  Same weights (axis_weight), fixed order, no atomics.
+__global__ void __launch_bounds__(TB)
+resize_bwd_axis_kernel(const float* __restrict__ dout, float* __restrict__ din, int64_t outer, int n_in, int n_out, int64_t inner,
+                       float st, float mul)
+{
+    const int64_t total = outer * n_in * inner;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TB) {
+        const int64_t in = i % inner;
+        const int j = (int)((i / inner) % n_in);
+        const int64_t o = i / (inner * n_in);
+        int lo, hi;
+        axis_range(j, st, n_out, n_in - 1, lo, hi);
+        const float* src = dout + (o * n_out) * inner + in;
+        float acc = 0.f;
+        for (int k = lo; k <= hi; ++k) {
+            const float w = axis_weight(k, st, n_in - 1, j);
+            if (w != 0.f) acc += w * src[(int64_t)k * inner];
+        }
+        din[i] = acc * mul;
+    }
+}
+
 // ------------------------------------------------------------------------- //
 // adjoint of out = s*b + (s*a) o (id + s*b)   (3-channel fields)            //
 //   da += s * scatter(w * dout);  db += s * (dout + sum_c dout_c * d interp(a_c)/d loc)
@@ -2474,6 +2500,33 @@ extern "C" int mmr_resize_trilinear_bwd_f32(const float* dout, float* din, int B
     if (resize_steps(X, Y, Z, Xo, Yo, Zo, grid_mode, zoom, stx, sty, stz)) return MMR_EINVAL;
     hipLaunchKernelGGL(resize_bwd_kernel, dim3(stream_grid((int64_t)B * X * Y * Z * C, TB)), dim3(TB), 0, st, dout,
                        din, B, X, Y, Z, C, Xo, Yo, Zo, stx, sty, stz, mul);
+    return check_launch();
+}
+
+// The same adjoint as three per-axis passes (resize_bwd_axis_kernel) through two intermediates in `ws`:
+// [B, X, Yo, Zo, C] after the x pass, [B, X, Y, Zo, C] after the y pass.
+extern "C" int64_t mmr_resize_trilinear_bwd_ws_bytes(int B, int X, int Y, int Z, int C, int Xo, int Yo, int Zo)
+{
+    if (B < 1 || X < 1 || Y < 1 || Z < 1 || C < 1 || Xo < 1 || Yo < 1 || Zo < 1) return MMR_EINVAL;
+    return ((int64_t)B * X * Yo * Zo * C + (int64_t)B * X * Y * Zo * C) * (int64_t)sizeof(float);
+}
+
+extern "C" int mmr_resize_trilinear_bwd_ws_f32(const float* dout, float* din, void* ws, int B, int X, int Y, int Z, int C, int Xo,
+                                               int Yo, int Zo, float mul, int grid_mode, float zoom, void* stream)
+{
+    if (!dout || !din || !ws || B < 1 || X < 1 || Y < 1 || Z < 1 || C < 1 || Xo < 1 || Yo < 1 || Zo < 1) return MMR_EINVAL;
+    hipStream_t st = as_stream(stream);
+    float stx, sty, stz;
+    if (resize_steps(X, Y, Z, Xo, Yo, Zo, grid_mode, zoom, stx, sty, stz)) return MMR_EINVAL;
+    float* t1 = static_cast<float*>(ws);
+    float* t2 = t1 + (int64_t)B * X * Yo * Zo * C;
+    const int64_t n1 = (int64_t)B * X * Yo * Zo * C, n2 = (int64_t)B * X * Y * Zo * C, n3 = (int64_t)B * X * Y * Z * C;
+    hipLaunchKernelGGL(resize_bwd_axis_kernel, dim3(stream_grid(n1, TB)), dim3(TB), 0, st, dout, t1, (int64_t)B, X, Xo,
+                       (int64_t)Yo * Zo * C, stx, 1.0f);
+    hipLaunchKernelGGL(resize_bwd_axis_kernel, dim3(stream_grid(n2, TB)), dim3(TB), 0, st, (const float*)t1, t2, (int64_t)B * X, Y, Yo,
+                       (int64_t)Zo * C, sty, 1.0f);
+    hipLaunchKernelGGL(resize_bwd_axis_kernel, dim3(stream_grid(n3, TB)), dim3(TB), 0, st, (const float*)t2, din, (int64_t)B * X * Y, Z,
+                       Zo, (int64_t)C, stz, mul);
     return check_launch();
 }
 

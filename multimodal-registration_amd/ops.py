@@ -704,14 +704,22 @@ def grad_l2_bwd(flow, loss_mult=1.0, scale=1.0, out=None):
     return out
 
 
-def resize_trilinear_bwd(dout, in_shape, mul=1.0, grid=None, zoom=0.0):
-    """Adjoint of resize_trilinear (same grid / zoom): dout [B,Xo,Yo,Zo,C] -> din [B,*in_shape,C]."""
+def resize_trilinear_bwd(dout, in_shape, mul=1.0, grid=None, zoom=0.0, separable=True):
+    """Adjoint of resize_trilinear (same grid / zoom): dout [B,Xo,Yo,Zo,C] -> din [B,*in_shape,C].  ``separable`` (default): three
+    per-axis passes through a work space; False: the one-launch 3-D gather (same result up to the summation order)."""
     _chk(dout, torch.float32, "dout")
     B, Xo, Yo, Zo, C = dout.shape
     X, Y, Z = (int(s) for s in in_shape)
     din = torch.empty((B, X, Y, Z, C), dtype=torch.float32, device=dout.device)
-    rc = _lib.load().mmr_resize_trilinear_bwd_f32(dout.data_ptr(), din.data_ptr(), B, X, Y, Z, C, Xo, Yo, Zo, float(mul),
-                                                  semantics.code("resize_grid", grid), float(zoom), _stream())
+    lib = _lib.load()
+    if separable:
+        ws = _ws(lib.mmr_resize_trilinear_bwd_ws_bytes(B, X, Y, Z, C, Xo, Yo, Zo), dout.device)
+        rc = lib.mmr_resize_trilinear_bwd_ws_f32(dout.data_ptr(), din.data_ptr(), ws.data_ptr(), B, X, Y, Z, C, Xo, Yo, Zo, float(mul),
+                                                 semantics.code("resize_grid", grid), float(zoom), _stream())
+        _lib.check(rc, "mmr_resize_trilinear_bwd_ws_f32")
+        return din
+    rc = lib.mmr_resize_trilinear_bwd_f32(dout.data_ptr(), din.data_ptr(), B, X, Y, Z, C, Xo, Yo, Zo, float(mul),
+                                          semantics.code("resize_grid", grid), float(zoom), _stream())
     _lib.check(rc, "mmr_resize_trilinear_bwd_f32")
     return din
 

@@ -65,8 +65,9 @@ def test_resize_bwd_is_adjoint_for_both_grids(dev, grid, shape, new, zoom):
     g = rng.standard_normal(new + (3,)).astype(np.float32)
     xt = torch.from_numpy(x).double().requires_grad_(True)
     (1.5 * G.resize(xt, new, grid=grid, zoom=zoom) * torch.from_numpy(g).double()).sum().backward()
-    got = mmr.ops.resize_trilinear_bwd(_t(g[None], dev), shape, mul=1.5, grid=grid, zoom=zoom)[0]
-    assert _rel(got, xt.grad) < 1e-5
+    for separable in (True, False):   # three per-axis passes (what the trainer runs) / the one-launch 3-D gather
+        got = mmr.ops.resize_trilinear_bwd(_t(g[None], dev), shape, mul=1.5, grid=grid, zoom=zoom, separable=separable)[0]
+        assert _rel(got, xt.grad) < 1e-5, separable
 
 
 @pytest.mark.parametrize("zlen", [37, 36])   # 37: one-z-per-lane forward kernel; 36 (Z % 4 == 0): four z per lane

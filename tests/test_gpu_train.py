@@ -102,8 +102,9 @@ def test_resize_bwd_is_adjoint(dev, shape, new, mul):
     g = rng.standard_normal(new + (3,)).astype(np.float32)
     xt = torch.from_numpy(x).double().requires_grad_(True)
     (mul * G.resize(xt, new) * torch.from_numpy(g).double()).sum().backward()
-    got = mmr.ops.resize_trilinear_bwd(_t(g[None], dev), shape, mul=mul)[0]
-    assert _rel(got, xt.grad) < 1e-5
+    for separable in (True, False):   # three per-axis passes (what the trainer runs) / the one-launch 3-D gather
+        got = mmr.ops.resize_trilinear_bwd(_t(g[None], dev), shape, mul=mul, separable=separable)[0]
+        assert _rel(got, xt.grad) < 1e-5, separable
 
 
 @pytest.mark.parametrize("scale", [0.4, 2.5])
