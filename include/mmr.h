@@ -329,6 +329,14 @@ int64_t mmr_conv3d_k3_dgrad_masked_ws_bytes(int B, int X, int Y, int Z, int Cout
 int mmr_conv3d_k3_dgrad_masked(const void* in0, int C0, const void* w_packed, float* out, int B, int X, int Y, int Z,
                                int Cout, const float* ymask, float alpha, float* dbias, void* ws, int accumulate,
                                int dtype, void* stream);
+/* the same with the gradient that reaches y (= ymask's tensor) through MaxPooling3D(2) folded into the epilogue:
+ * out = (conv(in0) + route(dpool)) * LeakyReLU'(y), dbias (+)= column sums; dpool [B, X/2, Y/2, Z/2, Cout] goes to the first
+ * maximum of every 2x2x2 window of y (window order x, y, z, like mmr_maxpool3d2_bwd_f32) -- the separate pooling-backward pass
+ * over the full-resolution gradient disappears.  MMR_DT_F32X3 / F32X1, Cout % 64 == 0 and % 128 != 0, even X, Y, Z; else
+ * MMR_EUNSUPPORTED.  Same work space as mmr_conv3d_k3_dgrad_masked. */
+int mmr_conv3d_k3_dgrad_masked_pool(const void* in0, int C0, const void* w_packed, float* out, int B, int X, int Y, int Z,
+                                    int Cout, const float* ymask, float alpha, float* dbias, void* ws, int accumulate,
+                                    int dtype, const float* dpool, void* stream);
 /* Keras Adam on one flat parameter buffer: g is multiplied by grad_scale first (1/world after a SUM all-reduce) */
 int mmr_adam_step_f32(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                       float eps, int64_t step, float grad_scale, void* stream);

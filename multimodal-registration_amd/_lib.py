@@ -79,6 +79,7 @@ SIGNATURES = {
     "mmr_leaky_bwd_bias_f32": (I, [P, P, P, P, P, c_int64, I, I, F, I, P]),
     "mmr_conv3d_k3_dgrad_masked_ws_bytes": (c_int64, [I, I, I, I, I]),
     "mmr_conv3d_k3_dgrad_masked": (I, [P, I, P, P, I, I, I, I, I, P, F, P, P, I, I, P]),
+    "mmr_conv3d_k3_dgrad_masked_pool": (I, [P, I, P, P, I, I, I, I, I, P, F, P, P, I, I, P, P]),
     "mmr_conv3d_k3_cout3_dgrad_masked_ws_bytes": (c_int64, [I, I, I, I, I]),
     "mmr_conv3d_k3_cout3_dgrad_masked_f32": (I, [P, P, P, I, I, I, I, I, P, F, P, P, I, P]),
     "mmr_conv3d_k3_cout3_dgrad_masked_f32x3": (I, [P, P, P, I, I, I, I, I, P, F, P, P, I, P]),

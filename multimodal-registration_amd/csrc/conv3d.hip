@@ -80,6 +80,8 @@ struct ConvParams {
     // split-K partials go to a compact buffer kpart[kz][blockIdx.x][tile voxel][Cout] (conv_ktail_finalize_kernel reads it)
     int tile0 = 0;
     int kcompact = 0;
+    // CV_POOLF: gradient of MaxPooling3D(2) of ymask's tensor, [B, X/2, Y/2, Z/2, Cout] (see CV_POOLF)
+    const float* dpool = nullptr;
 };
 
 template <int N> struct IntTag { static constexpr int value = N; };
@@ -91,6 +93,14 @@ constexpr int CV_DMA_A = 1 << 8;    // bf16 / exact fp32: the haloed A tile goes
 constexpr int CV_STAMP = 1 << 10;   // cycle stamps (only with -DMMR_DIAG; never the measured build)
 constexpr int CV_BATCHA = 1 << 12;  // fp32x3 / x1: all staging loads of a slice issued branch-free, masked when stored
 constexpr int CV_PRIO_Y = 1 << 15;  // static s_setprio 1 for waves 4-7
+// Masked data gradient (training) of a tensor y that ALSO feeds a MaxPooling3D(2): the gradient that arrives through the pooling
+// (dpool, at half resolution) is routed to the first maximum of every 2x2x2 window of y and added in this epilogue, before the
+// LeakyReLU mask and the bias column sums -- instead of a separate pass that reads y and reads + rewrites the whole gradient
+// (maxpool_bwd_v4_kernel: 3.3 GB for the first skip tensor of a 160^3 step, 0.6 ms).  The epilogue already loads y at every
+// voxel for the mask; with the wave's M tiles re-dealt so that one wave holds both x planes of a window (8 x 8 x 8 tile, wave =
+// x pair x 4 y rows x 8 z) the other seven window values are the lane's own second tile (x), lane ^ 8 (y) and lane ^ 1 (z):
+// window maximum and first-maximum index by two DPP steps each.  fp32x3 / x1, 64-column tile, even volume dims.
+constexpr int CV_POOLF = 1 << 23;
 // Folded upsampling.  A decoder layer convolves concat([UpSampling3D(2)(x) | skip]).  For the upsampled channels the 27
 // taps at a full-resolution voxel g = 2 i + p touch only a 2x2x2 block of x: per axis, parity p = 0 reads x[i-1] with
 // W[-1] and x[i] with W[0] + W[+1]; p = 1 reads x[i] with W[-1] + W[0] and x[i+1] with W[+1] (zero padding of the
@@ -208,6 +218,12 @@ __device__ __forceinline__ int row_perm(int r)
     return r + d;
 }
 
+// lane ^ 1 (quad_perm [1,0,3,2]) and lane ^ 8 (row_ror:8 inside a row of 16) as DPP moves -- CV_POOLF's window partners
+__device__ __forceinline__ int dpp_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true); }
+__device__ __forceinline__ int dpp_xor8(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, true); }
+__device__ __forceinline__ float dpp_xor1(float v) { return __int_as_float(dpp_xor1(__float_as_int(v))); }
+__device__ __forceinline__ float dpp_xor8(float v) { return __int_as_float(dpp_xor8(__float_as_int(v))); }
+
 template <int DT, int WM, int WN, int MT, int NT, int VAR>
 __global__ void __launch_bounds__(CONV_THREADS, 2)
 conv3d_k3_kernel(const ConvParams p)
@@ -233,6 +249,9 @@ conv3d_k3_kernel(const ConvParams p)
     // static priority for the younger half of the workgroup (-1 % on the 64-column fp32x3 tile, +14 % on the 256-column
     // bf16 tile whose DMA issue needs waves 0-3 to be the arbitration winners)
     constexpr bool PRIO_Y = (VAR & CV_PRIO_Y) != 0;
+    constexpr bool POOLF = (VAR & CV_POOLF) != 0;
+    static_assert(!POOLF || (((VAR & CV_M16) != 0) && WM == 8 && MT == 2 && NT == 2 && DT != MMR_DT_BF16 && DT != MMR_DT_F32),
+                  "pooling-gradient epilogue: fp32x3 / x1, 64-column tile");
     constexpr bool UPF = (VAR & CV_UPFOLD) != 0;
     constexpr bool CINIT = (VAR & CV_CINIT) != 0;
     constexpr bool PART16 = (VAR & CV_PART16) != 0;
@@ -301,11 +320,14 @@ conv3d_k3_kernel(const ConvParams p)
     f32x4 acc16[M16 ? 2 * MT : 1][M16 ? 2 * NT : 1];
     int a16_off[M16 ? 2 * MT : 1], b16_off[M16 ? 2 * NT : 1];
     const int r16 = lane & 15, q16 = lane >> 4;
+    // 16-voxel tile mi of this wave = 2 y rows x 8 z at (x, y) = (t16x(mi), t16y(mi)) of the workgroup's tile.  Ordinarily a wave
+    // owns MT consecutive 32-row M tiles; CV_POOLF deals them so that a wave holds BOTH x planes of a pooling window
+    auto t16x = [&](int mi) { return POOLF ? 2 * (wm >> 1) + (mi >> 1) : (wm * MT + (mi >> 1)) >> 1; };
+    auto t16y = [&](int mi) { return POOLF ? (wm & 1) * 4 + 2 * (mi & 1) : ((wm * MT + (mi >> 1)) & 1) * 4 + 2 * (mi & 1); };
     if constexpr (M16) {
 #pragma unroll
         for (int mi = 0; mi < 2 * MT; ++mi) {
-            const int mt = wm * MT + (mi >> 1);
-            a16_off[mi] = (((mt >> 1) * HY + (mt & 1) * 4 + 2 * (mi & 1) + (r16 >> 3)) * HZ + (r16 & 7)) * ROWB;
+            a16_off[mi] = ((t16x(mi) * HY + t16y(mi) + (r16 >> 3)) * HZ + (r16 & 7)) * ROWB;
 #pragma unroll
             for (int ni = 0; ni < 2 * NT; ++ni) acc16[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -991,10 +1013,43 @@ conv3d_k3_kernel(const ConvParams p)
                 else bv[ni][r] = (p.bias && co + ni * 4 + r < p.Cout) ? p.bias[co + ni * 4 + r] : 0.f;
                 csum[ni][r] = 0.f;
             }
+        // CV_POOLF: bit c of rt[mi] = "this lane's voxel of tile mi is the first maximum of its 2x2x2 window of ymask in channel
+        // co + c" (window order x, y, z like MaxPooling3D's argmax / maxpool_bwd_v4_kernel).  Every lane takes part (DPP): lanes
+        // whose voxel lies outside a ragged tile read a clamped address, their whole window is outside (even dims) and unused.
+        unsigned rt[M16 ? 2 * MT : 1];
+        if constexpr (POOLF) {
+            float ymv[4][16];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int gx = x0 + t16x(mi), gy = y0 + t16y(mi) + (r16 >> 3), gz = z0 + (r16 & 7);
+                const int cx = gx < p.X ? gx : p.X - 1, cy = gy < p.Y ? gy : p.Y - 1, cz = gz < p.Z ? gz : p.Z - 1;
+                const float* ym = p.ymask + ((((size_t)b * p.X + cx) * p.Y + cy) * p.Z + cz) * p.Cout + co;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const float4 q = *reinterpret_cast<const float4*>(ym + ni * 4);
+                    ymv[mi][ni * 4] = q.x; ymv[mi][ni * 4 + 1] = q.y; ymv[mi][ni * 4 + 2] = q.z; ymv[mi][ni * 4 + 3] = q.w;
+                }
+                rt[mi] = 0u;
+            }
+            const int ia = ((r16 >> 3) << 1) | (r16 & 1), ib = 4 + ia;     // window index of this lane's voxel in the x = 0 / x = 1 tile
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const float a = ymv[pr][c], bq = ymv[pr + 2][c];
+                    float m = fmaxf(a, bq);
+                    m = fmaxf(m, dpp_xor1(m));
+                    m = fmaxf(m, dpp_xor8(m));
+                    int f = a == m ? ia : (bq == m ? ib : 8);
+                    f = min(f, dpp_xor1(f));
+                    f = min(f, dpp_xor8(f));
+                    rt[pr] |= (f == ia ? 1u : 0u) << c;
+                    rt[pr + 2] |= (f == ib ? 1u : 0u) << c;
+                }
+        }
 #pragma unroll
         for (int mi = 0; mi < 2 * MT; ++mi) {
-            const int mt = wm * MT + (mi >> 1);
-            const int gx = x0 + (mt >> 1), gy = y0 + (mt & 1) * 4 + 2 * (mi & 1) + (r16 >> 3), gz = z0 + (r16 & 7);
+            const int gx = x0 + t16x(mi), gy = y0 + t16y(mi) + (r16 >> 3), gz = z0 + (r16 & 7);
             if (co < p.Cout && gx < p.X && gy < p.Y && gz < p.Z) {
                 const size_t o = ((((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz) * ostride + ocol;
                 float val[4][4];
@@ -1005,6 +1060,18 @@ conv3d_k3_kernel(const ConvParams p)
                         val[ni][r] = acc16[mi][ni][r] + bv[ni][r];
                         if (p.leaky && val[ni][r] < 0.f) val[ni][r] *= p.alpha;
                     }
+                if constexpr (POOLF) {   // + the pooling's gradient where this voxel was the window's maximum
+                    const float* dp = p.dpool + ((((size_t)b * (p.X >> 1) + (gx >> 1)) * (p.Y >> 1) + (gy >> 1)) * (p.Z >> 1) + (gz >> 1)) * p.Cout + co;
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        const float4 q = *reinterpret_cast<const float4*>(dp + ni * 4);
+                        const unsigned bits = rt[mi] >> (ni * 4);
+                        val[ni][0] += (bits & 1u) ? q.x : 0.f;
+                        val[ni][1] += (bits & 2u) ? q.y : 0.f;
+                        val[ni][2] += (bits & 4u) ? q.z : 0.f;
+                        val[ni][3] += (bits & 8u) ? q.w : 0.f;
+                    }
+                }
                 if (vec) {
                     if (domask) {
 #pragma unroll
@@ -1470,6 +1537,13 @@ int dispatch_conv(const ConvParams& p, hipStream_t st, int64_t* nblk_out = nullp
     if (stamps && BN == 256) return launch_conv<DT, 2, 4, 4, 2, V_FULL | (F32T ? CV_BATCHA : 0) | CV_STAMP>(p, nt, st, nblk_out);
     if (stamps && BN == 64) return launch_conv<DT, 8, 1, 2, 2, V_FULL | CV_BATCHA | CV_PRIO_Y | CV_STAMP>(p, nt, st, nblk_out);
 #endif
+    if (p.dpool) {   // masked data gradient + MaxPooling3D backward in the epilogue (CV_POOLF): the 64-column fp32 tiles only
+        if constexpr (F32T) {
+            if (BN == 64 && p.ymask && !p.csplit && !((p.X | p.Y | p.Z) & 1))
+                return launch_conv<DT, 8, 1, 2, 2, V_FULL | CV_BATCHA | CV_PRIO_Y | CV_POOLF>(p, nt, st, nblk_out);
+        }
+        return MMR_EUNSUPPORTED;
+    }
     switch (BN) {
         case 256: return launch_conv<DT, 2, 4, 4, 2, V_FULL | (F32T ? CV_BATCHA : 0)>(p, nt, st, nblk_out);
         case 128:
@@ -2527,15 +2601,39 @@ extern "C" int64_t mmr_conv3d_k3_dgrad_masked_ws_bytes(int B, int X, int Y, int 
 // Data gradient of a k3 conv (w_packed = transposed / flipped weights, no bias) whose result is at once pushed
 // through the LeakyReLU backward of the layer that produced the conv's input: out = conv(in) * (ymask < 0 ? alpha : 1),
 // dbias (+)= sum over voxels of out.  ymask = that layer's activated output [B,X,Y,Z,Cout] fp32.
+static int dgrad_masked_impl(const void* in0, int C0, const void* w_packed, float* out, int B, int X, int Y, int Z, int Cout,
+                             const float* ymask, float alpha, float* dbias, void* ws, int accumulate, int dtype,
+                             const float* dpool, void* stream);
+
 extern "C" int mmr_conv3d_k3_dgrad_masked(const void* in0, int C0, const void* w_packed, float* out, int B, int X, int Y,
                                           int Z, int Cout, const float* ymask, float alpha, float* dbias, void* ws,
                                           int accumulate, int dtype, void* stream)
+{
+    return dgrad_masked_impl(in0, C0, w_packed, out, B, X, Y, Z, Cout, ymask, alpha, dbias, ws, accumulate, dtype, nullptr, stream);
+}
+
+// The same with the gradient that reaches ymask's tensor y through MaxPooling3D(2) folded in: out = (conv(in0) + route(dpool)) *
+// LeakyReLU'(y), dbias (+)= column sums; dpool [B, X/2, Y/2, Z/2, Cout] is routed to the first maximum of every 2x2x2 window of
+// y (window order x, y, z).  MMR_DT_F32X3 / F32X1, Cout % 64 == 0 (but not % 128), even X, Y, Z; else MMR_EUNSUPPORTED.
+extern "C" int mmr_conv3d_k3_dgrad_masked_pool(const void* in0, int C0, const void* w_packed, float* out, int B, int X, int Y,
+                                               int Z, int Cout, const float* ymask, float alpha, float* dbias, void* ws,
+                                               int accumulate, int dtype, const float* dpool, void* stream)
+{
+    if (!dpool) return MMR_EINVAL;
+    if ((dtype != MMR_DT_F32X3 && dtype != MMR_DT_F32X1) || conv_bn(Cout) != 64 || ((X | Y | Z) & 1)) return MMR_EUNSUPPORTED;
+    return dgrad_masked_impl(in0, C0, w_packed, out, B, X, Y, Z, Cout, ymask, alpha, dbias, ws, accumulate, dtype, dpool, stream);
+}
+
+static int dgrad_masked_impl(const void* in0, int C0, const void* w_packed, float* out, int B, int X, int Y, int Z, int Cout,
+                             const float* ymask, float alpha, float* dbias, void* ws, int accumulate, int dtype,
+                             const float* dpool, void* stream)
 {
     if (!in0 || !w_packed || !out || !ymask || !dbias || !ws || B < 1 || X < 1 || Y < 1 || Z < 1 || Cout < 1 || C0 < 1)
         return MMR_EINVAL;
     if (dtype != MMR_DT_F32 && dtype != MMR_DT_F32X3 && dtype != MMR_DT_F32X1) return MMR_EINVAL;
     if (C0 % 32) return MMR_EINVAL;
     ConvParams p;
+    p.dpool = dpool;
     p.in0 = (const char*)in0; p.in1 = nullptr; p.wp = (const char*)w_packed; p.bias = nullptr;
     p.out = (char*)out;
     p.B = B; p.X = X; p.Y = Y; p.Z = Z; p.C0 = C0; p.C1 = 0; p.up0 = 0; p.Cout = Cout;

@@ -319,9 +319,17 @@ def conv3d_k3_dgrad_upfold(dz, w_packed, C0, ymask=None, dbias=None, alpha=0.2, 
     return out
 
 
-def conv3d_k3_dgrad_masked(dz, wt_packed, cin, ymask, dbias, alpha=0.2, accumulate=False, x3=False):
+def dgrad_masked_pool_supported(cin, x3, X, Y, Z):
+    """The masked data gradient can take the MaxPooling3D(2) backward of its output tensor into its epilogue
+    (mmr_conv3d_k3_dgrad_masked_pool) on the 64-column fp32x3 / x1 tile with even volume dims."""
+    return bool(x3) and cin % 64 == 0 and cin % 128 != 0 and not ((X | Y | Z) & 1)
+
+
+def conv3d_k3_dgrad_masked(dz, wt_packed, cin, ymask, dbias, alpha=0.2, accumulate=False, x3=False, pool_grad=None):
     """d(input) of a k3 conv, already multiplied by LeakyReLU'(ymask) of the layer that produced that input, whose
-    bias gradient (column sums of the result) lands in ``dbias``: the dgrad + leaky_bwd_bias_ pair in one kernel."""
+    bias gradient (column sums of the result) lands in ``dbias``: the dgrad + leaky_bwd_bias_ pair in one kernel.
+    ``pool_grad`` [B,X/2,Y/2,Z/2,cin]: the gradient that reaches the same tensor through MaxPooling3D(2) -- routed to each
+    window's first maximum and added before the mask (maxpool3d2_bwd(masked=True) folded into the epilogue)."""
     _chk(dz, torch.float32, "dz")
     _chk(ymask, torch.float32, "ymask")
     _chk(dbias, torch.float32, "dbias")
@@ -334,9 +342,17 @@ def conv3d_k3_dgrad_masked(dz, wt_packed, cin, ymask, dbias, alpha=0.2, accumula
     mode = conv_mode(torch.float32, x3)
     fam = f"conv3d_k3_mfma_{('f32', 'bf16', 'f32x3', 'f32x1')[mode]}_bn{256 if cin % 256 == 0 else 128 if cin % 128 == 0 else 64 if cin % 64 == 0 else 32}"
     with _Timed(fam, (C0, int(cin), X, Y, Z), 2.0 * 27 * C0 * cin * B * X * Y * Z):
-        rc = lib.mmr_conv3d_k3_dgrad_masked(dz.data_ptr(), C0, wt_packed.data_ptr(), out.data_ptr(), B, X, Y, Z, int(cin),
-                                            ymask.data_ptr(), float(alpha), dbias.data_ptr(), ws.data_ptr(),
-                                            int(accumulate), mode, _stream())
+        if pool_grad is not None:
+            _chk(pool_grad, torch.float32, "pool_grad")
+            if tuple(pool_grad.shape) != (B, X // 2, Y // 2, Z // 2, cin):
+                raise _lib.MmrError(f"pool_grad {tuple(pool_grad.shape)} != {(B, X // 2, Y // 2, Z // 2, cin)}")
+            rc = lib.mmr_conv3d_k3_dgrad_masked_pool(dz.data_ptr(), C0, wt_packed.data_ptr(), out.data_ptr(), B, X, Y, Z, int(cin),
+                                                     ymask.data_ptr(), float(alpha), dbias.data_ptr(), ws.data_ptr(),
+                                                     int(accumulate), mode, pool_grad.data_ptr(), _stream())
+        else:
+            rc = lib.mmr_conv3d_k3_dgrad_masked(dz.data_ptr(), C0, wt_packed.data_ptr(), out.data_ptr(), B, X, Y, Z, int(cin),
+                                                ymask.data_ptr(), float(alpha), dbias.data_ptr(), ws.data_ptr(),
+                                                int(accumulate), mode, _stream())
     _lib.check(rc, "mmr_conv3d_k3_dgrad_masked")
     return out
 

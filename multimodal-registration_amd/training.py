@@ -42,7 +42,7 @@ class SynthMorphTrainer:
     """model: fp32 VxmDense; gen_1/gen_2: synth.LabelsToImage (sharing the label list)."""
 
     def __init__(self, model, gen_1=None, gen_2=None, reg_param=1.0, optimizer=None, zero_pad_dice=False,
-                 process_group=None, world_size=1, rank=0, backward_precision=None, overlap_wgrad=False):
+                 process_group=None, world_size=1, rank=0, backward_precision=None, overlap_wgrad=False, fuse_pool_bwd=True):
         """gen_1 / gen_2 default to the generator pair of ``model.input_model`` (a model built the reference's way,
         ``VxmDense(..., input_model=InputModel(gen_1, gen_2))``, train_synthmorph.py:294-296).
         backward_precision: None = same arithmetic as the forward (fp32 / fp32x3); 'bf16' = dgrad and wgrad
@@ -52,7 +52,9 @@ class SynthMorphTrainer:
         reads a weight gradient before Adam).  Measured at C3: 26.0 -> 25.9 ms -- the matrix-core kernels hold every CU's LDS
         and both waves' full register budget per SIMD, so the HBM-bound kernels of the chain cannot run beside them and only
         the partial last rounds of launches fill; off by default so that per-kernel timings stay those of a kernel alone on
-        the chip.  Same kernels, same results."""
+        the chip.  Same kernels, same results.
+        fuse_pool_bwd: the MaxPooling3D backward of a skip tensor runs in the epilogue of the decoder conv's data gradient
+        (ops.conv3d_k3_dgrad_masked(pool_grad=)) where that kernel supports it; False keeps the separate pooling-backward pass."""
         if model.dtype != torch.float32:
             raise NotImplementedError("training runs the fp32 path (the reference trains in fp32)")
         im = getattr(model, "input_model", None)
@@ -71,6 +73,7 @@ class SynthMorphTrainer:
             raise ValueError("backward_precision must be None or 'bf16'")
         self.bwd_x3 = "hi" if backward_precision == "bf16" else model.x3
         self.pg, self.world, self.rank = process_group, int(world_size), int(rank)
+        self.fuse_pool_bwd = bool(fuse_pool_bwd)
         self.wstream = torch.cuda.Stream(device=model._flat.device) if (overlap_wgrad and model._flat.is_cuda) else None
         self.gflat = torch.zeros_like(model._flat)
         self.g, off = [], 0
@@ -185,6 +188,12 @@ class SynthMorphTrainer:
             else:
                 grads[id(t)] = g
 
+        # A skip tensor that also feeds a MaxPooling3D(2) gets two gradient contributions: the data gradient of the decoder layer
+        # that reads it and the pooling's.  Where ops.dgrad_masked_pool_supported says so, the first one is DEFERRED until the
+        # second exists and the pooling backward then runs in that conv's epilogue (no pass that reads the tensor and reads +
+        # rewrites its whole gradient: 3.3 GB at the first level of a 160^3 step).
+        pooled_from = {id(r[1]) for r in tape if r[0] == "pool"}
+        deferred = {}
         side = self.wstream
 
         def wgrad(fn, dz):
@@ -235,8 +244,12 @@ class SynthMorphTrainer:
                     wt_skip = ops.pack_conv_weights(wk[:, :, :, C0:, :].contiguous(), torch.float32, transpose_flip=True, x3=self.bwd_x3)
                     if want_mask(in1):
                         db, acc = bias_of(in1)
-                        grads[id(in1)] = ops.conv3d_k3_dgrad_masked(dz, wt_skip, C1, in1, db, accumulate=acc, x3=self.bwd_x3)
                         premasked.add(id(in1))
+                        if (self.fuse_pool_bwd and id(in1) in pooled_from
+                                and ops.dgrad_masked_pool_supported(C1, self.bwd_x3, *in1.shape[1:4])):
+                            deferred[id(in1)] = (dz, wt_skip, C1, db, acc)     # runs at in1's pool record
+                        else:
+                            grads[id(in1)] = ops.conv3d_k3_dgrad_masked(dz, wt_skip, C1, in1, db, accumulate=acc, x3=self.bwd_x3)
                     else:
                         grads[id(in1)] = ops.conv3d_k3(dz, wt_skip, None, C1, leaky=False, out_f32=True, x3=self.bwd_x3)
                     wt_up = ops.pack_dgrad_upfold_weights(wk, C0, x3=self.bwd_x3)
@@ -296,7 +309,10 @@ class SynthMorphTrainer:
             elif kind == "pool":
                 _, x, p = rec
                 dp = grads.pop(id(p))
-                if want_mask(x):
+                if id(x) in deferred:
+                    dzd, wtd, Cd, db, acc = deferred.pop(id(x))
+                    grads[id(x)] = ops.conv3d_k3_dgrad_masked(dzd, wtd, Cd, x, db, accumulate=acc, x3=self.bwd_x3, pool_grad=dp)
+                elif want_mask(x):
                     db, acc = bias_of(x)
                     grads[id(x)] = ops.maxpool3d2_bwd(x, dp, dx=grads.get(id(x)), masked=True, dbias=db, acc_b=acc)
                     premasked.add(id(x))

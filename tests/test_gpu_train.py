@@ -454,6 +454,50 @@ def test_dgrad_masked_equals_dgrad_then_leaky_bwd(dev, shape, Cmid, Cin, x3):
     assert _rel(db2, 2 * db_ref) < 1e-5
 
 
+@pytest.mark.parametrize("shape,Cmid,B", [((8, 8, 8), 64, 1), ((10, 12, 22), 32, 2), ((2, 2, 2), 64, 2), ((16, 8, 24), 128, 1)])
+@pytest.mark.parametrize("x3", [True, "hi"])
+def test_dgrad_masked_with_pooling_backward_in_the_epilogue(dev, shape, Cmid, B, x3):
+    """mmr_conv3d_k3_dgrad_masked_pool: the gradient of a skip tensor y that also feeds MaxPooling3D(2) -- data gradient of the
+    decoder conv + the pooling's gradient routed to each window's first maximum, times LeakyReLU'(y), bias gradient = column
+    sums -- in ONE launch, against (a) float64 autograd of conv + max_pool3d on the same linear piece and (b) the two-launch path
+    it replaces (dgrad_masked, then maxpool3d2_bwd(masked, accumulate)): same arithmetic, so equal to fp32 rounding.  Ragged
+    tiles, a volume of one window, batch of 2, TIES inside windows (first maximum in x, y, z order wins)."""
+    import mmr
+    import torch.nn.functional as F
+    ops = mmr.ops
+    rng = np.random.default_rng(hash((shape, Cmid)) % 2 ** 31)
+    Cy = 64
+    X, Y, Z = shape
+    dz = rng.standard_normal((B,) + shape + (Cmid,)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, Cy, Cmid)) * 0.05).astype(np.float32)              # forward kernel y (64 ch) -> Cmid
+    y = rng.standard_normal((B,) + shape + (Cy,)).astype(np.float32)
+    y[:, ::2, 1::2, :, :8] = 0.75          # ties: several equal maxima per window in the first channels
+    y[:, :, :, :, 8:12] = np.round(y[:, :, :, :, 8:12])                                    # and many accidental ones
+    dp = rng.standard_normal((B, X // 2, Y // 2, Z // 2, Cy)).astype(np.float32)
+    assert ops.dgrad_masked_pool_supported(Cy, x3, X, Y, Z)
+    wt = ops.pack_conv_weights(_t(w, dev), torch.float32, transpose_flip=True, x3=x3)
+    db = torch.full((Cy,), 5.0, device=dev)
+    got = ops.conv3d_k3_dgrad_masked(_t(dz, dev), wt, Cy, _t(y, dev), db, accumulate=True, x3=x3, pool_grad=_t(dp, dev))
+    # (b) the two-launch path
+    db2 = torch.zeros(Cy, device=dev)
+    two = ops.conv3d_k3_dgrad_masked(_t(dz, dev), wt, Cy, _t(y, dev), db2, x3=x3)
+    two = ops.maxpool3d2_bwd(_t(y, dev), _t(dp, dev), dx=two, masked=True, dbias=db2, acc_b=True)
+    assert _rel(got, two) < 2e-6 and _rel(db - 5.0, db2) < 1e-5
+    # (a) float64: d/dy_pre of sum(conv(y) * dz) + sum(pool(y) * dp) with y = LeakyReLU(y_pre) on y's linear piece
+    yt = torch.from_numpy(y).double().requires_grad_(True)
+    wk = torch.from_numpy(w).double()
+    c = F.conv3d(yt.permute(0, 4, 1, 2, 3), wk.permute(4, 3, 0, 1, 2), padding=1).permute(0, 2, 3, 4, 1)
+    pooled = F.max_pool3d(yt.permute(0, 4, 1, 2, 3), 2).permute(0, 2, 3, 4, 1)
+    ((c * torch.from_numpy(dz).double()).sum() + (pooled * torch.from_numpy(dp).double()).sum()).backward()
+    ref = yt.grad * torch.where(yt.detach() < 0, 0.2, 1.0)
+    tol = 1e-4 if x3 is True else 1.5e-2
+    # torch's max_pool3d backward also routes to the first maximum in (x, y, z) scan order
+    assert _rel(got, ref) < tol, _rel(got, ref)
+    assert _rel(db - 5.0, ref.sum((0, 1, 2, 3))) < (1e-4 if x3 is True else 2e-2)
+    with pytest.raises(mmr._lib.MmrError):      # odd dims: no whole windows -> refused, the caller keeps the two-launch path
+        ops.conv3d_k3_dgrad_masked(_t(dz[:, :-1], dev), wt, Cy, _t(y[:, :-1], dev), db, x3=x3, pool_grad=_t(dp, dev))
+
+
 @pytest.mark.parametrize("shape,Cin", [((8, 8, 8), 64), ((5, 9, 11), 128), ((2, 17, 3), 64)])
 def test_flow_dgrad_x3_kernel(dev, shape, Cin):
     """flow_dgrad_x3_kernel (channels as MFMA rows, K ordered (dx, dy | dz, co), bf16 hi/lo products): vs float64

@@ -1,7 +1,6 @@
 #!/usr/bin/env python
-"""C3 training step with the weight gradients on a side stream (SynthMorphTrainer(overlap_wgrad=True), the default) against
-the one-stream step, alternated in one process; also checks that both produce the same gradients.
-  python tools/time_overlap.py [steps]"""
+"""C3 training step A/B of one trainer option, alternated in one process, with a gradient comparison:
+  python tools/time_overlap.py [steps] [option]     option: overlap_wgrad (default) | fuse_pool_bwd"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,6 +8,7 @@ import mmr
 from mmr import synth, training
 dev = torch.device("cuda", 0)
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+opt = sys.argv[2] if len(sys.argv) > 2 else "overlap_wgrad"
 shape, L, feats = (160, 160, 160), 26, 64
 enc, dec = [feats] * 4, [feats] * 6
 maps = synth.generate_label_maps(shape, L, 1, [16, 32, 64], [8, 16, 32], 1, 3, seed=100, device=dev)
@@ -20,7 +20,7 @@ for ov in (False, True):
     g1, g2 = synth.labels_to_image(**kw, id=0, seed=11), synth.labels_to_image(**kw, id=1, seed=12)
     model = mmr.networks.VxmDense(shape, nb_unet_features=(enc, dec), int_steps=5, int_resolution=2, svf_resolution=2,
                                   compute_dtype="fp32x3", device=dev, seed=0)
-    trs[ov] = (training.SynthMorphTrainer(model, g1, g2, reg_param=1.0, optimizer=training.Adam(1e-4), overlap_wgrad=ov), g1, g2)
+    trs[ov] = (training.SynthMorphTrainer(model, g1, g2, reg_param=1.0, optimizer=training.Adam(1e-4), **{opt: ov}), g1, g2)
 # same draws -> same gradients
 d = {}
 for ov, (tr, g1, g2) in trs.items():
@@ -38,4 +38,4 @@ for rnd in range(3):
         for _ in range(steps):
             tr.train_step(src, src)
         torch.cuda.synchronize()
-        print(f"round {rnd} overlap_wgrad={ov!s:5s}: {(time.perf_counter() - t0) / steps * 1e3:.2f} ms/step", flush=True)
+        print(f"round {rnd} {opt}={ov!s:5s}: {(time.perf_counter() - t0) / steps * 1e3:.2f} ms/step", flush=True)
