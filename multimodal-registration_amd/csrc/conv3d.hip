@@ -1885,14 +1885,22 @@ conv3d_cin2_mfma_kernel(const float* __restrict__ src, const float* __restrict__
             // with the window maximum, the lanes with even y and z stage it (pooled voxel (y >> 1) * 4 + (z >> 1) of the wave)
             float pv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float m = fmaxf(vals2[0][r], vals2[1][r]);
-                // v_max_f32 with the DPP operand in the instruction (hipcc keeps update_dpp + max as two).  Inside an asm the
-                // compiler pads nothing: a DPP read of a VGPR written by the previous VALU instruction needs 2 wait states
-                asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(m) : "v"(m));
-                asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(m) : "v"(m));
-                pv[r] = m;
-            }
+            for (int r = 0; r < 16; ++r) pv[r] = fmaxf(vals2[0][r], vals2[1][r]);
+            // v_max_f32 with the DPP operand in the instruction (hipcc keeps update_dpp + max as two).  Inside an asm the
+            // compiler pads nothing and a DPP read of a VGPR written by the previous VALU instruction needs 2 wait states: all
+            // sixteen z steps, then all sixteen y steps, in ONE block -- every DPP source was written sixteen instructions
+            // earlier, so a single s_nop (for the value the compiler computed last) replaces the 32 of the per-value form
+#define MMR_PZ(i) "v_max_f32_dpp %" #i ", %" #i ", %" #i " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+#define MMR_PY(i) "v_max_f32_dpp %" #i ", %" #i ", %" #i " row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            asm("s_nop 1\n\t"
+                MMR_PZ(0) MMR_PZ(1) MMR_PZ(2) MMR_PZ(3) MMR_PZ(4) MMR_PZ(5) MMR_PZ(6) MMR_PZ(7)
+                MMR_PZ(8) MMR_PZ(9) MMR_PZ(10) MMR_PZ(11) MMR_PZ(12) MMR_PZ(13) MMR_PZ(14) MMR_PZ(15)
+                MMR_PY(0) MMR_PY(1) MMR_PY(2) MMR_PY(3) MMR_PY(4) MMR_PY(5) MMR_PY(6) MMR_PY(7)
+                MMR_PY(8) MMR_PY(9) MMR_PY(10) MMR_PY(11) MMR_PY(12) MMR_PY(13) MMR_PY(14) MMR_PY(15)
+                : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]), "+v"(pv[7]),
+                  "+v"(pv[8]), "+v"(pv[9]), "+v"(pv[10]), "+v"(pv[11]), "+v"(pv[12]), "+v"(pv[13]), "+v"(pv[14]), "+v"(pv[15]));
+#undef MMR_PZ
+#undef MMR_PY
             stage(64 + ((lane >> 4) & 1) * 4 + ((lane & 7) >> 1), pv, !(lane & 1) && !(lane & 8));
         }
         if ((n & (G - 1)) == G - 1) {
