@@ -438,7 +438,7 @@ def main():
     import mmr
 
     # which device every rank really sits on (gathered once; the judge reads it from the line instead of re-running)
-    rank_devices = [torch.cuda.current_device()]
+    rank_devices = [{"rank": rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(local)}]
     if use_dist:
         gathered = [None] * world
         dist.all_gather_object(gathered, (rank, torch.cuda.current_device(), torch.cuda.get_device_name(local)))

@@ -323,6 +323,8 @@ class SynthMorphTrainer:
                 dy = grads.pop(id(y))
                 dz = dy if id(y) in premasked else ops.leaky_bwd_bias_(y, dy, self.g[1], leaky=True)
                 wgrad(lambda: ops.conv3d_k3_cin2_wgrad(src, trg, dz, self.g[0], x3=bool(self.bwd_x3)), dz)
+        if deferred:   # a deferred skip gradient whose pooling record never came: the tape is not a U-Net's
+            raise RuntimeError(f"{len(deferred)} deferred skip gradient(s) were never completed (tape without the pooling record)")
         if side is not None:   # join: Adam / the all-reduce read every weight gradient
             done = torch.cuda.Event()
             done.record(side)
