@@ -1375,320 +1375,6 @@ conv_ksplit_finalize_kernel(const float* __restrict__ kpart, int nk, const float
     }
 }
 
-// ---- fp32x3 conv built for OCCUPANCY ("x3s"): 64 output columns, 4-wave workgroups, three of them per CU -------------------- //
-// The 8-wave kernel above owns a CU (140 KB of LDS, 2 waves per SIMD in lockstep, 48 MFMAs per wave between two barriers) and
-// keeps the matrix pipe 50 % busy on the 64-column fp32x3 tile.  A model of the tap loop (tools/ubench/occ_conv_model.hip: weight
-// group reload -> barrier -> 48 MFMAs with their fragment reads -> barrier) reaches 49 % of the bf16 peak with one 4-wave workgroup
-// per CU, 62 % with two and 64 % with three: INDEPENDENT workgroups fill each other's barrier, reload and fragment-latency gaps.
-// To fit three per CU the tile shrinks in K, not in M or N:
-//   * K slice = 16 channels; LDS row of the haloed 6 x 10 x 10-voxel A tile = 64 B = [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15]
-//     (38.4 KB), chunk XOR ((hy & 1) << 1): every ds_read_b128 lane group (2 y rows x 8 z of one k chunk pair) hits 16
-//     distinct 16-B slots of a 256-B bank line;
-//   * with 16 channels a product has K = 16 but the MFMA wants 32: the three products of TWO taps are regrouped into three
-//     full MFMAs -- R1(t): [a_hi | a_lo](t) x [w_hi | w_hi](t) = hi*hi + lo*hi of tap t; the same for t + 1; R2:
-//     [a_hi(t) | a_hi(t + 1)] x [w_lo(t) | w_lo(t + 1)] = hi*lo of both taps (lanes of the upper k half address the other tap);
-//     27 taps = 13 pairs + (tap 26, zero tap), whose R1(t + 1) is skipped: 16 wasted MFMAs in 664;
-//   * weights: 8 KB per tap pair ([tap 2][chunk 4][64 cols][16 B], columns permuted as in pack_kernel), single-buffered:
-//     barrier -> LDS-DMA -> barrier -> 48 MFMAs per wave; the other two workgroups of the CU run meanwhile;
-//   * workgroup = 4 waves = 4 x planes of a 4 x 8 x 8 tile, wave tile 64 voxels x 64 columns (64 accumulator registers).
-// Plain and masked (training dgrad) epilogues; one directly-read input.  Everything else stays on the 8-wave kernel.
-constexpr int S_THREADS = 256;
-constexpr int S_ROWB = 64;
-constexpr int S_A_BYTES = HROWS * S_ROWB;            // 38,400
-constexpr int S_PAIR_BYTES = 2 * 4 * 64 * 16;        // 8,192
-constexpr int S_PAIRS = 14;
-constexpr int S_LDS = S_A_BYTES + S_PAIR_BYTES;      // 46,592: three workgroups per CU
-constexpr int S_AITEMS = HROWS * 2;                  // (row, 8-channel group)
-constexpr int S_AIT = (S_AITEMS + S_THREADS - 1) / S_THREADS;   // 5
-
-__host__ __device__ inline int64_t conv_x3s_bytes(int Cin, int Cout)
-{
-    return (int64_t)(Cout / 64) * (Cin / 16) * S_PAIRS * S_PAIR_BYTES;
-}
-__host__ __device__ inline bool conv_x3s_shape_ok(int Cin, int Cout) { return Cin >= 16 && Cin % 16 == 0 && conv_bn(Cout) == 64; }
-
-// weight image of the x3s kernel: [n-tile][slice 16 ch][pair 14][tap in pair 2][chunk 4: hi 0-7, hi 8-15, lo 0-7, lo 8-15][64 cols][16 B]
-__global__ void pack_x3s_kernel(const float* __restrict__ w, char* __restrict__ wp, int Cin, int Cout, int transpose_flip)
-{
-    const int ns = Cin / 16, nt = Cout / 64;
-    const int64_t total = (int64_t)nt * ns * S_PAIRS * 2 * 4 * 64;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t r = i;
-        const int col = (int)(r % 64); r /= 64;
-        const int chunk = (int)(r % 4); r /= 4;
-        const int tsel = (int)(r % 2); r /= 2;
-        const int pr = (int)(r % S_PAIRS); r /= S_PAIRS;
-        const int sl = (int)(r % ns);
-        const int t = (int)(r / ns);
-        const int tap = 2 * pr + tsel;
-        const int co = t * 64 + conv_cout_of_col(col);
-        bf16_t o[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int ci = sl * 16 + (chunk & 1) * 8 + e;
-            float v = 0.f;
-            if (tap < 27) {
-                if (transpose_flip) v = w[((int64_t)(26 - tap) * Cout + co) * Cin + ci];  // keras dims [27][Cout][Cin]
-                else v = w[((int64_t)tap * Cin + ci) * Cout + co];
-            }
-            bf16_t hb = f32_to_bf16(v);
-            if (chunk >= 2) hb = f32_to_bf16(v - bf16_to_f32(hb));
-            o[e] = hb;
-        }
-        uint4 q;
-        q.x = (unsigned)o[0] | ((unsigned)o[1] << 16); q.y = (unsigned)o[2] | ((unsigned)o[3] << 16);
-        q.z = (unsigned)o[4] | ((unsigned)o[5] << 16); q.w = (unsigned)o[6] | ((unsigned)o[7] << 16);
-        *reinterpret_cast<uint4*>(wp + i * 16) = q;
-    }
-}
-
-// NBUF: weight-pair buffers: 1 = reload between two barriers, three workgroups per CU; 2 = double-buffered, two per CU.
-// MTX: x planes per wave: 1 = 4 x 8 x 8 tile (wave tile 64 x 64, 0.5 fragment reads per MFMA), 2 = 8 x 8 x 8 tile (wave tile 128 x 64, 0.375
-// reads per MFMA, halo 1.95x instead of 2.34x; 80 KB of LDS with NBUF = 2: two workgroups per CU)
-template <int NBUF, int MTX>
-__global__ void __launch_bounds__(S_THREADS, (NBUF == 1 && MTX == 1) ? 3 : 2)
-conv3d_k3_x3s_kernel(const ConvParams p)
-{
-    constexpr int TXS = 4 * MTX, HROWS_S = (TXS + 2) * HY * HZ, A_BYTES_S = HROWS_S * S_ROWB, NMT = 4 * MTX;
-    constexpr int AITEMS = HROWS_S * 2, AIT = (AITEMS + S_THREADS - 1) / S_THREADS;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;
-    char* sB = smem + A_BYTES_S;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r16 = lane & 15, q16 = lane >> 4;
-    int bid = (int)blockIdx.x;
-    const int tzi = bid % p.ntz; bid /= p.ntz;
-    const int tyi = bid % p.nty; bid /= p.nty;
-    const int txi = bid % p.ntx;
-    const int b = bid / p.ntx;
-    const int x0 = txi * TXS, y0 = tyi * TY, z0 = tzi * TZ;
-    const int ntile = (int)blockIdx.y;
-    const int ns = p.C0 / 16;
-    const char* wtile = p.wp + (size_t)ntile * ns * (S_PAIRS * S_PAIR_BYTES);
-
-    f32x4 acc[NMT][4];
-#pragma unroll
-    for (int mi = 0; mi < NMT; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // 16-voxel tile mi of this wave: x plane wave * MTX + (mi >> 2), y rows 2 (mi & 3) + (r16 >> 3), z = r16 & 7
-    int a_off[NMT];
-#pragma unroll
-    for (int mi = 0; mi < NMT; ++mi) a_off[mi] = (((wave * MTX + (mi >> 2)) * HY + 2 * (mi & 3) + (r16 >> 3)) * HZ + (r16 & 7)) * S_ROWB;
-    const int ypar0 = (r16 >> 3) & 1;
-
-    // staging roles: item = (halo row, 8-channel group); source offset (without the slice) and LDS destination once per tile
-    unsigned st_src[AIT];      // element offset into p.in0 (tensors of the 64-column layers stay below 2^32 elements)
-    unsigned st_dst[AIT];      // byte offset of the hi chunk in sA; the lo chunk is at ^ 32
-    unsigned st_ok = 0;
-#pragma unroll
-    for (int k = 0; k < AIT; ++k) {
-        const int i0 = tid + k * S_THREADS;
-        const int i = i0 < AITEMS ? i0 : AITEMS - 1;
-        const int row = i >> 1, c8 = i & 1;
-        const int hx = row / (HY * HZ), hy = (row / HZ) % HY, hz = row % HZ;
-        const int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
-        const bool ok = i0 < AITEMS && gx >= 0 && gx < p.X && gy >= 0 && gy < p.Y && gz >= 0 && gz < p.Z;
-        const int cx = gx < 0 ? 0 : (gx >= p.X ? p.X - 1 : gx), cy = gy < 0 ? 0 : (gy >= p.Y ? p.Y - 1 : gy),
-                  cz = gz < 0 ? 0 : (gz >= p.Z ? p.Z - 1 : gz);
-        st_src[k] = (unsigned)((((size_t)b * p.X + cx) * p.Y + cy) * p.Z + cz) * (unsigned)p.C0 + (unsigned)(c8 * 8);
-        st_dst[k] = (unsigned)(row * S_ROWB + ((c8 ^ ((hy & 1) << 1)) << 4));
-        st_ok |= ok ? (1u << k) : 0u;
-    }
-    const float* in = reinterpret_cast<const float*>(p.in0);
-    const unsigned sB_lds = lds_addr(sB);
-    auto issue_pair = [&](int s, int pr, int buf = 0) {
-        const char* src = wtile + ((size_t)s * S_PAIRS + pr) * S_PAIR_BYTES + tid * 16;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(sB_lds + buf * S_PAIR_BYTES + wave * 1024);
-        glds16(src, dst);
-        glds16(src + 4096, dst + 4096);
-    };
-    // one MFMA round of this wave: 4 voxel tiles x 4 column tiles, fragments from the lane's A / B addresses
-    auto round16 = [&](const char* pa, const char* pb) {
-        uint4 fa[NMT], fb[4];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) fb[ni] = *reinterpret_cast<const uint4*>(pb + ni * 256);
-#pragma unroll
-        for (int mi = 0; mi < NMT; ++mi) fa[mi] = *reinterpret_cast<const uint4*>(pa + a_off[mi]);
-#pragma unroll
-        for (int mi = 0; mi < NMT; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[ni]),
-                                                                    __builtin_bit_cast(bf16x8, fa[mi]), acc[mi][ni], 0, 0, 0);
-    };
-    // A address of tap `tap` for k chunk `chunk` of this lane's voxel rows (without a_off): tap offset + swizzled chunk
-    auto a_base = [&](int tap, int chunk) -> const char* {
-        const int dx = tap / 9, dy = (tap / 3) % 3, dz = tap % 3;
-        const int par = (ypar0 + dy) & 1;
-        return sA + ((dx * HY + dy) * HZ + dz) * S_ROWB + ((chunk ^ (par << 1)) << 4);
-    };
-
-    for (int s = 0; s < ns; ++s) {
-        __syncthreads();                       // every wave is done with the previous slice's A tile and weight pair
-        issue_pair(s, 0);                      // the first pair's DMA runs under the A staging
-        {
-            uint4 va[AIT], vb[AIT];
-#pragma unroll
-            for (int k = 0; k < AIT; ++k) {
-                const float* q = in + st_src[k] + s * 16;
-                va[k] = *reinterpret_cast<const uint4*>(q);
-                vb[k] = *reinterpret_cast<const uint4*>(q + 4);
-            }
-#pragma unroll
-            for (int k = 0; k < AIT; ++k) {
-                const unsigned m = (st_ok >> k) & 1u ? 0xffffffffu : 0u;
-                const unsigned u[8] = {va[k].x & m, va[k].y & m, va[k].z & m, va[k].w & m, vb[k].x & m, vb[k].y & m, vb[k].z & m, vb[k].w & m};
-                unsigned hi[4], lo[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float f0 = __uint_as_float(u[2 * e]), f1 = __uint_as_float(u[2 * e + 1]);
-                    hi[e] = pack_bf16x2(f0, f1);
-                    lo[e] = pack_bf16x2(f0 - __uint_as_float(hi[e] << 16), f1 - __uint_as_float(hi[e] & 0xffff0000u));
-                }
-                // (an item index beyond the tile was clamped to the last item: it stores the same values to the same place)
-                *reinterpret_cast<uint4*>(sA + st_dst[k]) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-                *reinterpret_cast<uint4*>(sA + (st_dst[k] ^ 32u)) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-            }
-        }
-        for (int pr = 0; pr < S_PAIRS; ++pr) {
-            const char* sBp = sB;
-            if constexpr (NBUF == 1) {
-                if (pr > 0) {
-                    __syncthreads();           // every wave has read the previous pair's weights
-                    issue_pair(s, pr);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();               // pair pr has landed (and, for pr = 0, the A tile is in place)
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();               // pair pr has landed everywhere; every wave is past pair pr - 1: its buffer is free
-                if (pr + 1 < S_PAIRS) issue_pair(s, pr + 1, (pr + 1) & 1);
-                sBp = sB + (pr & 1) * S_PAIR_BYTES;
-            }
-            const int t0 = 2 * pr;
-            const int t1 = t0 + 1 < 27 ? t0 + 1 : 26;          // pair 13: zero weights for the second tap, any valid A address
-            const char* pbr = sBp + ((q16 & 1) * 64 + r16) * 16;
-            round16(a_base(t0, q16), pbr);                                           // hi*hi + lo*hi of tap t0
-            if (pr + 1 < S_PAIRS) round16(a_base(t1, q16), pbr + 4 * 1024);           // ... of tap t0 + 1
-            round16(a_base((q16 >> 1) ? t1 : t0, q16 & 1),                           // hi*lo of both taps
-                    sBp + (((q16 >> 1) * 4 + 2 + (q16 & 1)) * 64 + r16) * 16);
-        }
-    }
-
-    // ---- epilogue: bias + LeakyReLU (forward) or mask + column sums (training dgrad), 64-B runs per lane ----
-    const int co = ntile * 64 + q16 * 16;
-    float bv[4][4], csum[4][4];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            bv[ni][r] = p.bias ? p.bias[co + ni * 4 + r] : 0.f;
-            csum[ni][r] = 0.f;
-        }
-#pragma unroll
-    for (int mi = 0; mi < NMT; ++mi) {
-        const int gx = x0 + wave * MTX + (mi >> 2), gy = y0 + 2 * (mi & 3) + (r16 >> 3), gz = z0 + (r16 & 7);
-        if (gx < p.X && gy < p.Y && gz < p.Z) {
-            const size_t o = ((((size_t)b * p.X + gx) * p.Y + gy) * p.Z + gz) * p.Cout + co;
-            float* po = reinterpret_cast<float*>(p.out) + o;
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = acc[mi][ni][r] + bv[ni][r];
-                    if (p.leaky && v[r] < 0.f) v[r] *= p.alpha;
-                }
-                if (p.ymask) {
-                    const float4 ym = *reinterpret_cast<const float4*>(p.ymask + o + ni * 4);
-                    if (ym.x < 0.f) v[0] *= p.alpha;
-                    if (ym.y < 0.f) v[1] *= p.alpha;
-                    if (ym.z < 0.f) v[2] *= p.alpha;
-                    if (ym.w < 0.f) v[3] *= p.alpha;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) csum[ni][r] += v[r];
-                }
-                *reinterpret_cast<float4*>(po + ni * 4) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-        }
-    }
-    if (p.ymask) {
-        __syncthreads();                       // the A tile is free
-        float* s_col = reinterpret_cast<float*>(smem);   // [4 waves][64]
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float c = csum[ni][r];
-                c += __shfl_xor(c, 1);
-                c += __shfl_xor(c, 2);
-                c += __shfl_xor(c, 4);
-                c += __shfl_xor(c, 8);
-                if (r16 == 0) s_col[wave * 64 + q16 * 16 + ni * 4 + r] = c;
-            }
-        __syncthreads();
-        if (tid < 64) {
-            double t = 0.0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) t += (double)s_col[k * 64 + tid];
-            p.part[(size_t)(ntile * 64 + tid) * gridDim.x + blockIdx.x] = t;
-        }
-    }
-}
-
-// x3s serves: fp32x3, 64-column tiles, one directly-read input, plain or masked epilogue, enough tiles to fill three workgroups per
-// CU twice over (smaller launches keep the 8-wave kernel with its split-K forms)
-#ifdef MMR_DIAG
-int g_diag_x3s = 1;      // diagnostic build: mmr_debug_x3s(0) sends every launch to the 8-wave kernel (same-box A/B)
-extern "C" int mmr_debug_x3s(int on) { g_diag_x3s = on; return MMR_OK; }
-#endif
-inline bool conv_x3s_applies(const ConvParams& p)
-{
-#ifdef MMR_DIAG
-    if (!g_diag_x3s) return false;
-#endif
-    if (!conv_x3s_shape_ok(p.C0, p.Cout) || p.C1 != 0 || p.up0 || p.csplit || p.cinit || p.dpool || p.out1) return false;
-    if ((size_t)p.B * p.X * p.Y * p.Z * (size_t)p.C0 >= (1ull << 32)) return false;
-    const int64_t tiles = (int64_t)p.B * ((p.X + TX - 1) / TX) * ((p.Y + TY - 1) / TY) * ((p.Z + TZ - 1) / TZ) * (p.Cout / 64);
-    return tiles >= 2 * 768;
-}
-
-template <int NBUF, int MTX>
-inline int launch_conv_x3s_v(const ConvParams& p, hipStream_t st, int64_t* nblk_out)
-{
-    constexpr int TXS = 4 * MTX;
-    constexpr int LDS = (TXS + 2) * HY * HZ * S_ROWB + NBUF * S_PAIR_BYTES;
-    static_assert(LDS <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    auto kern = conv3d_k3_x3s_kernel<NBUF, MTX>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
-        attr_set = true;
-    }
-    ConvParams q = p;
-    q.ntx = (p.X + TXS - 1) / TXS; q.nty = (p.Y + TY - 1) / TY; q.ntz = (p.Z + TZ - 1) / TZ;
-    const int64_t nblk = (int64_t)q.B * q.ntx * q.nty * q.ntz;
-    if (nblk > 0x7fffffff) return MMR_EINVAL;
-    if (nblk_out) *nblk_out = nblk;
-    // the x3s image follows the 8-wave kernel's image in the packed buffer (mmr_conv3d_k3_pack writes both)
-    q.wp = p.wp + (int64_t)(p.Cout / 64) * (p.C0 / 32) * 27 * 64 * 128;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, p.Cout / 64), dim3(S_THREADS), LDS, st, q);
-    return check_launch();
-}
-
-inline int launch_conv_x3s(const ConvParams& p, hipStream_t st, int64_t* nblk_out)
-{
-#ifdef MMR_DIAG
-    if (g_diag_x3s == 2) return launch_conv_x3s_v<2, 1>(p, st, nblk_out);
-    if (g_diag_x3s == 3) return launch_conv_x3s_v<2, 2>(p, st, nblk_out);
-    if (g_diag_x3s == 4) return launch_conv_x3s_v<1, 2>(p, st, nblk_out);
-#endif
-    return launch_conv_x3s_v<1, 1>(p, st, nblk_out);
-}
-
 // Tail of a launch whose tile count is not a multiple of the CU count (one workgroup per CU: a launch of 2 400 tiles runs as
 // ten rounds of 256, the last one 37 % full -- 9.4 rounds of work in the time of 10; 300 tiles: 1.2 in the time of 2).  The
 // last nblk % ncu tiles are launched on their own with their K walk split over ncu / R workgroups each (compact fp32 partials,
@@ -1851,9 +1537,6 @@ int dispatch_conv(const ConvParams& p, hipStream_t st, int64_t* nblk_out = nullp
     if (stamps && BN == 256) return launch_conv<DT, 2, 4, 4, 2, V_FULL | (F32T ? CV_BATCHA : 0) | CV_STAMP>(p, nt, st, nblk_out);
     if (stamps && BN == 64) return launch_conv<DT, 8, 1, 2, 2, V_FULL | CV_BATCHA | CV_PRIO_Y | CV_STAMP>(p, nt, st, nblk_out);
 #endif
-    if constexpr (DT == MMR_DT_F32X3) {
-        if (conv_x3s_applies(p)) return launch_conv_x3s(p, st, nblk_out);
-    }
     if (p.dpool) {   // masked data gradient + MaxPooling3D backward in the epilogue (CV_POOLF): the 64-column fp32 tiles only
         if constexpr (F32T) {
             if (BN == 64 && p.ymask && !p.csplit && !((p.X | p.Y | p.Z) & 1))
@@ -2713,11 +2396,7 @@ extern "C" int64_t mmr_conv3d_k3_packed_bytes(int Cin, int Cout, int dtype)
     if (Cin % kc) return MMR_EINVAL;
     const int BN = conv_bn(Cout);
     const int nt = (Cout + BN - 1) / BN;
-    int64_t bytes = (int64_t)nt * (Cin / kc) * 27 * BN * 128;
-    // fp32x3, 64-column layers: the image of the occupancy-built kernel (conv3d_k3_x3s_kernel) follows the ordinary one; which
-    // kernel runs depends on the volume, which the pack does not know
-    if (dtype == MMR_DT_F32X3 && conv_x3s_shape_ok(Cin, Cout)) bytes += conv_x3s_bytes(Cin, Cout);
-    return bytes;
+    return (int64_t)nt * (Cin / kc) * 27 * BN * 128;
 }
 
 extern "C" int mmr_conv3d_k3_pack(const float* w_keras, void* w_packed, int Cin, int Cout, int dtype,
@@ -2727,11 +2406,7 @@ extern "C" int mmr_conv3d_k3_pack(const float* w_keras, void* w_packed, int Cin,
     if (!w_keras || !w_packed || bytes < 0) return MMR_EINVAL;
     const int BN = conv_bn(Cout);
     const int nt = (Cout + BN - 1) / BN;
-    const int64_t bytes8 = (int64_t)nt * (Cin / ((dtype == MMR_DT_BF16) ? 64 : 32)) * 27 * BN * 128;   // the 8-wave kernels' image
-    const int grid = stream_grid(bytes8 / 16, 256);
-    if (dtype == MMR_DT_F32X3 && conv_x3s_shape_ok(Cin, Cout))
-        hipLaunchKernelGGL(pack_x3s_kernel, dim3(stream_grid(conv_x3s_bytes(Cin, Cout) / 16, 256)), dim3(256), 0, as_stream(stream), w_keras,
-                           (char*)w_packed + bytes8, Cin, Cout, transpose_flip);
+    const int grid = stream_grid(bytes / 16, 256);
     if (dtype == MMR_DT_BF16)
         hipLaunchKernelGGL(pack_kernel<MMR_DT_BF16>, dim3(grid), dim3(256), 0, as_stream(stream), w_keras,
                            (char*)w_packed, Cin, Cout, BN, nt, transpose_flip, 0);

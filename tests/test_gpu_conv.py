@@ -316,53 +316,3 @@ def test_half_partial_of_folded_pair_saturates_at_the_half_range(dev):
     assert np.abs(out - (clamped + ref_skip)).max() < 1e-5 * 65504      # fp32 accumulation on a 65504 base (ulp 2^-8)
     exact = ops.conv3d_k3_upfold(t0, t1, w_up, w_skip, None, Cout, leaky=False, out_f32=True, half_partial=False).cpu().numpy()
     assert np.abs(exact - (ref_up + ref_skip)).max() < 1e-5 * np.abs(ref_up).max()
-
-
-@pytest.mark.parametrize("shape,B,Cin,Cout", [((64, 64, 96), 1, 64, 64), ((58, 70, 98), 1, 32, 64), ((44, 60, 70), 2, 128, 64),
-                                              ((40, 48, 104), 1, 96, 192)])
-def test_x3s_occupancy_kernel_windows_vs_oracle(dev, shape, B, Cin, Cout):
-    """conv3d_k3_x3s_kernel (fp32x3, 64-column layers, launches of >= 1536 4x8x8 tiles: the kernel every full-resolution 64 -> 64
-    conv of BASELINE configs[2] runs on): 16-channel K slices, tap-pair MFMA regrouping, three 4-wave workgroups per CU.  Windows
-    against the C oracle on cropped inputs -- far corner and origin corner (zero-padded faces), an interior block across tile
-    seams -- at north_star's 1e-4; ragged tiles on every axis, batch of 2, 2 - 8 slices, three column tiles; bit-reproducible."""
-    import mmr
-    from oracle.cbind import conv3d_same
-    ops = mmr.ops
-    rng = np.random.default_rng(hash((shape, Cin, Cout)) % 2 ** 31)
-    x = rng.standard_normal((B,) + shape + (Cin,)).astype(np.float32)
-    w = (rng.standard_normal((3, 3, 3, Cin, Cout)) * np.sqrt(2.0 / (27 * Cin))).astype(np.float32)
-    bias = (rng.standard_normal(Cout) * 0.1).astype(np.float32)
-    xt = torch.from_numpy(x).to(dev)
-    wp = ops.pack_conv_weights(torch.from_numpy(w).to(dev), torch.float32, x3=True)
-    y = ops.conv3d_k3(xt, wp, torch.from_numpy(bias).to(dev), Cout, leaky=True, x3=True)
-    assert torch.equal(y, ops.conv3d_k3(xt, wp, torch.from_numpy(bias).to(dev), Cout, leaky=True, x3=True))
-    yc = y.cpu().numpy()
-    n = 14
-    X, Y, Z = shape
-    for bi, org in ((0, (0, 0, 0)), (B - 1, (X - n, Y - n, Z - n)), (0, (X // 2 - 5, Y // 2 - 3, Z // 2 - 6))):
-        sl = tuple(slice(o, o + n) for o in org)
-        ref = conv3d_same(x[bi:bi + 1][(slice(None),) + sl], w, bias, leaky=True, alpha=0.2)[0]
-        keep = tuple(slice(0 if o == 0 else 1, n if o + n == s else n - 1) for o, s in zip(org, shape))
-        vol = tuple(slice(o + k.start, o + k.stop) for o, k in zip(org, keep))
-        err = np.abs(yc[bi][vol] - ref[keep]).max() / np.abs(ref[keep]).max()
-        assert err < 1e-4, (org, err)
-
-
-def test_x3s_masked_dgrad_epilogue(dev):
-    """The occupancy kernel's training epilogue (LeakyReLU backward of the producing layer + bias column sums) at a size where it
-    runs: against the unfused pair (the conv + leaky_bwd_bias_), same arithmetic."""
-    import mmr
-    ops = mmr.ops
-    rng = np.random.default_rng(5)
-    shape, C = (64, 64, 96), 64
-    dz = torch.from_numpy(rng.standard_normal((1,) + shape + (C,)).astype(np.float32)).to(dev)
-    w = torch.from_numpy((rng.standard_normal((3, 3, 3, C, C)) * 0.05).astype(np.float32)).to(dev)
-    y = torch.from_numpy(rng.standard_normal((1,) + shape + (C,)).astype(np.float32)).to(dev)
-    wt = ops.pack_conv_weights(w, torch.float32, transpose_flip=True, x3=True)
-    ref = ops.conv3d_k3(dz, wt, None, C, leaky=False, out_f32=True, x3=True)
-    db_ref = torch.zeros(C, device=dev)
-    ref = ops.leaky_bwd_bias_(y, ref, db_ref, leaky=True)
-    db = torch.full((C,), 3.0, device=dev)
-    got = ops.conv3d_k3_dgrad_masked(dz, wt, C, y, db, accumulate=True, x3=True)
-    assert torch.equal(got, ref)
-    assert float((db - 3.0 - db_ref).abs().max()) < 1e-5 * float(db_ref.abs().max())
