@@ -99,3 +99,15 @@ def test_torchrun_form_two_ranks():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["dist"]["world_size"] == 2 and d["dist"]["launched_by"] == "torchrun" and d["dist"]["allreduce_ms_per_step"] > 0
+
+
+def test_default_line_over_rccl_world_1():
+    """The whole default line with the process group forced onto `nccl` (= RCCL) at world size 1 (MMR_FORCE_DIST=1): the rank /
+    device gather, the barriers and the training leg's gradient all-reduce run as real RCCL calls on the device, as in the
+    driver's N > 1 launches; the line reports the backend and the all-reduce it timed."""
+    d = _run("--shape", "32", "32", "32", "--features", "32", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+             env={"MMR_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1"})
+    assert d["dist"]["backend"] == "nccl" and d["dist"]["world_size"] == 1 and d["dist"]["rank_devices"][0]["rank"] == 0
+    dp = d["dp_training"]
+    assert dp["backend"] == "nccl" and dp["allreduce_ms_per_step"] > 0 and dp["allreduce_bytes"] > 0
+    assert "rccl" in d["config"]["collectives"]
