@@ -146,6 +146,61 @@ def test_c2_network_zero_flow_head_is_identity(dev):
     assert torch.equal(a["y_source"], b["y_source"]) and torch.equal(a["preint_flow"], b["preint_flow"])
 
 
+def test_c2_whole_network_bf16_full_size_vs_rounding_oracle(dev):
+    """BASELINE configs[1] exactly as bench.py times it -- 160x160x192, enc/dec = 256, bf16, three folded decoder layers, 19 200-
+    workgroup launches -- as a WHOLE forward against oracle/net_torch with bf16 rounding at the same points (one full-size
+    torch-CPU forward, ~1 min on the box's 16 cores; skipped when the host cannot hold its ~40 GB of fp32 activations).
+    Gate 2e-2 of each output's scale, as at 80x80x96."""
+    import os
+    import mmr
+    from oracle import net_np, net_torch
+    avail = float("inf")
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                avail = int(ln.split()[1]) / 1e6
+        v = open("/sys/fs/cgroup/memory.max").read().strip()
+        if v.isdigit():
+            avail = min(avail, int(v) / 1e9)
+    except OSError:
+        pass
+    if avail < 70:
+        pytest.skip(f"needs ~40 GB of host memory for the full-size CPU forward, {avail:.0f} GB available")
+    enc, dec = [256] * 4, [256] * 6
+    rng = np.random.default_rng(31)
+    import scipy.ndimage as ndi
+    n = lambda v: ((v - v.min()) / (v.max() - v.min())).astype(np.float32)
+    mov = n(ndi.gaussian_filter(rng.random(C2, dtype=np.float32), 2.0))[None, ..., None]
+    fix = n(ndi.gaussian_filter(rng.random(C2, dtype=np.float32), 2.0))[None, ..., None]
+    weights = net_np.init_weights(enc, dec, seed=9, flow_std=1e-2)
+    for i in range(1, len(weights), 2):
+        weights[i] = (rng.standard_normal(weights[i].shape) * 0.05).astype(np.float32)
+    model = mmr.networks.VxmDense(C2, nb_unet_features=(enc, dec), int_steps=5, int_resolution=2, svf_resolution=2, compute_dtype="bf16")
+    model.set_weights(weights)
+    mmr.ops.PROFILE = []
+    try:
+        moved, preint = model.predict([mov, fix])
+        fams = [f for f, *_ in mmr.ops.PROFILE]
+    finally:
+        mmr.ops.PROFILE = None
+    assert sum(f.endswith("bf16_bn256_upfold") for f in fams) == 3 and sum(f.endswith("bf16_bn256_cinit") for f in fams) == 3, fams
+    pos = model.references.pos_flow.cpu().numpy()
+    del model
+    torch.cuda.empty_cache()
+    q = net_torch.bf16_round
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), len(os.sched_getaffinity(0)))))
+    ref = net_torch.vxm_dense_forward(torch.from_numpy(mov), torch.from_numpy(fix), net_torch.prepare_weights(weights, quant=q),
+                                      enc, dec, 5, 2, 2, quant=q)
+    ref = {k: v.numpy() for k, v in ref.items()}
+    assert np.abs(ref["pos_flow"]).max() > 0.5, "test flow too small to be meaningful"
+    errs = {}
+    for name, got, exp in (("preint_flow", preint, ref["preint_flow"]), ("pos_flow", pos, ref["pos_flow"]), ("moved", moved, ref["moved"])):
+        errs[name] = np.abs(got - exp).max() / np.abs(exp).max()
+    print("160x160x192 / 256-feature whole-net parity [bf16, folded]: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    for name, err in errs.items():
+        assert err < 2e-2, f"{name}: rel-to-scale err {err:.3e} >= 2e-2"
+
+
 def test_c3_training_step_same_subject_zero_head(dev):
     """C3 sizes (160^3, 64 features, 26 labels): identical label maps + zero flow head -> every present label scores 2|t.p| / (|t|+|p|) = 1, i.e.
     Dice = -(labels present)/L and the Keras loss (1 + dice) + reg * grad follows; one full step (generators, fwd, bwd, Adam) stays finite."""
