@@ -397,6 +397,8 @@ def main():
     ap.add_argument("--shape", type=int, nargs=3, default=None)
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp32", "fp32x3"])
     ap.add_argument("--bwd", default=None, choices=["bf16"], help="train: opt-in bf16-product backward (not the default)")
+    ap.add_argument("--no-render-ahead", action="store_true",
+                    help="train: render each step's image pair inside the step instead of one step ahead on the generator stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="infer: skip the training leg reported under \"secondary\"")
     args = ap.parse_args()
@@ -509,7 +511,8 @@ def main():
                                             world_size=world, rank=rank, backward_precision=args.bwd)
             src = torch.from_numpy(maps[0][None, ..., None]).to(dev)
             trg = src  # config/config.json: same_subj true -- the pair is two generator renderings of one label map
-            step = lambda: tr.train_step(src, trg)["loss"]
+            # as SynthMorphTrainer.fit runs it: the next step's two renderings queued on the generator stream behind this step
+            step = lambda: tr.train_step(src, trg, next_labels=None if args.no_render_ahead else (src, trg))["loss"]
             workload = (f"train_synthmorph.py step (BASELINE configs[2]): {shape[0]}^3, enc/dec={feats}, {L} labels, Dice + "
                         f"Grad-l2(reg 1), same_subj pairs, generators + fwd + bwd + all-reduce + Adam, 1 pair per GPU, label maps resident in HBM"
                         + (" [OPT-IN bf16-product backward]" if args.bwd else ""))

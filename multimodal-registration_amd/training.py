@@ -75,6 +75,7 @@ class SynthMorphTrainer:
         self.pg, self.world, self.rank = process_group, int(world_size), int(rank)
         self.fuse_pool_bwd = bool(fuse_pool_bwd)
         self.wstream = torch.cuda.Stream(device=model._flat.device) if (overlap_wgrad and model._flat.is_cuda) else None
+        self.gstream, self._ahead = None, None   # generator stream and the pair it rendered ahead (train_step(next_labels=))
         self.gflat = torch.zeros_like(model._flat)
         self.g, off = [], 0
         for w in model._w:
@@ -332,11 +333,44 @@ class SynthMorphTrainer:
         return grads
 
     # ------------------------------------------------------------------ one step
-    def forward_backward(self, src_labels, trg_labels, draws_1=None, draws_2=None, train=True):
-        """src/trg label maps uint8 [b,*S,1] of this rank's shard. Fills self.gflat (unreduced)."""
+    def _render(self, src_labels, trg_labels, draws_1=None, draws_2=None):
         g1 = self.gen_1.generate(src_labels, draws=draws_1, want_onehot=False)
         g2 = self.gen_2.generate(trg_labels, draws=draws_2, want_onehot=False)
-        ima_1, ima_2, lab1, lab2 = g1["image"], g2["image"], g1["labels"], g2["labels"]
+        return g1["image"], g2["image"], g1["labels"], g2["labels"]
+
+    def _render_ahead(self, labels, ready):
+        """The two generator renderings of the NEXT step's label maps on a stream of their own, queued after this step's
+        kernels: ~60 launches of small HBM- / latency-bound kernels (Perlin fields, five compose steps at half resolution,
+        blurs, min-max) that leave most of the chip idle when they run alone and fit beside the matrix-core kernels.  Keras
+        does the analogous thing on the host (``fit`` pulls the generator from a prefetch queue).  Same kernels, same host
+        draws in the same order, same values; ``ready`` = main-stream event after which the label maps may be read."""
+        src, trg = labels
+        main = torch.cuda.current_stream()
+        if self.gstream is None:
+            self.gstream = torch.cuda.Stream(device=self.model._flat.device)
+        self.gstream.wait_event(ready)
+        with torch.cuda.stream(self.gstream):
+            out = self._render(src, trg)
+            done = torch.cuda.Event()
+            done.record(self.gstream)
+        for t in (src, trg):
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(self.gstream)
+        for t in out:
+            t.record_stream(main)
+        self._ahead = (src, trg, out, done)
+
+    def forward_backward(self, src_labels, trg_labels, draws_1=None, draws_2=None, train=True):
+        """src/trg label maps uint8 [b,*S,1] of this rank's shard. Fills self.gflat (unreduced)."""
+        if self._ahead is not None and train and draws_1 is None and draws_2 is None:
+            a_src, a_trg, rendered, done = self._ahead
+            self._ahead = None
+            if a_src is not src_labels or a_trg is not trg_labels:
+                raise RuntimeError("train_step(next_labels=) announced other label maps than the ones this step was called with")
+            torch.cuda.current_stream().wait_event(done)
+            ima_1, ima_2, lab1, lab2 = rendered
+        else:
+            ima_1, ima_2, lab1, lab2 = self._render(src_labels, trg_labels, draws_1, draws_2)
         b = ima_1.shape[0]
         tape = []
         flow = self._forward(ima_1, ima_2, tape)
@@ -353,13 +387,20 @@ class SynthMorphTrainer:
         self._backward(tape, dflow)
         return out
 
-    def train_step(self, src_labels, trg_labels, draws_1=None, draws_2=None):
+    def train_step(self, src_labels, trg_labels, draws_1=None, draws_2=None, next_labels=None):
+        """next_labels=(src, trg): the label maps the NEXT ``train_step`` will be called with (the same objects); their two
+        renderings are queued on the generator stream behind this step's kernels (``_render_ahead``)."""
+        if next_labels is not None and self.model._flat.is_cuda:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())   # whatever produced next_labels is already queued
         out = self.forward_backward(src_labels, trg_labels, draws_1, draws_2, train=True)
         if self.world > 1 or parallel.forced():
             with ops._Timed("comm:allreduce_grads", (self.world,), float(self.gflat.numel() * 4)):
                 parallel.allreduce_sum_(self.gflat, self.pg)  # one 5.8 MB (64f) message
         self.opt.apply(self.model._flat, self.gflat, grad_scale=1.0 / self.world)
         self.model.invalidate_packed()
+        if next_labels is not None and self.model._flat.is_cuda:
+            self._render_ahead(next_labels, ready)
         return out
 
     def test_step(self, src_labels, trg_labels):
@@ -367,7 +408,7 @@ class SynthMorphTrainer:
 
     # ------------------------------------------------------------------ fit
     def fit(self, gen, validation_data=None, validation_steps=0, initial_epoch=0, epochs=1, steps_per_epoch=1,
-            save_name=None, save_freq=0, verbose=1, log=None, local_batches=False, local_val_batches=None):
+            save_name=None, save_freq=0, verbose=1, log=None, local_batches=False, local_val_batches=None, render_ahead=True):
         """Keras-``fit``-like loop over a ``gen_synthmorph_eb`` generator.
 
         local_batches=False: ``gen`` yields the GLOBAL batch and this rank takes rows rank*b:(rank+1)*b (what
@@ -375,7 +416,10 @@ class SynthMorphTrainer:
         local_batches=True: ``gen`` already yields only this rank's rows (``run_training`` builds it that way, so no
         rank draws, flips or masks volumes it then throws away).  The same for ``validation_data`` through
         ``local_val_batches`` (default: like ``local_batches``); a validation batch that is drawn globally but is not
-        a multiple of the world size is evaluated whole on every rank.  The logged losses are means over all ranks."""
+        a multiple of the world size is evaluated whole on every rank.  The logged losses are means over all ranks.
+        render_ahead: inside an epoch the next batch is pulled from ``gen`` one step early and its two renderings run on the
+        generator stream beside the current step (``train_step(next_labels=)``); every random stream is still consumed in the
+        same order, so the run is the same run.  Nothing is pulled across an epoch end (validation, checkpoint)."""
         if local_val_batches is None:
             local_val_batches = local_batches
         dev = self.model._flat.device
@@ -383,12 +427,17 @@ class SynthMorphTrainer:
         for epoch in range(initial_epoch, epochs):
             t0 = time.perf_counter()
             losses = []
-            for _ in range(steps_per_epoch):
+            def pull():
                 (src, trg), _void = next(gen)
                 if not local_batches:
                     sl = parallel.shard_rows(src.shape[0], self.rank, self.world)
                     src, trg = src[sl], trg[sl]
-                o = self.train_step(src, trg)
+                return src, trg
+            nxt = None
+            for i in range(steps_per_epoch):
+                cur = nxt if nxt is not None else pull()
+                nxt = pull() if (render_ahead and dev.type == "cuda" and i + 1 < steps_per_epoch) else None
+                o = self.train_step(*cur, next_labels=nxt)
                 losses.append(o["loss"])
             mean_loss = parallel.allreduce_mean_scalar(float(torch.stack(losses).mean()), dev, self.pg)
             rec = {"epoch": epoch + 1, "loss": mean_loss, "s_per_step": (time.perf_counter() - t0) / steps_per_epoch}

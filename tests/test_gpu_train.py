@@ -299,7 +299,7 @@ def test_full_training_step_gradients(dev, cdt, kinks, tol, enc, dec):
     _check_step_gradients(dev, cdt, kinks, tol, enc, dec)
 
 
-def _check_step_gradients(dev, cdt, kinks, tol, enc, dec, shape=(16, 16, 32), L=5, B=2, block=4, int_steps=3, families=()):
+def _check_step_gradients(dev, cdt, kinks, tol, enc, dec, shape=(16, 16, 32), L=5, B=2, block=4, int_steps=3, families=(), report=None):
     """Every gradient tensor of one SynthMorph step (train_synthmorph.py:296-308) against oracle/grad_torch.synthmorph_loss;
     ``families``: kernel-family suffixes that must have run (ops.PROFILE) -- the folded launches at sizes where they engage."""
     import mmr
@@ -352,12 +352,28 @@ def _check_step_gradients(dev, cdt, kinks, tol, enc, dec, shape=(16, 16, 32), L=
               if r[0] == "conv0" or (r[0] == "conv" and r[6])]
     total, rdice, rgl, rpos, rflow = G.synthmorph_loss(ima1.cpu().double(), ima2.cpu().double(), gen1["onehot"].cpu().double(),
                                                       gen2["onehot"].cpu().double(), wt, enc, dec, int_steps, 0.8, kinks=kk)
+    if report is not None:
+        rflow.retain_grad()
     total.backward()
     assert np.abs(rpos.detach().numpy()).max() > 0.3, "flow too small to exercise the warp"
     assert _rel(flow, rflow) < 1e-4 and _rel(pos, rpos) < 1e-4
     assert abs(float(dice) - float(rdice.detach())) < 1e-5 and _rel(gl, rgl) < 1e-4
     names = [p[0] for p in model.plan]
     errs = [_rel(g, w.grad) for g, w in zip(tr.g, wt)]
+    if report is not None:   # tools/grad_parity_fullsize.py: every error instead of the first failure, and how ill-conditioned the
+        # flow head's bias gradient (a plain sum of d loss / d flow over all voxels) is: sum |terms| / |sum|
+        dfl = tr._tail_backward(dpos, svf, steps).double()
+        cond = (dfl.abs().sum((0, 1, 2, 3)) / dfl.sum((0, 1, 2, 3)).abs()).cpu().numpy()
+        report.append(("flow bias cancellation sum|t| / |sum t| per channel", cond.tolist()))
+        dd = (dfl.cpu() - rflow.grad).abs()
+        big = dd > 1e-3 * rflow.grad.abs().max()   # voxels on another linear piece of the tail (floor / clamp of interpn)
+        report.append(("d loss / d flow, elementwise (rel. to max)", float(dd.max() / rflow.grad.abs().max())))
+        report.append(("   voxels off by more than 1e-3 of the max, and their share of the bias-gradient difference per channel",
+                       [int(big.sum())] + ((dd * big).sum((0, 1, 2, 3)) / (dfl.cpu().sum((0, 1, 2, 3)) - rflow.grad.sum((0, 1, 2, 3))).abs()
+                                            .clamp(min=1e-300)).tolist()))
+        for i, err in enumerate(errs):
+            report.append((f"{names[i // 2]} {'bias' if i % 2 else 'kernel'}", float(err)))
+        return
     if families:
         print(f"step gradients at {shape} [{cdt}]: worst {max(errs):.2e} ({names[int(np.argmax(errs)) // 2]})")
     for i, err in enumerate(errs):
@@ -395,6 +411,46 @@ def test_training_lowers_loss_and_is_reproducible(dev):
     l2, w2 = run()
     # float atomics in the gather adjoints make later steps drift in the last bits; the first steps must agree
     assert np.allclose(l1[:4], l2[:4], rtol=1e-4, atol=1e-5) and abs(l1[-1] - l2[-1]) < 0.05
+
+
+def test_render_ahead_is_the_same_run(dev):
+    """train_step(next_labels=): the next step's two renderings run on the generator stream behind the current step.  Same
+    host draws in the same order -> the images are bit-identical to a twin generator's and the run is the run without it."""
+    import mmr
+    from mmr import synth, training
+    shape, enc, dec, L = (16, 16, 32), [32, 32], [32, 32, 32], 4
+    rng = np.random.default_rng(18)
+    mk = lambda: torch.from_numpy(np.repeat(np.repeat(np.repeat(rng.integers(0, L, (1, 4, 4, 8)), 4, 1), 4, 2), 4, 3)
+                                  .astype(np.uint8)[..., None]).to(dev)
+    batches = [(mk(), mk()) for _ in range(5)]
+    kw = dict(in_shape=shape, in_label_list=np.arange(L), out_label_list=np.arange(L), warp_std=1, warp_res=8, blur_std=1,
+              bias_std=0.3, bias_res=8, gamma_std=0.25)
+
+    def run(ahead):
+        g1, g2 = synth.labels_to_image(**kw, id=0, seed=1), synth.labels_to_image(**kw, id=1, seed=2)
+        model = mmr.networks.VxmDense(shape, nb_unet_features=(enc, dec), int_steps=3, int_resolution=2, svf_resolution=2,
+                                      compute_dtype="fp32x3", seed=5)
+        tr = training.SynthMorphTrainer(model, g1, g2, reg_param=0.1, optimizer=training.Adam(1e-3))
+        losses, imgs = [], []
+        for i, b in enumerate(batches):
+            nxt = batches[i + 1] if ahead and i + 1 < len(batches) else None
+            losses.append(float(tr.train_step(*b, next_labels=nxt)["loss"]))
+            if nxt is not None:
+                torch.cuda.synchronize()
+                imgs.append((tr._ahead[2][0].clone(), tr._ahead[2][3].clone()))
+        return losses, imgs, tr
+    l0, _, _ = run(False)
+    l1, imgs, tr = run(True)
+    assert tr._ahead is None and tr.gstream is not None
+    t1, t2 = synth.labels_to_image(**kw, id=0, seed=1), synth.labels_to_image(**kw, id=1, seed=2)
+    for i, b in enumerate(batches):
+        a, c = t1.generate(b[0], want_onehot=False), t2.generate(b[1], want_onehot=False)
+        if i:
+            assert torch.equal(imgs[i - 1][0], a["image"]) and torch.equal(imgs[i - 1][1], c["labels"])
+    assert np.allclose(l0[:3], l1[:3], rtol=1e-4, atol=1e-5) and abs(l0[-1] - l1[-1]) < 0.05, (l0, l1)
+    tr.train_step(*batches[0], next_labels=batches[1])
+    with pytest.raises(RuntimeError, match="announced other label maps"):
+        tr.train_step(*batches[2])
 
 
 def test_optin_bf16_backward(dev):
