@@ -144,6 +144,26 @@ int mmr_conv3d_k3_fwd_init(const void* in, int Cin, const void* w_packed, const 
 int64_t mmr_conv3d_k3_dgrad_upfold_packed_bytes(int Cz, int C0, int dtype);
 int mmr_conv3d_k3_dgrad_upfold_pack(const float* w_up_keras, void* w_packed, int C0, int Cz, int dtype, void* stream);
 int64_t mmr_conv3d_k3_dgrad_upfold_ws_bytes(int B, int X2, int Y2, int Z2, int C0);
+/* Every weight image of a training step in ONE launch (after the optimizer step all of them are stale at once:
+ * train_synthmorph.py:296-308 runs forward + backward on the weights Adam just wrote).  A job names a Keras kernel
+ * w [27][rows_total][cols] fp32 (the layer's whole kernel, in place) and the input-channel rows row_off .. row_off + rows
+ * of it, so the channel slices of a concat layer need no contiguous copy:
+ *   MMR_PACK_FWD     = mmr_conv3d_k3_pack(w_slice, out, Cin = rows, Cout = cols, transpose_flip = 0)
+ *   MMR_PACK_DGRAD   = mmr_conv3d_k3_pack(w_slice, out, Cin = cols, Cout = rows, transpose_flip = 1)
+ *   MMR_PACK_UPFOLD  = mmr_conv3d_k3_upfold_pack(w_slice, out, C0 = rows, Cout = cols)
+ *   MMR_PACK_DGFOLD  = mmr_conv3d_k3_dgrad_upfold_pack(w_slice, out, C0 = rows, Cz = cols)
+ * bit for bit; out holds mmr_conv3d_k3_pack_job_bytes(kind, rows, cols, dtype) bytes.  `jobs` is a host array. */
+#define MMR_PACK_FWD 0
+#define MMR_PACK_DGRAD 1
+#define MMR_PACK_UPFOLD 2
+#define MMR_PACK_DGFOLD 3
+typedef struct MmrPackJob {
+    const float* w;
+    void* out;
+    int32_t kind, rows_total, row_off, rows, cols, reserved;
+} MmrPackJob;
+int64_t mmr_conv3d_k3_pack_job_bytes(int kind, int rows, int cols, int dtype);
+int mmr_conv3d_k3_pack_batch(const MmrPackJob* jobs, int njobs, int dtype, void* stream);
 int mmr_conv3d_k3_dgrad_upfold(const void* dz, int Cz, const void* w_packed, float* out, int B, int X2, int Y2, int Z2,
                                int C0, const float* ymask, float alpha, float* dbias, void* ws, int accumulate,
                                int dtype, void* stream);

@@ -16,6 +16,15 @@ P = c_void_p
 I = c_int
 F = c_float
 
+PACK_FWD, PACK_DGRAD, PACK_UPFOLD, PACK_DGFOLD = 0, 1, 2, 3
+
+
+class PackJob(ctypes.Structure):
+    """MmrPackJob of include/mmr.h."""
+    _fields_ = [("w", c_void_p), ("out", c_void_p), ("kind", ctypes.c_int32), ("rows_total", ctypes.c_int32),
+                ("row_off", ctypes.c_int32), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 # name -> (restype, argtypes); mirrors include/mmr.h one to one
 SIGNATURES = {
     "mmr_version": (I, []),
@@ -37,6 +46,8 @@ SIGNATURES = {
     "mmr_conv3d_k3_fwd_init": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, F, I, I, P, P]),
     "mmr_conv3d_k3_dgrad_upfold_packed_bytes": (c_int64, [I, I, I]),
     "mmr_conv3d_k3_dgrad_upfold_pack": (I, [P, P, I, I, I, P]),
+    "mmr_conv3d_k3_pack_job_bytes": (c_int64, [I, I, I, I]),
+    "mmr_conv3d_k3_pack_batch": (I, [P, I, I, P]),
     "mmr_conv3d_k3_dgrad_upfold_ws_bytes": (c_int64, [I, I, I, I, I]),
     "mmr_conv3d_k3_dgrad_upfold": (I, [P, I, P, P, I, I, I, I, I, P, F, P, P, I, I, P]),
     "mmr_conv3d_k3_cin2_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, F, I, P]),

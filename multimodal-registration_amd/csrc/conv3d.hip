@@ -1229,84 +1229,34 @@ __host__ __device__ inline int conv_cout_of_col(int col)
     return (g << 6) + ((i >> 2) << 4) + (ni << 2) + (i & 3);
 }
 
+// One 16-B chunk (item i) of a weight image.  ``ld`` / ``off``: the job reads input-channel rows off .. off + n of a Keras
+// kernel whose row count is ld ([27][ld][cols]), so a channel slice of a concat layer needs no contiguous copy.
 template <int DT>
-__global__ void pack_kernel(const float* __restrict__ w, char* __restrict__ wp, int Cin, int Cout, int BN, int ntiles,
-                            int transpose_flip, int plain_cols)
+__device__ __forceinline__ void pack_item(const float* __restrict__ w, char* __restrict__ wp, int Cin, int Cout, int BN,
+                                          int nslices, int transpose_flip, int plain_cols, int ld, int off, int64_t i)
 {
     constexpr int KC = Elt<DT>::kc;
     constexpr int EPC = (DT == MMR_DT_F32) ? 4 : 8;  // elements per 16-B chunk (fp32x3 chunks hold 8 bf16)
-    const int nslices = Cin / KC;
-    const int64_t total = (int64_t)ntiles * nslices * 27 * 8 * BN;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t r = i;
-        const int col = (int)(r % BN); r /= BN;
-        const int chunk = (int)(r % 8); r /= 8;
-        const int tap = (int)(r % 27); r /= 27;
-        const int s = (int)(r % nslices);
-        const int t = (int)(r / nslices);
-        const int co = t * BN + ((conv_uses_m16(DT, BN) && !plain_cols) ? conv_cout_of_col(col) : col);
-        char* dst = wp + i * 16;
+    int64_t r = i;
+    const int col = (int)(r % BN); r /= BN;
+    const int chunk = (int)(r % 8); r /= 8;
+    const int tap = (int)(r % 27); r /= 27;
+    const int s = (int)(r % nslices);
+    const int t = (int)(r / nslices);
+    const int co = t * BN + ((conv_uses_m16(DT, BN) && !plain_cols) ? conv_cout_of_col(col) : col);
+    char* dst = wp + i * 16;
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            const int cc = (DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) ? (chunk & 3) : chunk;
-            const int ci = s * KC + cc * EPC + e;
-            float v = 0.f;
-            if (co < Cout) {
-                if (transpose_flip) v = w[((int64_t)(26 - tap) * Cout + co) * Cin + ci];  // keras dims [27][Cout][Cin]
-                else v = w[((int64_t)tap * Cin + ci) * Cout + co];
-            }
-            if (DT == MMR_DT_F32) {
-                reinterpret_cast<float*>(dst)[e] = v;
-            } else {
-                bf16_t hb = f32_to_bf16(v);
-                if ((DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) && chunk >= 4) hb = f32_to_bf16(v - bf16_to_f32(hb));  // lo part
-                reinterpret_cast<bf16_t*>(dst)[e] = hb;
-            }
+    for (int e = 0; e < EPC; ++e) {
+        const int cc = (DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) ? (chunk & 3) : chunk;
+        const int ci = s * KC + cc * EPC + e;
+        float v = 0.f;
+        if (co < Cout) {
+            if (transpose_flip) v = w[((int64_t)(26 - tap) * ld + off + co) * Cin + ci];  // keras dims [27][ld >= Cout][Cin]
+            else v = w[((int64_t)tap * ld + off + ci) * Cout + co];
         }
-    }
-}
-
-// Folded-upsampling weight image (CV_UPFOLD): [class 8][n-tile][slice][tap 8][chunk 8][BN][16 B]; tap bit s per axis of
-// parity class bit p sums the original taps { p=0,s=0: {0} | p=0,s=1: {1,2} | p=1,s=0: {0,1} | p=1,s=1: {2} } (fp32 sums,
-// then the same bf16 / hi-lo encoding and column permutation as pack_kernel).  w = Keras [27][C0][Cout] of the upsampled
-// channels only.
-template <int DT>
-__global__ void pack_upfold_kernel(const float* __restrict__ w, char* __restrict__ wp, int Cin, int Cout, int BN, int ntiles)
-{
-    constexpr int KC = Elt<DT>::kc;
-    constexpr int EPC = 8;
-    const int nslices = Cin / KC;
-    const int64_t total = (int64_t)8 * ntiles * nslices * 8 * 8 * BN;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t r = i;
-        const int col = (int)(r % BN); r /= BN;
-        const int chunk = (int)(r % 8); r /= 8;
-        const int tap = (int)(r % 8); r /= 8;
-        const int s = (int)(r % nslices); r /= nslices;
-        const int t = (int)(r % ntiles);
-        const int cls = (int)(r / ntiles);
-        const int co = t * BN + conv_cout_of_col(col);
-        int lo3[3], n3[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const int pb = (cls >> (2 - a)) & 1, sb = (tap >> (2 - a)) & 1;
-            lo3[a] = pb == 0 ? (sb == 0 ? 0 : 1) : (sb == 0 ? 0 : 2);
-            n3[a] = (pb == 0) == (sb == 0) ? 1 : 2;        // (0,0) and (1,1): one tap; (0,1) and (1,0): two
-        }
-        char* dst = wp + i * 16;
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            const int cc = (DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) ? (chunk & 3) : chunk;
-            const int ci = s * KC + cc * EPC + e;
-            float v = 0.f;
-            if (co < Cout) {
-                for (int a = 0; a < n3[0]; ++a)
-                    for (int bb = 0; bb < n3[1]; ++bb)
-                        for (int c = 0; c < n3[2]; ++c) {
-                            const int tp = ((lo3[0] + a) * 3 + (lo3[1] + bb)) * 3 + (lo3[2] + c);
-                            v += w[((int64_t)tp * Cin + ci) * Cout + co];
-                        }
-            }
+        if (DT == MMR_DT_F32) {
+            reinterpret_cast<float*>(dst)[e] = v;
+        } else {
             bf16_t hb = f32_to_bf16(v);
             if ((DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) && chunk >= 4) hb = f32_to_bf16(v - bf16_to_f32(hb));  // lo part
             reinterpret_cast<bf16_t*>(dst)[e] = hb;
@@ -1314,48 +1264,141 @@ __global__ void pack_upfold_kernel(const float* __restrict__ w, char* __restrict
     }
 }
 
+template <int DT>
+__global__ void pack_kernel(const float* __restrict__ w, char* __restrict__ wp, int Cin, int Cout, int BN, int ntiles,
+                            int transpose_flip, int plain_cols)
+{
+    const int nslices = Cin / Elt<DT>::kc;
+    const int64_t total = (int64_t)ntiles * nslices * 27 * 8 * BN;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        pack_item<DT>(w, wp, Cin, Cout, BN, nslices, transpose_flip, plain_cols, transpose_flip ? Cout : Cin, 0, i);
+}
+
+// Folded-upsampling weight image (CV_UPFOLD): [class 8][n-tile][slice][tap 8][chunk 8][BN][16 B]; tap bit s per axis of
+// parity class bit p sums the original taps { p=0,s=0: {0} | p=0,s=1: {1,2} | p=1,s=0: {0,1} | p=1,s=1: {2} } (fp32 sums,
+// then the same bf16 / hi-lo encoding and column permutation as pack_kernel).  w = Keras [27][C0][Cout] of the upsampled
+// channels only.
+template <int DT>
+__device__ __forceinline__ void pack_upfold_item(const float* __restrict__ w, char* __restrict__ wp, int Cin, int Cout, int BN,
+                                                 int ntiles, int nslices, int ld, int off, int64_t i)
+{
+    constexpr int KC = Elt<DT>::kc;
+    constexpr int EPC = 8;
+    int64_t r = i;
+    const int col = (int)(r % BN); r /= BN;
+    const int chunk = (int)(r % 8); r /= 8;
+    const int tap = (int)(r % 8); r /= 8;
+    const int s = (int)(r % nslices); r /= nslices;
+    const int t = (int)(r % ntiles);
+    const int cls = (int)(r / ntiles);
+    const int co = t * BN + conv_cout_of_col(col);
+    int lo3[3], n3[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int pb = (cls >> (2 - a)) & 1, sb = (tap >> (2 - a)) & 1;
+        lo3[a] = pb == 0 ? (sb == 0 ? 0 : 1) : (sb == 0 ? 0 : 2);
+        n3[a] = (pb == 0) == (sb == 0) ? 1 : 2;        // (0,0) and (1,1): one tap; (0,1) and (1,0): two
+    }
+    char* dst = wp + i * 16;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const int cc = (DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) ? (chunk & 3) : chunk;
+        const int ci = s * KC + cc * EPC + e;
+        float v = 0.f;
+        if (co < Cout) {
+            for (int a = 0; a < n3[0]; ++a)
+                for (int bb = 0; bb < n3[1]; ++bb)
+                    for (int c = 0; c < n3[2]; ++c) {
+                        const int tp = ((lo3[0] + a) * 3 + (lo3[1] + bb)) * 3 + (lo3[2] + c);
+                        v += w[((int64_t)tp * ld + off + ci) * Cout + co];
+                    }
+        }
+        bf16_t hb = f32_to_bf16(v);
+        if ((DT == MMR_DT_F32X3 || DT == MMR_DT_F32X1) && chunk >= 4) hb = f32_to_bf16(v - bf16_to_f32(hb));  // lo part
+        reinterpret_cast<bf16_t*>(dst)[e] = hb;
+    }
+}
+
+template <int DT>
+__global__ void pack_upfold_kernel(const float* __restrict__ w, char* __restrict__ wp, int Cin, int Cout, int BN, int ntiles)
+{
+    const int nslices = Cin / Elt<DT>::kc;
+    const int64_t total = (int64_t)8 * ntiles * nslices * 8 * 8 * BN;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        pack_upfold_item<DT>(w, wp, Cin, Cout, BN, ntiles, nslices, Cin, 0, i);
+}
+
 // Weight image of the dgrad fold (CV_DGFOLD): [n-tile over the C0 gradient channels][class 8][dz-channel slice][tap 8][chunk]
 // [BN][16 B], value(k = dz channel co, n = up channel c) = sum of the forward weights W[t][c][co] over the taps t that
 // (class, tap bit) covers (same table as pack_upfold_kernel; no tap flip: the halo offsets 2 - p - s carry the transpose).
 // w = Keras [27][C0][Cz] of the upsampled input channels (Cz = the layer's output channels = dz channels).
 template <int DT>
-__global__ void pack_dgfold_kernel(const float* __restrict__ w, char* __restrict__ wp, int C0, int Cz, int BN, int ntiles)
+__device__ __forceinline__ void pack_dgfold_item(const float* __restrict__ w, char* __restrict__ wp, int C0, int Cz, int BN,
+                                                 int ncs, int ld, int off, int64_t i)
 {
     constexpr int KC = Elt<DT>::kc;
-    const int ncs = Cz / KC;
-    const int64_t total = (int64_t)ntiles * 8 * ncs * 8 * 8 * BN;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t r = i;
-        const int col = (int)(r % BN); r /= BN;
-        const int chunk = (int)(r % 8); r /= 8;
-        const int tap = (int)(r % 8); r /= 8;
-        const int cs = (int)(r % ncs); r /= ncs;
-        const int cls = (int)(r % 8);
-        const int t = (int)(r / 8);
-        const int n = t * BN + (conv_uses_m16(DT, BN) ? conv_cout_of_col(col) : col);   // up channel c
-        int lo3[3], n3[3];
+    int64_t r = i;
+    const int col = (int)(r % BN); r /= BN;
+    const int chunk = (int)(r % 8); r /= 8;
+    const int tap = (int)(r % 8); r /= 8;
+    const int cs = (int)(r % ncs); r /= ncs;
+    const int cls = (int)(r % 8);
+    const int t = (int)(r / 8);
+    const int n = t * BN + (conv_uses_m16(DT, BN) ? conv_cout_of_col(col) : col);   // up channel c
+    int lo3[3], n3[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const int pb = (cls >> (2 - a)) & 1, sb = (tap >> (2 - a)) & 1;
-            lo3[a] = pb == 0 ? (sb == 0 ? 0 : 1) : (sb == 0 ? 0 : 2);
-            n3[a] = (pb == 0) == (sb == 0) ? 1 : 2;
+    for (int a = 0; a < 3; ++a) {
+        const int pb = (cls >> (2 - a)) & 1, sb = (tap >> (2 - a)) & 1;
+        lo3[a] = pb == 0 ? (sb == 0 ? 0 : 1) : (sb == 0 ? 0 : 2);
+        n3[a] = (pb == 0) == (sb == 0) ? 1 : 2;
+    }
+    char* dst = wp + i * 16;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = cs * KC + (chunk & 3) * 8 + e;                                 // dz channel co
+        float v = 0.f;
+        if (n < C0) {
+            for (int a = 0; a < n3[0]; ++a)
+                for (int bb = 0; bb < n3[1]; ++bb)
+                    for (int c = 0; c < n3[2]; ++c) {
+                        const int tp = ((lo3[0] + a) * 3 + (lo3[1] + bb)) * 3 + (lo3[2] + c);
+                        v += w[((int64_t)tp * ld + off + n) * Cz + k];
+                    }
         }
-        char* dst = wp + i * 16;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = cs * KC + (chunk & 3) * 8 + e;                                 // dz channel co
-            float v = 0.f;
-            if (n < C0) {
-                for (int a = 0; a < n3[0]; ++a)
-                    for (int bb = 0; bb < n3[1]; ++bb)
-                        for (int c = 0; c < n3[2]; ++c) {
-                            const int tp = ((lo3[0] + a) * 3 + (lo3[1] + bb)) * 3 + (lo3[2] + c);
-                            v += w[((int64_t)tp * C0 + n) * Cz + k];
-                        }
-            }
-            bf16_t hb = f32_to_bf16(v);
-            if (chunk >= 4) hb = f32_to_bf16(v - bf16_to_f32(hb));  // lo part
-            reinterpret_cast<bf16_t*>(dst)[e] = hb;
+        bf16_t hb = f32_to_bf16(v);
+        if (chunk >= 4) hb = f32_to_bf16(v - bf16_to_f32(hb));  // lo part
+        reinterpret_cast<bf16_t*>(dst)[e] = hb;
+    }
+}
+
+template <int DT>
+__global__ void pack_dgfold_kernel(const float* __restrict__ w, char* __restrict__ wp, int C0, int Cz, int BN, int ntiles)
+{
+    const int ncs = Cz / Elt<DT>::kc;
+    const int64_t total = (int64_t)ntiles * 8 * ncs * 8 * 8 * BN;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        pack_dgfold_item<DT>(w, wp, C0, Cz, BN, ncs, C0, 0, i);
+}
+
+// All weight images of a training step in ONE launch (mmr_conv3d_k3_pack_batch): item i of the launch belongs to the job
+// whose [first, first + items) holds it; the job table travels as a kernel argument.
+struct PackJobDev { const float* w; char* out; int64_t first; int kind, ld, off, a, b, BN, ntiles, nsl; };
+constexpr int PACK_BATCH_MAX = 32;
+struct PackBatch { int n; int64_t total; PackJobDev j[PACK_BATCH_MAX]; };
+
+template <int DT>
+__global__ void __launch_bounds__(256) pack_batch_kernel(const PackBatch pb)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pb.total; i += (int64_t)gridDim.x * blockDim.x) {
+        int jj = 0;
+        while (jj + 1 < pb.n && i >= pb.j[jj + 1].first) ++jj;
+        const PackJobDev& q = pb.j[jj];
+        const int64_t li = i - q.first;
+        if (q.kind == MMR_PACK_FWD) pack_item<DT>(q.w, q.out, q.a, q.b, q.BN, q.nsl, 0, 0, q.ld, q.off, li);
+        else if (q.kind == MMR_PACK_DGRAD) pack_item<DT>(q.w, q.out, q.b, q.a, q.BN, q.nsl, 1, 0, q.ld, q.off, li);
+        else if constexpr (DT != MMR_DT_F32) {
+            if (q.kind == MMR_PACK_UPFOLD) pack_upfold_item<DT>(q.w, q.out, q.a, q.b, q.BN, q.ntiles, q.nsl, q.ld, q.off, li);
+            else pack_dgfold_item<DT>(q.w, q.out, q.a, q.b, q.BN, q.nsl, q.ld, q.off, li);
         }
     }
 }
@@ -2565,6 +2608,60 @@ extern "C" int mmr_conv3d_k3_dgrad_upfold_pack(const float* w_up_keras, void* w_
     hipLaunchKernelGGL(pack_dgfold_kernel<MMR_DT_F32X3>, dim3(stream_grid(bytes / 16, 256)), dim3(256), 0, as_stream(stream),
                        w_up_keras, (char*)w_packed, C0, Cz, BN, C0 / BN);
     return check_launch();
+}
+
+// Bytes of the weight image job (kind, rows, cols) produces (the *_packed_bytes of the matching single-image entry point).
+extern "C" int64_t mmr_conv3d_k3_pack_job_bytes(int kind, int rows, int cols, int dtype)
+{
+    switch (kind) {
+    case MMR_PACK_FWD: return mmr_conv3d_k3_packed_bytes(rows, cols, dtype);
+    case MMR_PACK_DGRAD: return mmr_conv3d_k3_packed_bytes(cols, rows, dtype);
+    case MMR_PACK_UPFOLD: return mmr_conv3d_k3_upfold_packed_bytes(rows, cols, dtype);
+    case MMR_PACK_DGFOLD: return mmr_conv3d_k3_dgrad_upfold_packed_bytes(cols, rows, dtype);
+    }
+    return MMR_EINVAL;
+}
+
+template <int DT>
+static int pack_batch_launch(const MmrPackJob* jobs, int njobs, int dtype, hipStream_t st)
+{
+    for (int j0 = 0; j0 < njobs; j0 += PACK_BATCH_MAX) {
+        PackBatch pb;
+        pb.n = njobs - j0 < PACK_BATCH_MAX ? njobs - j0 : PACK_BATCH_MAX;
+        pb.total = 0;
+        for (int k = 0; k < pb.n; ++k) {
+            const MmrPackJob& q = jobs[j0 + k];
+            PackJobDev& d = pb.j[k];
+            const int64_t bytes = mmr_conv3d_k3_pack_job_bytes(q.kind, q.rows, q.cols, dtype);
+            d.w = q.w; d.out = (char*)q.out; d.first = pb.total; d.kind = q.kind; d.ld = q.rows_total; d.off = q.row_off;
+            d.a = q.rows; d.b = q.cols;
+            const int ncols = (q.kind == MMR_PACK_FWD || q.kind == MMR_PACK_UPFOLD) ? q.cols : q.rows;   // the image's N axis
+            const int nk = (q.kind == MMR_PACK_FWD || q.kind == MMR_PACK_UPFOLD) ? q.rows : q.cols;      // its contraction axis
+            d.BN = conv_bn(ncols);
+            d.ntiles = (ncols + d.BN - 1) / d.BN;
+            d.nsl = nk / Elt<DT>::kc;
+            pb.total += bytes / 16;
+        }
+        hipLaunchKernelGGL(pack_batch_kernel<DT>, dim3(stream_grid(pb.total, 256)), dim3(256), 0, st, pb);
+    }
+    return check_launch();
+}
+
+// Several weight images in one launch: what mmr_conv3d_k3_pack (kinds FWD, DGRAD = transpose_flip), mmr_conv3d_k3_upfold_pack
+// and mmr_conv3d_k3_dgrad_upfold_pack write one at a time, bit for bit, reading channel slices of the Keras kernels in place.
+// `jobs` is a HOST array (copied into the launch).  All images of a call share `dtype`.
+extern "C" int mmr_conv3d_k3_pack_batch(const MmrPackJob* jobs, int njobs, int dtype, void* stream)
+{
+    if (!jobs || njobs < 1 || dtype < 0 || dtype > MMR_DT_F32X1) return MMR_EINVAL;
+    for (int k = 0; k < njobs; ++k) {
+        const MmrPackJob& q = jobs[k];
+        if (!q.w || !q.out || q.rows < 1 || q.cols < 1 || q.row_off < 0 || q.row_off + q.rows > q.rows_total) return MMR_EINVAL;
+        const int64_t bytes = mmr_conv3d_k3_pack_job_bytes(q.kind, q.rows, q.cols, dtype);
+        if (bytes < 0) return (int)bytes;
+    }
+    if (dtype == MMR_DT_BF16) return pack_batch_launch<MMR_DT_BF16>(jobs, njobs, dtype, as_stream(stream));
+    if (dtype == MMR_DT_F32) return pack_batch_launch<MMR_DT_F32>(jobs, njobs, dtype, as_stream(stream));
+    return pack_batch_launch<MMR_DT_F32X3>(jobs, njobs, dtype, as_stream(stream));
 }
 
 extern "C" int64_t mmr_conv3d_k3_dgrad_upfold_ws_bytes(int B, int X2, int Y2, int Z2, int C0)

@@ -153,6 +153,7 @@ class VxmDense:
         # low-resolution grid, 8/27 of its multiply-adds) wherever ops.upfold_supported says both launches fill the chip
         self.fold_upsampling = bool(fold_upsampling)
         self._packed_fold = {}
+        self._book = ops.PackBook()   # every weight image of this model (forward here, the backward's in training.py)
         # input_model (train_synthmorph.py:294-296): its two outputs are source / target and its inputs (the label maps)
         # become the model's inputs.  Anything that is not the generator pair is refused rather than ignored.
         if input_model is not None and not isinstance(input_model, InputModel):
@@ -258,17 +259,24 @@ class VxmDense:
             idx, cout = self._logical_index(li)
             self._w[2 * li][..., :cout].index_copy_(3, idx, k)
             self._w[2 * li + 1][:cout].copy_(b)
-        self._packed = None
-        self._packed_fold = {}
+        self.invalidate_packed()
 
     def invalidate_packed(self):
         """Call after the flat parameter buffer was updated in place (optimizer step)."""
         self._packed = None
         self._packed_fold = {}
+        self._book.invalidate()
+
+    def repack(self):
+        """After an optimizer step: every weight image made so far (forward, folded, the trainer's transposed ones)
+        rewritten in place in one launch; the lists handed out by ``_pack`` stay valid."""
+        self._book.invalidate()
+        self._book.refresh()
 
     def _pack(self):
         if self._packed is None:
-            self._packed = [None] + [ops.pack_conv_weights(self._w[2 * i].contiguous(), self.dtype, x3=self.x3)
+            mode = ops.conv_mode(self.dtype, self.x3)
+            self._packed = [None] + [self._book.get(("fwd", i), ops.PACK_FWD, self._w[2 * i], 0, self._w[2 * i].shape[3], mode)
                                      for i in range(1, len(self.plan))]
         return self._packed
 
@@ -378,7 +386,9 @@ class VxmDense:
         if (self.fold_upsampling and kw.get("up0") and in1 is not None
                 and ops.upfold_supported(x.shape[-1], in1.shape[-1], cout, self.dtype, self.x3, *in1.shape[:4])):
             if li not in self._packed_fold:
-                self._packed_fold[li] = ops.pack_upfold_weights(self._w[2 * li].contiguous(), x.shape[-1], self.dtype, x3=self.x3)
+                wk, C0, mode = self._w[2 * li], int(x.shape[-1]), ops.conv_mode(self.dtype, self.x3)
+                self._packed_fold[li] = (self._book.get(("upfold", li, C0), ops.PACK_UPFOLD, wk, 0, C0, mode),
+                                         self._book.get(("skip", li, C0), ops.PACK_FWD, wk, C0, int(wk.shape[3]) - C0, mode))
             w_up, w_skip = self._packed_fold[li]
             return ops.conv3d_k3_upfold(x, in1, w_up, w_skip, self._w[2 * li + 1], cout, x3=self.x3,
                                         **{k: v for k, v in kw.items() if k not in ("in1", "up0")})

@@ -9,6 +9,7 @@ import torch
 from . import _lib, semantics
 
 F32, BF16, F32X3, F32X1 = 0, 1, 2, 3
+PACK_FWD, PACK_DGRAD, PACK_UPFOLD, PACK_DGFOLD = _lib.PACK_FWD, _lib.PACK_DGRAD, _lib.PACK_UPFOLD, _lib.PACK_DGFOLD
 LINEAR, NEAREST = 0, 1
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -211,6 +212,53 @@ def upfold_supported(C0, C1, cout, dtype, x3, B, X, Y, Z):
     tx = 4 if bn == 256 else 8
     tiles = lambda x, y, z: B * (-(-x // tx)) * (-(-y // 8)) * (-(-z // 8)) * (cout // bn)
     return tiles(X // 2, Y // 2, Z // 2) * 8 >= 256 and tiles(X, Y, Z) >= 256
+
+
+class PackBook:
+    """The weight images of one model as persistent buffers.  ``get`` returns the image of a job (packing it on first use
+    or when stale); after an optimizer step ``refresh`` rewrites EVERY image recorded so far in one launch
+    (mmr_conv3d_k3_pack_batch) instead of one launch -- and, for the channel slices of the concat layers, one contiguous
+    copy -- per image: 25 launches of a C3 training step become one.  Jobs read the layer's whole Keras kernel in place:
+    rows row_off .. row_off + rows of its input-channel axis."""
+
+    def __init__(self):
+        self._e = {}
+
+    def get(self, key, kind, w_keras, row_off, rows, mode):
+        e = self._e.get(key)
+        if e is None or e["w"].data_ptr() != w_keras.data_ptr() or e["job"] != (kind, int(row_off), int(rows), mode):
+            _chk(w_keras, torch.float32, "w_keras")
+            rows_total, cols = int(w_keras.shape[3]), int(w_keras.shape[4])
+            nbytes = _lib.load().mmr_conv3d_k3_pack_job_bytes(kind, int(rows), cols, mode)
+            if nbytes < 0:
+                raise _lib.MmrError(f"cannot pack weights (kind {kind}, rows {rows} of {rows_total}, cols {cols}, mode {mode})")
+            e = self._e[key] = dict(w=w_keras, job=(kind, int(row_off), int(rows), mode), dims=(rows_total, cols), valid=False,
+                                    out=torch.empty(nbytes, dtype=torch.uint8, device=w_keras.device))
+        if not e["valid"]:
+            self._run([e])
+        return e["out"]
+
+    def invalidate(self):
+        for e in self._e.values():
+            e["valid"] = False
+
+    def refresh(self):
+        """Rewrite every stale image: one launch per arithmetic mode in the book (one, unless the backward is opt-in bf16)."""
+        stale = [e for e in self._e.values() if not e["valid"]]
+        for mode in sorted({e["job"][3] for e in stale}):
+            self._run([e for e in stale if e["job"][3] == mode])
+
+    @staticmethod
+    def _run(entries):
+        jobs = (_lib.PackJob * len(entries))()
+        for j, e in zip(jobs, entries):
+            kind, off, rows, _ = e["job"]
+            j.w, j.out, j.kind, j.rows_total, j.row_off, j.rows, j.cols = (e["w"].data_ptr(), e["out"].data_ptr(), kind,
+                                                                              e["dims"][0], off, rows, e["dims"][1])
+        rc = _lib.load().mmr_conv3d_k3_pack_batch(jobs, len(entries), entries[0]["job"][3], _stream())
+        _lib.check(rc, "mmr_conv3d_k3_pack_batch")
+        for e in entries:
+            e["valid"] = True
 
 
 def pack_upfold_weights(w_keras, C0, dtype, x3=False):

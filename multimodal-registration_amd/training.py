@@ -42,7 +42,8 @@ class SynthMorphTrainer:
     """model: fp32 VxmDense; gen_1/gen_2: synth.LabelsToImage (sharing the label list)."""
 
     def __init__(self, model, gen_1=None, gen_2=None, reg_param=1.0, optimizer=None, zero_pad_dice=False,
-                 process_group=None, world_size=1, rank=0, backward_precision=None, overlap_wgrad=False, fuse_pool_bwd=True):
+                 process_group=None, world_size=1, rank=0, backward_precision=None, overlap_wgrad=False, fuse_pool_bwd=True,
+                 batch_repack=True):
         """gen_1 / gen_2 default to the generator pair of ``model.input_model`` (a model built the reference's way,
         ``VxmDense(..., input_model=InputModel(gen_1, gen_2))``, train_synthmorph.py:294-296).
         backward_precision: None = same arithmetic as the forward (fp32 / fp32x3); 'bf16' = dgrad and wgrad
@@ -54,7 +55,9 @@ class SynthMorphTrainer:
         the partial last rounds of launches fill; off by default so that per-kernel timings stay those of a kernel alone on
         the chip.  Same kernels, same results.
         fuse_pool_bwd: the MaxPooling3D backward of a skip tensor runs in the epilogue of the decoder conv's data gradient
-        (ops.conv3d_k3_dgrad_masked(pool_grad=)) where that kernel supports it; False keeps the separate pooling-backward pass."""
+        (ops.conv3d_k3_dgrad_masked(pool_grad=)) where that kernel supports it; False keeps the separate pooling-backward pass.
+        batch_repack: after the optimizer step every weight image of the model (forward, folded, transposed) is rewritten by
+        one launch (VxmDense.repack); False marks them stale and each is packed by its own launch where the next step needs it."""
         if model.dtype != torch.float32:
             raise NotImplementedError("training runs the fp32 path (the reference trains in fp32)")
         im = getattr(model, "input_model", None)
@@ -74,6 +77,7 @@ class SynthMorphTrainer:
         self.bwd_x3 = "hi" if backward_precision == "bf16" else model.x3
         self.pg, self.world, self.rank = process_group, int(world_size), int(rank)
         self.fuse_pool_bwd = bool(fuse_pool_bwd)
+        self.batch_repack = bool(batch_repack)
         self.wstream = torch.cuda.Stream(device=model._flat.device) if (overlap_wgrad and model._flat.is_cuda) else None
         self.gstream, self._ahead = None, None   # generator stream and the pair it rendered ahead (train_step(next_labels=))
         self.gflat = torch.zeros_like(model._flat)
@@ -84,6 +88,7 @@ class SynthMorphTrainer:
             off += n
         if self.world > 1 or parallel.forced():
             parallel.broadcast_(model._flat, 0, self.pg)
+            model.invalidate_packed()
 
     # ------------------------------------------------------------------ forward with tape
     def _forward(self, src, trg, tape):
@@ -160,6 +165,7 @@ class SynthMorphTrainer:
     # ------------------------------------------------------------------ backward over the tape
     def _backward(self, tape, dflow):
         m = self.model
+        bmode = ops.conv_mode(torch.float32, self.bwd_x3)
         grads = {}
         first = tape[-1]
         grads[id(first[5])] = dflow
@@ -242,7 +248,7 @@ class SynthMorphTrainer:
                     # comes straight out at LOW resolution from the 8-class x 8-tap fold (no full-resolution intermediate,
                     # no pooling pass), already multiplied by LeakyReLU'(x) with x's bias gradient
                     wk = m._w[2 * li]
-                    wt_skip = ops.pack_conv_weights(wk[:, :, :, C0:, :].contiguous(), torch.float32, transpose_flip=True, x3=self.bwd_x3)
+                    wt_skip = m._book.get(("dgrad_skip", li, C0), ops.PACK_DGRAD, wk, C0, C1, bmode)
                     if want_mask(in1):
                         db, acc = bias_of(in1)
                         premasked.add(id(in1))
@@ -253,7 +259,7 @@ class SynthMorphTrainer:
                             grads[id(in1)] = ops.conv3d_k3_dgrad_masked(dz, wt_skip, C1, in1, db, accumulate=acc, x3=self.bwd_x3)
                     else:
                         grads[id(in1)] = ops.conv3d_k3(dz, wt_skip, None, C1, leaky=False, out_f32=True, x3=self.bwd_x3)
-                    wt_up = ops.pack_dgrad_upfold_weights(wk, C0, x3=self.bwd_x3)
+                    wt_up = m._book.get(("dgfold", li, C0), ops.PACK_DGFOLD, wk, 0, C0, bmode)
                     if want_mask(x):
                         db, acc = bias_of(x)
                         grads[id(x)] = ops.conv3d_k3_dgrad_upfold(dz, wt_up, C0, ymask=x, dbias=db, accumulate=acc, x3=self.bwd_x3)
@@ -263,7 +269,7 @@ class SynthMorphTrainer:
                     del dz, dy
                     continue
                 else:
-                    wt = ops.pack_conv_weights(m._w[2 * li], torch.float32, transpose_flip=True, x3=self.bwd_x3)
+                    wt = m._book.get(("dgrad", li), ops.PACK_DGRAD, m._w[2 * li], 0, C0 + C1, bmode)
                     if plain and want_mask(x):
                         db, acc = bias_of(x)
                         dcat = ops.conv3d_k3_dgrad_masked(dz, wt, C0, x, db, accumulate=acc, x3=self.bwd_x3)
@@ -398,7 +404,10 @@ class SynthMorphTrainer:
             with ops._Timed("comm:allreduce_grads", (self.world,), float(self.gflat.numel() * 4)):
                 parallel.allreduce_sum_(self.gflat, self.pg)  # one 5.8 MB (64f) message
         self.opt.apply(self.model._flat, self.gflat, grad_scale=1.0 / self.world)
-        self.model.invalidate_packed()
+        if self.batch_repack:
+            self.model.repack()   # all weight images of the next step in one launch
+        else:
+            self.model.invalidate_packed()
         if next_labels is not None and self.model._flat.is_cuda:
             self._render_ahead(next_labels, ready)
         return out

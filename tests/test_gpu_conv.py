@@ -316,3 +316,45 @@ def test_half_partial_of_folded_pair_saturates_at_the_half_range(dev):
     assert np.abs(out - (clamped + ref_skip)).max() < 1e-5 * 65504      # fp32 accumulation on a 65504 base (ulp 2^-8)
     exact = ops.conv3d_k3_upfold(t0, t1, w_up, w_skip, None, Cout, leaky=False, out_f32=True, half_partial=False).cpu().numpy()
     assert np.abs(exact - (ref_up + ref_skip)).max() < 1e-5 * np.abs(ref_up).max()
+
+
+def test_pack_batch_equals_the_single_image_packs(dev):
+    """mmr_conv3d_k3_pack_batch (ops.PackBook): every kind of weight image, whole kernels and channel slices read in place,
+    bit for bit what the one-image entry points write from contiguous copies -- first use (one job per launch) and the
+    refresh after the weights changed (all jobs in one launch)."""
+    import mmr
+    from mmr import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    w = (torch.randn((3, 3, 3, 128, 64), generator=g) * 0.1).to(dev)
+    C0 = 64
+    for dtype, x3 in ((torch.bfloat16, False), (torch.float32, True), (torch.float32, "hi"), (torch.float32, False)):
+        mode = ops.conv_mode(dtype, x3)
+        book = ops.PackBook()
+
+        def images():
+            got = {"fwd": book.get("fwd", ops.PACK_FWD, w, 0, 128, mode), "skip": book.get("skip", ops.PACK_FWD, w, C0, 64, mode),
+                   "dg": book.get("dg", ops.PACK_DGRAD, w, 0, 128, mode), "dgs": book.get("dgs", ops.PACK_DGRAD, w, C0, 64, mode)}
+            ws = w[:, :, :, C0:, :].contiguous()
+            ref = {"fwd": ops.pack_conv_weights(w, dtype, x3=x3), "skip": ops.pack_conv_weights(ws, dtype, x3=x3),
+                   "dg": ops.pack_conv_weights(w, dtype, transpose_flip=True, x3=x3),
+                   "dgs": ops.pack_conv_weights(ws, dtype, transpose_flip=True, x3=x3)}
+            if mode in (ops.BF16, ops.F32X3):
+                got["up"] = book.get("up", ops.PACK_UPFOLD, w, 0, C0, mode)
+                ref["up"] = ops.pack_upfold_weights(w, C0, dtype, x3=x3)[0]
+            if mode in (ops.F32X3, ops.F32X1):
+                got["dgf"] = book.get("dgf", ops.PACK_DGFOLD, w, 0, C0, mode)
+                ref["dgf"] = ops.pack_dgrad_upfold_weights(w, C0, x3=x3)
+            return got, ref
+        got, ref = images()
+        for k in ref:
+            assert got[k].numel() == ref[k].numel() and torch.equal(got[k], ref[k]), (dtype, x3, k)
+        ptrs = {k: v.data_ptr() for k, v in got.items()}
+        w.mul_(-0.7).add_(0.01)
+        book.invalidate()
+        book.refresh()                                  # one launch for every image recorded
+        assert all(e["valid"] for e in book._e.values())
+        got, ref = images()
+        for k in ref:
+            assert got[k].data_ptr() == ptrs[k] and torch.equal(got[k], ref[k]), (dtype, x3, k, "refresh")
+    with pytest.raises(mmr._lib.MmrError):
+        ops.PackBook().get("bad", ops.PACK_UPFOLD, w, 0, C0, ops.F32)   # no folded image in exact fp32

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """C3 training step A/B of one trainer option, alternated in one process, with a gradient comparison:
-  python tools/time_overlap.py [steps] [option]     option: overlap_wgrad (default) | fuse_pool_bwd"""
+  python tools/time_overlap.py [steps] [option]     option: overlap_wgrad (default) | fuse_pool_bwd | batch_repack"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
