@@ -1478,9 +1478,18 @@ wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int 
         const int ci = (int)((i / Cout) % Cin);
         const int tap = (int)(i / ((int64_t)Cout * Cin));
         const int slice = ci >> 5, cob = co >> 6;
-        float s = 0.f;
-        for (int k = 0; k < nblk; ++k)
-            s += slab[((((size_t)k * nslices + slice) * ncob + cob) * 27 + tap) * 2048 + (ci & 31) * 64 + (co & 63)];
+        // eight slabs in flight per thread (the one-accumulator form ran as nblk dependent round trips: 23 us per layer at
+        // 160^3); fixed association -> still bitwise reproducible
+        const float* base = slab + (((size_t)slice * ncob + cob) * 27 + tap) * 2048 + (ci & 31) * 64 + (co & 63);
+        const size_t kstride = (size_t)nslices * ncob * 27 * 2048;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 7 < nblk; k += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += base[(size_t)(k + u) * kstride];
+        }
+        for (; k < nblk; ++k) a[0] += base[(size_t)k * kstride];
+        const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
         float* o = dw + ((int64_t)tap * cin_total + ci_off + ci) * Cout + co;
         if (accumulate) *o += s; else *o = s;
     }
@@ -1500,7 +1509,7 @@ wgrad_fold_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
         const int tap = (int)(i / ((int64_t)Cout * C0));
         const int slice = ci >> 5, cob = co >> 6;
         const int t3[3] = {tap / 9, (tap / 3) % 3, tap % 3};
-        float s = 0.f;
+        float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // one accumulator per (class, tap bit) pair: 8 loads in flight
         for (int k = 0; k < nblk; ++k) {
             const float* base = slab + ((((size_t)k * nslices + slice) * ncob + cob) * 8) * (27 * 2048) + (ci & 31) * 64 + (co & 63);
 #pragma unroll
@@ -1515,9 +1524,10 @@ wgrad_fold_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                     cls = (cls << 1) | pp;
                     tau = tau * 3 + pp + ss;
                 }
-                s += base[((size_t)cls * 27 + tau) * 2048];
+                a8[m] += base[((size_t)cls * 27 + tau) * 2048];
             }
         }
+        const float s = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
         float* o = dw + ((int64_t)tap * cin_total + ci) * Cout + co;
         if (accumulate) *o += s; else *o = s;
     }
