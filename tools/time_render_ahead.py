@@ -30,7 +30,9 @@ wa, wb = trs[False].model._flat, trs[True].model._flat
 print("losses in step / ahead:", losses[False], losses[True])
 print("weights after 4 steps: max |diff| / max |w| =", float((wa - wb).abs().max() / wa.abs().max()))
 for rnd in range(3):
-    for ahead, tr in trs.items():
+    for ahead, at in ((False, "tail"), (True, "end"), (True, "tail")):
+        tr = trs[ahead]
+        tr.render_at = at
         nl = (src, src) if ahead else None
         for _ in range(2):
             tr.train_step(src, src, next_labels=nl)
@@ -39,6 +41,6 @@ for rnd in range(3):
         for _ in range(steps):
             tr.train_step(src, src, next_labels=nl)
         torch.cuda.synchronize()
-        print(f"round {rnd} render_ahead={ahead!s:5s}: {(time.perf_counter() - t0) / steps * 1e3:.2f} ms/step", flush=True)
+        print(f"round {rnd} render_ahead={ahead!s:5s} at={at if ahead else '-':4s}: {(time.perf_counter() - t0) / steps * 1e3:.2f} ms/step", flush=True)
         if ahead:   # drop the pair rendered for a step that this loop does not run, so the next round starts clean
             tr._ahead = None
