@@ -49,7 +49,8 @@ class SynthMorphTrainer:
         backward_precision: None = same arithmetic as the forward (fp32 / fp32x3); 'bf16' = dgrad and wgrad
         products on the bf16 hi halves only (one MFMA instead of three, fp32 accumulate) -- an opt-in
         mixed-precision backward; the forward (and therefore every output and loss) keeps fp32-grade accuracy.
-        overlap_wgrad (opt-in): the weight-gradient kernels run on a second HIP stream (nothing on the data-gradient chain
+        overlap_wgrad (opt-in; True, or "small" = only the levels of at most 100 k voxels, whose launches underfill the chip):
+        the weight-gradient kernels run on a second HIP stream (nothing on the data-gradient chain
         reads a weight gradient before Adam).  Measured at C3: 26.0 -> 25.9 ms -- the matrix-core kernels hold every CU's LDS
         and both waves' full register budget per SIMD, so the HBM-bound kernels of the chain cannot run beside them and only
         the partial last rounds of launches fill; off by default so that per-kernel timings stay those of a kernel alone on
@@ -79,6 +80,8 @@ class SynthMorphTrainer:
         self.fuse_pool_bwd = bool(fuse_pool_bwd)
         self.batch_repack = bool(batch_repack)
         self.wstream = torch.cuda.Stream(device=model._flat.device) if (overlap_wgrad and model._flat.is_cuda) else None
+        # "small": only the levels whose launches leave most of the chip idle (<= 40^3 voxels of a 160^3 step)
+        self.wstream_max_voxels = 100_000 if overlap_wgrad == "small" else None
         self.gstream, self._ahead = None, None   # generator stream and the pair it rendered ahead (train_step(next_labels=))
         self.render_at = "end"   # where a step queues the next pair's renderings: behind the whole step ("end") or behind the
         # flow head, beside the small kernels of the tail ("tail"); measured equal (24.3 ms both, 24.7 without)
@@ -209,7 +212,8 @@ class SynthMorphTrainer:
             """Run the weight-gradient launch ``fn`` behind everything enqueued so far, on the side stream when there is one.
             ``dz`` is a temporary of the main stream that the side stream reads: the allocator must not hand its block out again
             before that read has run (record_stream); activations live on the tape until the streams have been joined."""
-            if side is None:
+            if side is None or (self.wstream_max_voxels is not None
+                                and dz.shape[1] * dz.shape[2] * dz.shape[3] > self.wstream_max_voxels):
                 return fn()
             ev = torch.cuda.Event()
             ev.record()

@@ -16,7 +16,8 @@ kw = dict(in_shape=shape, in_label_list=np.arange(L), out_label_list=np.arange(L
           bias_std=0.3, bias_res=40, gamma_std=0.25, device=dev)
 src = torch.from_numpy(maps[0][None, ..., None]).to(dev)
 trs = {}
-for ov in (False, True):
+vals = (False, "small", True) if opt == "overlap_wgrad" else (False, True)
+for ov in vals:
     g1, g2 = synth.labels_to_image(**kw, id=0, seed=11), synth.labels_to_image(**kw, id=1, seed=12)
     model = mmr.networks.VxmDense(shape, nb_unet_features=(enc, dec), int_steps=5, int_resolution=2, svf_resolution=2,
                                   compute_dtype="fp32x3", device=dev, seed=0)
