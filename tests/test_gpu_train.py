@@ -453,6 +453,36 @@ def test_render_ahead_is_the_same_run(dev):
         tr.train_step(*batches[2])
 
 
+def test_fit_with_and_without_render_ahead_is_the_same_history(dev):
+    """fit(render_ahead=): two epochs with validation, device-resident and host label maps -- the next batch is pulled one step
+    early inside an epoch only, so the data generator, both image generators and the validation generator are consumed in
+    the same order either way."""
+    import mmr
+    from mmr import data, synth, training
+    shape, enc, dec, L = (16, 16, 32), [32, 32], [32, 32, 32], 4
+    rng = np.random.default_rng(28)
+    maps = [np.repeat(np.repeat(np.repeat(rng.integers(0, L, (4, 4, 8)), 4, 0), 4, 1), 4, 2).astype(np.uint8) for _ in range(6)]
+    kw = dict(in_shape=shape, in_label_list=np.arange(L), out_label_list=np.arange(L), warp_std=1, warp_res=8, blur_std=1,
+              bias_std=0.3, bias_res=8, gamma_std=0.25)
+    for device in (dev, None):
+        hist = {}
+        for ahead in (False, True):
+            np.random.seed(7)   # set_random_zero_borders draws from the global NumPy state, like the reference's
+            g1, g2 = synth.labels_to_image(**kw, id=0, seed=1), synth.labels_to_image(**kw, id=1, seed=2)
+            model = mmr.networks.VxmDense(shape, nb_unet_features=(enc, dec), int_steps=3, int_resolution=2, svf_resolution=2,
+                                          compute_dtype="fp32x3", seed=5)
+            # a small step: the float atomics of the gather adjoints make two runs of the SAME schedule drift apart (see
+            # test_training_lowers_loss_and_is_reproducible); a batch consumed out of order would move the losses by ~1e-2
+            tr = training.SynthMorphTrainer(model, g1, g2, reg_param=0.1, optimizer=training.Adam(1e-5))
+            gen = data.gen_synthmorph_eb(maps[:4], batch_size=1, rng=np.random.default_rng(3), device=device)
+            val = data.gen_synthmorph_eb(maps[4:], batch_size=1, rng=np.random.default_rng(4), device=device)
+            hist[ahead] = tr.fit(gen, validation_data=val, validation_steps=2, epochs=2, steps_per_epoch=4, verbose=0,
+                                 render_ahead=ahead)
+            assert tr._ahead is None
+        for a, b in zip(hist[False], hist[True]):
+            assert abs(a["loss"] - b["loss"]) < 2e-5 and abs(a["val_loss"] - b["val_loss"]) < 2e-5, (hist[False], hist[True])
+
+
 def test_optin_bf16_backward(dev):
     """Opt-in mixed-precision backward: forward unchanged (fp32x3), weight gradients within bf16-product accuracy
     of the fp32x3 gradients, and training still converges."""
