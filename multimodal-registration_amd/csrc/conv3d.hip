@@ -1494,10 +1494,20 @@ inline int conv_ksplit(int64_t nblk, int ntiles_n, int G)
 {
     const int64_t wgs = nblk * ntiles_n;
     if (wgs >= 128 || G < 18) return 1;
-    int S = (int)((256 + wgs - 1) / wgs);
-    if (S > G / 9) S = G / 9;  // at least 9 taps per block: the A tile is staged per block
-    if (S > 16) S = 16;
-    return S < 2 ? 1 : S;
+    int smax = G / 9;          // at least 9 taps per block: the A tile is staged per block
+    if (smax > 16) smax = 16;
+    // rounds of workgroups (one per CU) x (taps per block + what a block costs before its first tap: A tile, offset table,
+    // first weights ~ 12 taps).  The round count matters: 38 tiles x 7 = 266 blocks is TWO rounds of a seventh each, x 6 is one
+    // round of a sixth (the old rule, ceil(256 / tiles), overshot the chip by a few blocks at 38, 43, 52, 125 ... tiles).
+    const int ncu = conv_ncu();
+    int best = 1;
+    int64_t best_cost = 0;
+    for (int S = 1; S <= (smax < 1 ? 1 : smax); ++S) {
+        const int64_t rounds = (wgs * S + ncu - 1) / ncu;
+        const int64_t cost = rounds * ((G + S - 1) / S + 12);
+        if (S == 1 || cost < best_cost) { best = S; best_cost = cost; }
+    }
+    return best;
 }
 
 template <int DT, int WM, int WN, int MT, int NT, int VAR>
