@@ -56,6 +56,22 @@ __device__ __forceinline__ AxisG axis_setup_g(float loc, int maxi)
     return a;
 }
 
+// voxel index -> (x, y, z): 32-bit divisions whenever the volume has fewer than 2^31 voxels (the 64-bit ones are ~100
+// instructions each and these per-voxel kernels did three per voxel)
+__device__ __forceinline__ void voxel_xyz(int64_t v, int Y, int Z, bool small, int& x, int& y, int& z)
+{
+    if (small) {
+        const unsigned u = (unsigned)v, q = u / (unsigned)Z;
+        z = (int)(u - q * (unsigned)Z);
+        x = (int)(q / (unsigned)Y);
+        y = (int)(q - (unsigned)x * (unsigned)Y);
+    } else {
+        z = (int)(v % Z);
+        y = (int)((v / Z) % Y);
+        x = (int)(v / ((int64_t)Y * Z));
+    }
+}
+
 // ------------------------------------------------------------------------- //
 // Dice from label maps                                                      //
 // ------------------------------------------------------------------------- //
@@ -76,8 +92,10 @@ dice_labels_partial_kernel(const uint8_t* __restrict__ lab1, const uint8_t* __re
     const uint8_t* a2 = lab2 + (int64_t)b * nvox;
     const float* f = flow + (int64_t)b * nvox * 3;
     const int64_t sy = Z, sx = (int64_t)Y * Z;
+    const bool small = nvox < (int64_t)0x7fffffff;
     for (int64_t v = (int64_t)blockIdx.x * TB + tid; v < nvox; v += (int64_t)nblk * TB) {
-        const int z = (int)(v % Z), y = (int)((v / Z) % Y), x = (int)(v / sx);
+        int x, y, z;
+        voxel_xyz(v, Y, Z, small, x, y, z);
         const AxisG ax = axis_setup_g((float)x + f[v * 3], X - 1);
         const AxisG ay = axis_setup_g((float)y + f[v * 3 + 1], Y - 1);
         const AxisG az = axis_setup_g((float)z + f[v * 3 + 2], Z - 1);
@@ -183,8 +201,10 @@ dice_labels_bwd_kernel(const uint8_t* __restrict__ lab1, const uint8_t* __restri
     const float* f = flow + (int64_t)b * nvox * 3;
     float* df = dflow + (int64_t)b * nvox * 3;
     const int64_t sy = Z, sx = (int64_t)Y * Z;
+    const bool small = nvox < (int64_t)0x7fffffff;
     for (int64_t v = (int64_t)blockIdx.x * TB + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * TB) {
-        const int z = (int)(v % Z), y = (int)((v / Z) % Y), x = (int)(v / sx);
+        int x, y, z;
+        voxel_xyz(v, Y, Z, small, x, y, z);
         const AxisG ax = axis_setup_g((float)x + f[v * 3], X - 1);
         const AxisG ay = axis_setup_g((float)y + f[v * 3 + 1], Y - 1);
         const AxisG az = axis_setup_g((float)z + f[v * 3 + 2], Z - 1);
@@ -217,26 +237,31 @@ dice_labels_bwd_kernel(const uint8_t* __restrict__ lab1, const uint8_t* __restri
 // ------------------------------------------------------------------------- //
 // Grad-l2 backward: dflow (+)= scale*loss_mult/3 * sum_d (2/n_d) * (diff_prev - diff_next)   //
 // ------------------------------------------------------------------------- //
+// a wave per (b, x, y) row of Z * C contiguous floats: no per-element 64-bit index arithmetic (see grad_l2_partial_kernel)
 __global__ void __launch_bounds__(TB)
 grad_l2_bwd_kernel(const float* __restrict__ f, float* __restrict__ df, int B, int X, int Y, int Z, int C,
                    float cx, float cy, float cz, int accumulate)
 {
-    const int64_t nel = (int64_t)X * Y * Z * C;
-    const int64_t total = (int64_t)B * nel;
-    const int64_t sz = C, sy = (int64_t)Z * C, sx = (int64_t)Y * Z * C;
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TB) {
-        const int64_t e = i % nel;
-        const int64_t v = e / C;
-        const int z = (int)(v % Z), y = (int)((v / Z) % Y), x = (int)(v / ((int64_t)Z * Y));
-        const float c0 = f[i];
-        float g = 0.f;
-        if (x > 0) g += cx * (c0 - f[i - sx]);
-        if (x + 1 < X) g -= cx * (f[i + sx] - c0);
-        if (y > 0) g += cy * (c0 - f[i - sy]);
-        if (y + 1 < Y) g -= cy * (f[i + sy] - c0);
-        if (z > 0) g += cz * (c0 - f[i - sz]);
-        if (z + 1 < Z) g -= cz * (f[i + sz] - c0);
-        if (accumulate) df[i] += g; else df[i] = g;
+    const int rowlen = Z * C;
+    const int64_t sy = rowlen, sx = (int64_t)Y * rowlen;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t nrows = (int64_t)B * X * Y;
+    for (int64_t row = (int64_t)blockIdx.x * (TB / 64) + wv; row < nrows; row += (int64_t)gridDim.x * (TB / 64)) {
+        const int y = (int)(row % Y), x = (int)((row / Y) % X);
+        const float* r = f + row * rowlen;
+        float* o = df + row * rowlen;
+        const bool lx = x > 0, hx = x + 1 < X, ly = y > 0, hy = y + 1 < Y;
+        for (int t = lane; t < rowlen; t += 64) {
+            const float c0 = r[t];
+            float g = 0.f;
+            if (lx) g += cx * (c0 - r[t - sx]);
+            if (hx) g -= cx * (r[t + sx] - c0);
+            if (ly) g += cy * (c0 - r[t - sy]);
+            if (hy) g -= cy * (r[t + sy] - c0);
+            if (t >= C) g += cz * (c0 - r[t - C]);
+            if (t + C < rowlen) g -= cz * (r[t + C] - c0);
+            if (accumulate) o[t] += g; else o[t] = g;
+        }
     }
 }
 
@@ -349,6 +374,55 @@ resize_bwd_axis_kernel(const float* __restrict__ dout, float* __restrict__ din, 
             if (w != 0.f) acc += w * src[(int64_t)k * inner];
         }
         din[i] = acc * mul;
+    }
+}
+
+// The same pass for inner >= 256: one (outer, j) line per workgroup row (blockIdx.y = j, blockIdx.z = outer index), threads along
+// `inner`.  The candidate range and the (at most RBW) weights are those of the whole line: computed once per thread, then the
+// element loop is loads and multiply-adds only -- no 64-bit index divisions and no floor / clamp per candidate and element.
+constexpr int RBW = 8;
+__global__ void __launch_bounds__(TB)
+resize_bwd_axis_lines_kernel(const float* __restrict__ dout, float* __restrict__ din, int n_in, int n_out, int64_t inner, float st,
+                             float mul)
+{
+    const int j = blockIdx.y;
+    const int64_t o = blockIdx.z;
+    int lo, hi;
+    axis_range(j, st, n_out, n_in - 1, lo, hi);
+    float w[RBW];
+#pragma unroll
+    for (int k = 0; k < RBW; ++k) w[k] = (lo + k <= hi) ? axis_weight(lo + k, st, n_in - 1, j) : 0.f;
+    const float* src = dout + (o * n_out + lo) * inner;
+    float* dst = din + (o * n_in + j) * inner;
+    for (int64_t in = (int64_t)blockIdx.x * TB + threadIdx.x; in < inner; in += (int64_t)gridDim.x * TB) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < RBW; ++k)
+            if (w[k] != 0.f) acc += w[k] * src[(int64_t)k * inner + in];   // w[k] == 0 beyond hi: no read past the tensor
+        dst[in] = acc * mul;
+    }
+}
+
+// host side of one pass: the line kernel where it applies (long inner, few candidates per line, grid dims in range)
+static void launch_resize_bwd_axis(const float* dout, float* din, int64_t outer, int n_in, int n_out, int64_t inner, float st,
+                                   float mul, hipStream_t stream)
+{
+    // candidates per line: ceil((j + 1) / st) - floor((j - 1) / st) + 1 <= 2 / st + 3 (st > 0), the whole axis when st == 0
+    // st < 1 (the adjoint of an up-sampling: 5 - 6 candidates per line) is where the hoisted weights pay: 76 -> 63 us for the x2
+    // resize of a 160^3 field; with one or two candidates per line (st = 2) the element-indexed kernel is the faster one (101 vs 106)
+    bool few = st > 0.f && st < 1.f && 2.0f / st + 3.0f <= (float)RBW;
+    if (few) {   // the last input index also gathers every output clamped onto it (axis_range: hi = n_out - 1 for j == n_in - 1)
+        const int lo_last = (int)floorf((float)(n_in - 2) / st);
+        few = n_out - (lo_last < 0 ? 0 : lo_last) <= RBW;
+    }
+    if (inner >= 256 && few && outer <= 65535 && n_in <= 65535) {
+        int gx = (int)((inner + TB - 1) / TB);
+        if (gx > 64) gx = 64;
+        hipLaunchKernelGGL(resize_bwd_axis_lines_kernel, dim3(gx, n_in, (unsigned)outer), dim3(TB), 0, stream, dout, din, n_in, n_out,
+                           inner, st, mul);
+    } else {
+        hipLaunchKernelGGL(resize_bwd_axis_kernel, dim3(stream_grid(outer * n_in * inner, TB)), dim3(TB), 0, stream, dout, din, outer,
+                           n_in, n_out, inner, st, mul);
     }
 }
 
@@ -2496,7 +2570,7 @@ extern "C" int mmr_grad_l2_bwd_f32(const float* flow, float* dflow, int B, int X
     const float cx = (float)(k / ((double)(X - 1) * Y * Z * C));
     const float cy = (float)(k / ((double)X * (Y - 1) * Z * C));
     const float cz = (float)(k / ((double)X * Y * (Z - 1) * C));
-    hipLaunchKernelGGL(grad_l2_bwd_kernel, dim3(stream_grid((int64_t)B * X * Y * Z * C, TB)), dim3(TB), 0,
+    hipLaunchKernelGGL(grad_l2_bwd_kernel, dim3(stream_grid((int64_t)B * X * Y * 64, TB)), dim3(TB), 0,
                        as_stream(stream), flow, dflow, B, X, Y, Z, C, cx, cy, cz, accumulate);
     return check_launch();
 }
@@ -2530,13 +2604,9 @@ extern "C" int mmr_resize_trilinear_bwd_ws_f32(const float* dout, float* din, vo
     if (resize_steps(X, Y, Z, Xo, Yo, Zo, grid_mode, zoom, stx, sty, stz)) return MMR_EINVAL;
     float* t1 = static_cast<float*>(ws);
     float* t2 = t1 + (int64_t)B * X * Yo * Zo * C;
-    const int64_t n1 = (int64_t)B * X * Yo * Zo * C, n2 = (int64_t)B * X * Y * Zo * C, n3 = (int64_t)B * X * Y * Z * C;
-    hipLaunchKernelGGL(resize_bwd_axis_kernel, dim3(stream_grid(n1, TB)), dim3(TB), 0, st, dout, t1, (int64_t)B, X, Xo,
-                       (int64_t)Yo * Zo * C, stx, 1.0f);
-    hipLaunchKernelGGL(resize_bwd_axis_kernel, dim3(stream_grid(n2, TB)), dim3(TB), 0, st, (const float*)t1, t2, (int64_t)B * X, Y, Yo,
-                       (int64_t)Zo * C, sty, 1.0f);
-    hipLaunchKernelGGL(resize_bwd_axis_kernel, dim3(stream_grid(n3, TB)), dim3(TB), 0, st, (const float*)t2, din, (int64_t)B * X * Y, Z,
-                       Zo, (int64_t)C, stz, mul);
+    launch_resize_bwd_axis(dout, t1, (int64_t)B, X, Xo, (int64_t)Yo * Zo * C, stx, 1.0f, st);
+    launch_resize_bwd_axis((const float*)t1, t2, (int64_t)B * X, Y, Yo, (int64_t)Zo * C, sty, 1.0f, st);
+    launch_resize_bwd_axis((const float*)t2, din, (int64_t)B * X * Y, Z, Zo, (int64_t)C, stz, mul, st);
     return check_launch();
 }
 
