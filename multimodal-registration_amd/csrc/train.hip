@@ -500,40 +500,76 @@ compose_bwd_tiled_kernel(const float* __restrict__ a, const float* __restrict__ 
     float* dabase = da + b * nvox * 3;
     const bool alias = (da == db);
     __syncthreads();
+    // The trilinear splat is LDS float atomics (~117 LDS cycles per ds_add_f32 wave-instruction): a 16-lane DPP row is one
+    // z line of the tile, and where the field is smooth the UPPER z corner of voxel z is the LOWER z corner of voxel z + 1 -- then
+    // lane z + 1 adds both values with one atomic and lane z issues none for that corner: 12 - 15 atomics per voxel instead of 24.
+    auto shr1f = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true)); };
+    auto shr1i = [](int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); };   // row_shr:1, 0 into the row's first lane
+    auto shl1i = [](int v) { return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xf, 0xf, true); };   // row_shl:1, 0 into its last lane
+    static_assert(CB_TZ == 16 && (CB_TX * CB_TY * CB_TZ) % TB == 0, "a DPP row = one z line of the tile; every lane runs every step");
     for (int lv = threadIdx.x; lv < CB_TX * CB_TY * CB_TZ; lv += TB) {
         const int lz = lv % CB_TZ, ly = (lv / CB_TZ) % CB_TY, lx = lv / (CB_TZ * CB_TY);
         const int x = x0 + lx, y = y0 + ly, z = z0 + lz;
-        if (x >= X || y >= Y || z >= Z) continue;
-        const int64_t v = b * nvox + ((int64_t)x * Y + y) * Z + z;
+        const bool active = x < X && y < Y && z < Z;
+        const int cxv = active ? x : 0, cyv = active ? y : 0, czv = active ? z : 0;      // inactive lanes: any valid voxel, values zeroed
+        const int64_t v = b * nvox + ((int64_t)cxv * Y + cyv) * Z + czv;
         const float* f = bf + v * 3;
-        const AxisG ax = axis_setup_g((float)x + f[0] * s, X - 1);
-        const AxisG ay = axis_setup_g((float)y + f[1] * s, Y - 1);
-        const AxisG az = axis_setup_g((float)z + f[2] * s, Z - 1);
-        const float g[3] = {dout[v * 3], dout[v * 3 + 1], dout[v * 3 + 2]};
+        const AxisG ax = axis_setup_g((float)cxv + f[0] * s, X - 1);
+        const AxisG ay = axis_setup_g((float)cyv + f[1] * s, Y - 1);
+        const AxisG az = axis_setup_g((float)czv + f[2] * s, Z - 1);
+        const float g[3] = {active ? dout[v * 3] : 0.f, active ? dout[v * 3 + 1] : 0.f, active ? dout[v * 3 + 2] : 0.f};
         float dl[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc) {
-            const int qx = cc >> 2, qy = (cc >> 1) & 1, qz = cc & 1;
-            const int ix = qx ? ax.i1 : ax.i0, iy = qy ? ay.i1 : ay.i0, iz = qz ? az.i1 : az.i0;
-            const int64_t off = ix * sx + iy * sy + (int64_t)iz * 3;
-            const float wx = qx ? ax.w1 : ax.w0, wy = qy ? ay.w1 : ay.w0, wz = qz ? az.w1 : az.w0;
-            const float w = (wx * wy) * wz;
-            const int rx = ix - x0 + CB_M, ry = iy - y0 + CB_M, rz = iz - z0 + CB_M;
-            const bool inimg = (unsigned)rx < (unsigned)CB_RX && (unsigned)ry < (unsigned)CB_RY && (unsigned)rz < (unsigned)CB_RZ;
-            const int ro = ((rx * CB_RY + ry) * CB_RZ + rz) * 3;
-            float dotv = 0.f;
+        for (int pq = 0; pq < 4; ++pq) {
+            const int qx = pq >> 1, qy = pq & 1;
+            const int ix = qx ? ax.i1 : ax.i0, iy = qy ? ay.i1 : ay.i0;
+            const float wx = qx ? ax.w1 : ax.w0, wy = qy ? ay.w1 : ay.w0;
+            const int64_t offxy = ix * sx + iy * sy;
+            const int rx = ix - x0 + CB_M, ry = iy - y0 + CB_M;
+            const bool inxy = (unsigned)rx < (unsigned)CB_RX && (unsigned)ry < (unsigned)CB_RY;
+            float wq[2];
+            int64_t offq[2];
+            int roq[2];
+            bool inq[2];
+#pragma unroll
+            for (int qz = 0; qz < 2; ++qz) {
+                const int iz = qz ? az.i1 : az.i0;
+                const float wz = qz ? az.w1 : az.w0;
+                offq[qz] = offxy + (int64_t)iz * 3;
+                wq[qz] = (wx * wy) * wz;
+                const int rz = iz - z0 + CB_M;
+                inq[qz] = inxy && (unsigned)rz < (unsigned)CB_RZ;
+                roq[qz] = ((rx * CB_RY + ry) * CB_RZ + rz) * 3;
+                float dotv = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dotv += g[c] * (abase[offq[qz] + c] * s);
+                dl[0] += (qx ? 1.f : -1.f) * wy * wz * dotv;
+                dl[1] += (qy ? 1.f : -1.f) * wx * wz * dotv;
+                dl[2] += (qz ? 1.f : -1.f) * wx * wy * dotv;
+            }
+            // voxel offsets fit 31 bits here (the tiled kernel runs for nt <= 2^31 tiles of >= 1 voxel; offsets of a 3-channel field
+            // of fewer than 2^31 / 3 voxels) -- else no merging
+            const bool small = (int64_t)B * nvox * 3 < (int64_t)0x7ffffff0;
+            const int key1 = (active && small) ? (int)(b * nvox * 3 + offq[1]) + 1 : 0;     // 0 = nothing to hand over
+            const int key0 = (int)(b * nvox * 3 + offq[0]) + 1;
+            const bool take = active && small && shr1i(key1) == key0;                    // the lower lane's upper corner is my lower corner
+            const bool given = shl1i(take ? 1 : 0) != 0;                                   // ... and the upper lane took mine
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                dotv += g[c] * (abase[off + c] * s);
-                if (w != 0.f) {
-                    if (inimg) atomicAdd(&img[ro + c], s * w * g[c]);
-                    else atomicAdd(dabase + off + c, s * w * g[c]);
+                const float v1 = s * wq[1] * g[c];
+                const float pv = shr1f(v1);
+                const float v0 = s * wq[0] * g[c] + (take ? pv : 0.f);
+                if (active && (wq[0] != 0.f || take)) {
+                    if (inq[0]) atomicAdd(&img[roq[0] + c], v0);
+                    else atomicAdd(dabase + offq[0] + c, v0);
+                }
+                if (active && wq[1] != 0.f && !given) {
+                    if (inq[1]) atomicAdd(&img[roq[1] + c], v1);
+                    else atomicAdd(dabase + offq[1] + c, v1);
                 }
             }
-            dl[0] += (qx ? 1.f : -1.f) * wy * wz * dotv;
-            dl[1] += (qy ? 1.f : -1.f) * wx * wz * dotv;
-            dl[2] += (qz ? 1.f : -1.f) * wx * wy * dotv;
         }
+        if (!active) continue;
         const float d0 = s * (g[0] + ax.inr * dl[0]), d1 = s * (g[1] + ay.inr * dl[1]), d2 = s * (g[2] + az.inr * dl[2]);
         if (alias) {
             float* o = img + (((lx + CB_M) * CB_RY + ly + CB_M) * CB_RZ + lz + CB_M) * 3;
