@@ -126,13 +126,20 @@ dice_labels_partial_kernel(const uint8_t* __restrict__ lab1, const uint8_t* __re
         }
     }
     __syncthreads();
-    // ordered reduction over the 256 private columns: thread (l, half)
-    for (int l = tid; l < L; l += TB) {
+    // reduction over the 256 private columns in a fixed order: a wave per label (the one-thread-per-label form walked 2 x 256 LDS
+    // words serially with 26 of 256 threads busy: ~16 us per workgroup of a 74-us kernel)
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int l = wv; l < L; l += TB / 64) {
         double st = 0.0, sb = 0.0;
-        for (int k = 0; k < TB; ++k) { st += (double)s_tp[l * TB + k]; sb += (double)s_bt[l * TB + k]; }
-        double* o = part + (((int64_t)b * nblk + blockIdx.x) * L + l) * 2;
-        o[0] = st;
-        o[1] = sb;
+#pragma unroll
+        for (int k = 0; k < TB / 64; ++k) { st += (double)s_tp[l * TB + k * 64 + lane]; sb += (double)s_bt[l * TB + k * 64 + lane]; }
+        st = wave_sum(st);
+        sb = wave_sum(sb);
+        if (lane == 0) {
+            double* o = part + (((int64_t)b * nblk + blockIdx.x) * L + l) * 2;
+            o[0] = st;
+            o[1] = sb;
+        }
     }
 }
 
