@@ -526,55 +526,86 @@ compose_bwd_tiled_kernel(const float* __restrict__ a, const float* __restrict__ 
         const AxisG az = axis_setup_g((float)czv + f[2] * s, Z - 1);
         const float g[3] = {active ? dout[v * 3] : 0.f, active ? dout[v * 3 + 1] : 0.f, active ? dout[v * 3 + 2] : 0.f};
         float dl[3] = {0.f, 0.f, 0.f};
+        // voxel offsets fit 31 bits here (offsets of a 3-channel field of fewer than 2^31 / 3 voxels) -- else no merging
+        const bool small = (int64_t)B * nvox * 3 < (int64_t)0x7ffffff0;
+        const int lane_ = threadIdx.x & 63, row4 = lane_ >> 4;       // the wave's four z lines are four consecutive y
+        const int up_addr = ((lane_ - 16) & 63) * 4, dn_addr = ((lane_ + 16) & 63) * 4;
 #pragma unroll
-        for (int pq = 0; pq < 4; ++pq) {
-            const int qx = pq >> 1, qy = pq & 1;
-            const int ix = qx ? ax.i1 : ax.i0, iy = qy ? ay.i1 : ay.i0;
-            const float wx = qx ? ax.w1 : ax.w0, wy = qy ? ay.w1 : ay.w0;
-            const int64_t offxy = ix * sx + iy * sy;
-            const int rx = ix - x0 + CB_M, ry = iy - y0 + CB_M;
-            const bool inxy = (unsigned)rx < (unsigned)CB_RX && (unsigned)ry < (unsigned)CB_RY;
-            float wq[2];
-            int64_t offq[2];
-            int roq[2];
-            bool inq[2];
+        for (int qx = 0; qx < 2; ++qx) {
+            const int ix = qx ? ax.i1 : ax.i0;
+            const float wx = qx ? ax.w1 : ax.w0;
+            const int rx = ix - x0 + CB_M;
+            // pending adds of this lane: [qy][qz] -> key (voxel offset + 1), three values, target, "still to be issued by me"
+            int key[2][2], ro[2][2];
+            int64_t off[2][2];
+            float val[2][2][3];
+            bool pend[2][2], inq[2][2], mine[2][2];
+#pragma unroll
+            for (int qy = 0; qy < 2; ++qy) {
+                const int iy = qy ? ay.i1 : ay.i0;
+                const float wy = qy ? ay.w1 : ay.w0;
+                const int64_t offxy = ix * sx + iy * sy;
+                const int ry = iy - y0 + CB_M;
+                const bool inxy = (unsigned)rx < (unsigned)CB_RX && (unsigned)ry < (unsigned)CB_RY;
+                float wq[2];
+#pragma unroll
+                for (int qz = 0; qz < 2; ++qz) {
+                    const int iz = qz ? az.i1 : az.i0;
+                    const float wz = qz ? az.w1 : az.w0;
+                    off[qy][qz] = offxy + (int64_t)iz * 3;
+                    wq[qz] = (wx * wy) * wz;
+                    const int rz = iz - z0 + CB_M;
+                    inq[qy][qz] = inxy && (unsigned)rz < (unsigned)CB_RZ;
+                    ro[qy][qz] = ((rx * CB_RY + ry) * CB_RZ + rz) * 3;
+                    key[qy][qz] = (int)(b * nvox * 3 + off[qy][qz]) + 1;
+                    float dotv = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) dotv += g[c] * (abase[off[qy][qz] + c] * s);
+                    dl[0] += (qx ? 1.f : -1.f) * wy * wz * dotv;
+                    dl[1] += (qy ? 1.f : -1.f) * wx * wz * dotv;
+                    dl[2] += (qz ? 1.f : -1.f) * wx * wy * dotv;
+                }
+                // z: the lower lane's upper corner is my lower corner -> I add both, it adds nothing there
+                const bool take = active && small && shr1i((active && small) ? key[qy][1] : 0) == key[qy][0];
+                const bool given = shl1i(take ? 1 : 0) != 0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float v1 = s * wq[1] * g[c];
+                    const float pv = shr1f(v1);
+                    val[qy][0][c] = s * wq[0] * g[c] + (take ? pv : 0.f);
+                    val[qy][1][c] = v1;
+                }
+                pend[qy][0] = active && (wq[0] != 0.f || take);
+                pend[qy][1] = active && wq[1] != 0.f && !given;
+                mine[qy][0] = active;
+                mine[qy][1] = active && !given;
+            }
+            // y: the same between the wave's z lines -- the y + 1 line takes what the y line has pending for the same voxel
 #pragma unroll
             for (int qz = 0; qz < 2; ++qz) {
-                const int iz = qz ? az.i1 : az.i0;
-                const float wz = qz ? az.w1 : az.w0;
-                offq[qz] = offxy + (int64_t)iz * 3;
-                wq[qz] = (wx * wy) * wz;
-                const int rz = iz - z0 + CB_M;
-                inq[qz] = inxy && (unsigned)rz < (unsigned)CB_RZ;
-                roq[qz] = ((rx * CB_RY + ry) * CB_RZ + rz) * 3;
-                float dotv = 0.f;
+                const int hand = (pend[1][qz] && small) ? key[1][qz] : 0;
+                const int upkey = __builtin_amdgcn_ds_bpermute(up_addr, hand);
+                const bool takey = row4 > 0 && mine[0][qz] && upkey != 0 && upkey == key[0][qz];
+                const bool giveny = __builtin_amdgcn_ds_bpermute(dn_addr, takey ? 1 : 0) != 0 && row4 < 3;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) dotv += g[c] * (abase[offq[qz] + c] * s);
-                dl[0] += (qx ? 1.f : -1.f) * wy * wz * dotv;
-                dl[1] += (qy ? 1.f : -1.f) * wx * wz * dotv;
-                dl[2] += (qz ? 1.f : -1.f) * wx * wy * dotv;
+                for (int c = 0; c < 3; ++c) {
+                    const float upv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(up_addr, __builtin_bit_cast(int, val[1][qz][c])));
+                    if (takey) val[0][qz][c] += upv;
+                }
+                pend[0][qz] = pend[0][qz] || takey;
+                pend[1][qz] = pend[1][qz] && !giveny;
             }
-            // voxel offsets fit 31 bits here (the tiled kernel runs for nt <= 2^31 tiles of >= 1 voxel; offsets of a 3-channel field
-            // of fewer than 2^31 / 3 voxels) -- else no merging
-            const bool small = (int64_t)B * nvox * 3 < (int64_t)0x7ffffff0;
-            const int key1 = (active && small) ? (int)(b * nvox * 3 + offq[1]) + 1 : 0;     // 0 = nothing to hand over
-            const int key0 = (int)(b * nvox * 3 + offq[0]) + 1;
-            const bool take = active && small && shr1i(key1) == key0;                    // the lower lane's upper corner is my lower corner
-            const bool given = shl1i(take ? 1 : 0) != 0;                                   // ... and the upper lane took mine
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float v1 = s * wq[1] * g[c];
-                const float pv = shr1f(v1);
-                const float v0 = s * wq[0] * g[c] + (take ? pv : 0.f);
-                if (active && (wq[0] != 0.f || take)) {
-                    if (inq[0]) atomicAdd(&img[roq[0] + c], v0);
-                    else atomicAdd(dabase + offq[0] + c, v0);
-                }
-                if (active && wq[1] != 0.f && !given) {
-                    if (inq[1]) atomicAdd(&img[roq[1] + c], v1);
-                    else atomicAdd(dabase + offq[1] + c, v1);
-                }
-            }
+            for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+                for (int qz = 0; qz < 2; ++qz)
+                    if (pend[qy][qz]) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            if (inq[qy][qz]) atomicAdd(&img[ro[qy][qz] + c], val[qy][qz][c]);
+                            else atomicAdd(dabase + off[qy][qz] + c, val[qy][qz][c]);
+                        }
+                    }
         }
         if (!active) continue;
         const float d0 = s * (g[0] + ax.inr * dl[0]), d1 = s * (g[1] + ay.inr * dl[1]), d2 = s * (g[2] + az.inr * dl[2]);
