@@ -107,16 +107,27 @@ def test_resize_bwd_is_adjoint(dev, shape, new, mul):
         assert _rel(got, xt.grad) < 1e-5, separable
 
 
-@pytest.mark.parametrize("scale", [0.4, 2.5])
+@pytest.mark.parametrize("scale", [0.4, 2.5, "smooth", "smooth_large"])
 def test_compose_bwd_tiled_multi_tile(dev, scale):
     """compose_bwd_tiled_kernel: several 8x8x16 tiles with overhang, batch of 2, splats inside the LDS image (small
-    displacements) and beyond its 2-voxel margin (large ones, global-atomic path), aliased (VecInt) and separate outputs."""
+    displacements) and beyond its 2-voxel margin (large ones, global-atomic path), aliased (VecInt) and separate outputs.
+    'smooth': fields that vary slowly (what VecInt sees) -- there neighbouring voxels splat onto shared corners and the kernel merges
+    them along z (DPP) and y (ds_bpermute) before the atomic, also across the clamped borders and the ragged tile edges."""
     import mmr
     from oracle import grad_torch as G
+    from scipy.ndimage import zoom
     rng = np.random.default_rng(13)
     S = (19, 10, 37)
-    a = (rng.standard_normal((2,) + S + (3,)) * scale).astype(np.float32)
-    b = (rng.standard_normal((2,) + S + (3,)) * scale).astype(np.float32)
+    if isinstance(scale, str):
+        amp = 1.2 if scale == "smooth" else 4.0
+        coarse = lambda: rng.standard_normal((2, 4, 3, 5, 3)) * amp
+        up = lambda c: np.stack([np.stack([zoom(c[i, ..., k], [S[0] / 4, S[1] / 3, S[2] / 5], order=1) for k in range(3)], -1)
+                                 for i in range(2)]).astype(np.float32)
+        a, b = up(coarse()), up(coarse())
+        assert a.shape == (2,) + S + (3,)
+    else:
+        a = (rng.standard_normal((2,) + S + (3,)) * scale).astype(np.float32)
+        b = (rng.standard_normal((2,) + S + (3,)) * scale).astype(np.float32)
     g = rng.standard_normal((2,) + S + (3,)).astype(np.float32)
     da, db = mmr.ops.compose_bwd(_t(a, dev), _t(b, dev), _t(g, dev))
     for i in range(2):
