@@ -3,8 +3,9 @@
 Replaces ``tf.distribute.MirroredStrategy`` (train_synthmorph.py:284-285, the reference's only
 collective): Keras scales each replica's loss by 1/num_replicas and SUM-all-reduces the gradients.
 Here every rank holds the 22 gradient tensors as views of one flat fp32 buffer, so the exchange is a
-single ``all_reduce(SUM)`` of 5.8 MB (64 features) / 92 MB (256 features) over RCCL/xGMI followed by the
-1/world scale folded into the Adam kernel.  Label-map synthesis and the data feed shard by index with
+``all_reduce(SUM)`` of 5.8 MB (64 features) / 92 MB (256 features) over RCCL/xGMI -- issued as two buckets: everything but the
+encoder's gradients as soon as the decoder's backward is done (it runs under the encoder's backward, >= 3 ms at C3), the
+encoder's few hundred KB at the end -- followed by the 1/world scale folded into the Adam kernel.  Label-map synthesis and the data feed shard by index with
 no communication.  Works on any torch.distributed backend (RCCL on GPUs, gloo in the CPU tests).
 """
 import os
@@ -66,6 +67,14 @@ def allreduce_sum_(flat, group=None):
     if active(group):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
+
+
+def allreduce_sum_async(flat, group=None):
+    """Start the in-place SUM all-reduce of a contiguous slice of the gradient buffer behind the work queued on the current
+    stream so far; returns a handle whose ``wait()`` orders the current stream behind the collective (None for a single rank)."""
+    if active(group):
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    return None
 
 
 def allreduce_mean_scalar(value, device, group=None):

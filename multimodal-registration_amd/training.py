@@ -86,11 +86,16 @@ class SynthMorphTrainer:
         self.render_at = "end"   # where a step queues the next pair's renderings: behind the whole step ("end") or behind the
         # flow head, beside the small kernels of the tail ("tail"); measured equal (24.3 ms both, 24.7 without)
         self.gflat = torch.zeros_like(model._flat)
-        self.g, off = [], 0
+        self.g, self.goff, off = [], [], 0
         for w in model._w:
             n = w.numel()
             self.g.append(self.gflat[off:off + n].view(w.shape))
+            self.goff.append(off)
             off += n
+        # data parallel: the gradients of every layer behind the encoder are complete when the backward reaches the last encoder
+        # conv -- their all-reduce starts there and runs under the encoder's backward (bucket 1); the rest follows the backward
+        self._bucket_li = len(model.enc) - 1
+        self._ar_early, self._reduce_early = None, False   # only train_step reduces; forward_backward leaves gflat unreduced
         if self.world > 1 or parallel.forced():
             parallel.broadcast_(model._flat, 0, self.pg)
             model.invalidate_packed()
@@ -226,6 +231,11 @@ class SynthMorphTrainer:
             kind = rec[0]
             if kind == "conv":
                 _, li, x, up0, in1, y, leaky = rec
+                if (self._reduce_early and li == self._bucket_li and self._bucket_li > 0 and side is None
+                        and (self.world > 1 or parallel.forced())):
+                    # every layer > li has its weight and bias gradient by now (a layer's bias sums are closed before its own
+                    # record is reached): all-reduce them behind what is queued, under the rest of the backward
+                    self._ar_early = parallel.allreduce_sum_async(self.gflat[self.goff[2 * (li + 1)]:], self.pg)
                 dy = grads.pop(id(y))
                 if id(y) in premasked:
                     dz = dy
@@ -413,10 +423,19 @@ class SynthMorphTrainer:
         if next_labels is not None and self.render_at != "tail":
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream())   # whatever produced next_labels is already queued
-        out = self.forward_backward(src_labels, trg_labels, draws_1, draws_2, train=True, next_labels=next_labels)
+        self._reduce_early = True
+        try:
+            out = self.forward_backward(src_labels, trg_labels, draws_1, draws_2, train=True, next_labels=next_labels)
+        finally:
+            self._reduce_early = False
         if self.world > 1 or parallel.forced():
             with ops._Timed("comm:allreduce_grads", (self.world,), float(self.gflat.numel() * 4)):
-                parallel.allreduce_sum_(self.gflat, self.pg)  # one 5.8 MB (64f) message
+                if self._ar_early is not None:   # bucket 1 (5.4 of 5.8 MB at 64 f) has been running since the last encoder conv
+                    parallel.allreduce_sum_(self.gflat[:self.goff[2 * (self._bucket_li + 1)]], self.pg)
+                    self._ar_early.wait()
+                    self._ar_early = None
+                else:
+                    parallel.allreduce_sum_(self.gflat, self.pg)
         self.opt.apply(self.model._flat, self.gflat, grad_scale=1.0 / self.world)
         if self.batch_repack:
             self.model.repack()   # all weight images of the next step in one launch

@@ -46,7 +46,7 @@ g_local = tr.gflat.clone()
 parallel.allreduce_sum_(tr.gflat)                  # world 1: SUM over one rank must return the same bits
 assert torch.equal(tr.gflat, g_local) and calls["all_reduce"] == 1
 l0 = float(tr.train_step(lab, lab, d1, d2)["loss"])
-assert calls["all_reduce"] == 2
+assert calls["all_reduce"] == 3                    # a step = two buckets: decoder + flow under the encoder's backward, encoder after it
 for _ in range(8):
     l1 = float(tr.train_step(lab, lab, d1, d2)["loss"])
 assert l1 < l0
