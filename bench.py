@@ -516,7 +516,8 @@ def main():
             workload = (f"train_synthmorph.py step (BASELINE configs[2]): {shape[0]}^3, enc/dec={feats}, {L} labels, Dice + "
                         f"Grad-l2(reg 1), same_subj pairs, generators + fwd + bwd + all-reduce + Adam, 1 pair per GPU, label maps resident in HBM"
                         + (" [OPT-IN bf16-product backward]" if args.bwd else ""))
-            par = f"dp{world} (batch sharded by rank, one SUM all-reduce of {model._flat.numel() * 4 / 1e6:.1f} MB over RCCL)"
+            par = (f"dp{world} (batch sharded by rank, SUM all-reduce of {model._flat.numel() * 4 / 1e6:.1f} MB over RCCL in two buckets, "
+                   "the decoder's under the encoder's backward)")
             cpu_fn = lambda: cpu_baseline_train(enc, dec, shape, L, maps[0])
             extra["allreduce_bytes"] = model._flat.numel() * 4
         else:  # ncc
