@@ -2156,13 +2156,18 @@ constexpr int MH_THREADS = 256;
 // issued before the first MFMA, from clamped always-valid addresses, and masked when used.  The generic path (NS = 0)
 // loads one k-step ahead behind `if (row in volume)`, which hipcc turns into a branch and a full wait per load: the
 // 2 x Cin/32 loads of a plane ran as dependent round trips and the kernel streamed 1.8 TB/s of its 2.5 GB input.
-template <bool X3, int NS = 0>
-__global__ void __launch_bounds__(MH_THREADS, 1)
+// HY (round 4): y rows of the haloed patch = 2 x the waves of the workgroup.  HY = 16 (bf16, Cin = 256): 14 x 14 outputs per patch
+// (halo redundancy 1.31 instead of 1.52), eight waves with two row tiles each -- twice the prefetched bytes in flight per CU --,
+// ONE P plane of 256 rows (two barriers per plane), up to two outputs per thread.
+template <bool X3, int NS = 0, int HY = MH_HY>
+__global__ void __launch_bounds__(HY * 32, 1)
 flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
                        float* __restrict__ out, int B, int X, int Y, int Z, int Cin, int nseg, int seglen, int nty, int ntz,
                        int ntiles, int pbufs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TYO = HY - 2, ROWS = HY * MH_HZ, THREADS = HY * 32;
+    constexpr int NOUT = TYO * MH_TZ * 3, OPT = (NOUT + THREADS - 1) / THREADS;   // outputs (voxel, channel) of a patch plane, per thread
     const int nkc = Cin / 8;                       // 16-B k-chunks
     char* sW = smem;                               // [X3 ? 2 : 1][nkc][96][16 B]
     float* sP = reinterpret_cast<float*>(smem + (X3 ? 2 : 1) * nkc * 96 * 16);  // [pbufs][128][81]
@@ -2171,7 +2176,7 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
     const int r16 = lane & 15, q16 = lane >> 4;
     constexpr int ES = X3 ? 4 : 2;
 
-    for (int i = tid; i < nkc * 96; i += MH_THREADS) {  // weight image W'[k = ci][n = tap*3+co], once per block
+    for (int i = tid; i < nkc * 96; i += THREADS) {  // weight image W'[k = ci][n = tap*3+co], once per block
         const int n = i % 96, kc = i / 96;
         unsigned hi[4], lo[4];
 #pragma unroll
@@ -2191,11 +2196,16 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
         *reinterpret_cast<uint4*>(sW + (size_t)i * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
         if constexpr (X3) *reinterpret_cast<uint4*>(sW + (size_t)(nkc * 96 + i) * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
     }
-    // output role of this thread
+    // output role of this thread: (voxel, channel) number tid of the patch plane -- and, HY = 16, number tid + THREADS as well
+    static_assert(OPT == 1 || OPT == 2, "one or two outputs per thread");
     const int co = tid % 3, ov = tid / 3;
-    const int vz = ov % MH_TZ, vy = ov / MH_TZ;  // vy < 6 for tid < 252
-    const bool outthr = tid < MH_TY * MH_TZ * 3;
+    const int vz = ov % MH_TZ, vy = ov / MH_TZ;  // vy < TYO for tid < NOUT
+    const bool outthr = tid < NOUT;
     const float bco = bias ? bias[co] : 0.f;
+    const int idx1 = (tid + THREADS < NOUT) ? tid + THREADS : 0;
+    const int co1 = idx1 % 3, vz1 = (idx1 / 3) % MH_TZ, vy1 = (idx1 / 3) / MH_TZ;
+    const bool outthr1 = OPT == 2 && tid + THREADS < NOUT;
+    const float bco1 = (OPT == 2 && bias) ? bias[co1] : 0.f;
     const int nsteps = Cin / 32;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -2204,7 +2214,7 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
         const int tyi = t % nty; t /= nty;
         const int seg = t % nseg;
         const int b = t / nseg;
-        const int y0 = tyi * MH_TY, z0 = tzi * MH_TZ;
+        const int y0 = tyi * TYO, z0 = tzi * MH_TZ;
         const int xs = seg * seglen, xe = (xs + seglen < X) ? xs + seglen : X;
         // this wave's two row tiles = halo y-rows hy = 2 wave + j, lane r16 = halo z
         size_t rowoff[2];
@@ -2220,6 +2230,9 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
         const int gyo = y0 + vy, gzo = z0 + vz;
         const bool ook = outthr && gyo < Y && gzo < Z;
         float a_prev = 0.f, a_cur = 0.f;
+        const int gyo1 = y0 + vy1, gzo1 = z0 + vz1;
+        const bool ook1 = outthr1 && gyo1 < Y && gzo1 < Z;
+        float a_prev1 = 0.f, a_cur1 = 0.f;
         // NS > 0: the A fragments of plane xp + 1 are loaded while plane xp is multiplied and gathered (native 128-bit vectors,
         // so that the loop-carried registers get no copies behind the loads).  With one 4-wave workgroup per CU (130 KB of
         // LDS) nothing else hides the HBM latency: a plane took 12 k cycles for 1.5 k cycles of MFMA.
@@ -2231,7 +2244,7 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
         // in flight, not by HBM bandwidth or by its halo (an XCD-contiguous tile order changes nothing).
         // (bf16 only: the narrow fp32x3 inputs run two workgroups per CU, which already doubles the bytes in flight; two planes
         // ahead cost them 5 %)
-        constexpr bool DEEP = !X3;
+        constexpr bool DEEP = !X3 && HY == MH_HY;   // HY = 16: eight waves already hold twice the bytes in flight; a second buffer spills (52 B)
         constexpr int AHEAD = DEEP ? 2 : 1;
         typedef u32x4_t PreBuf[NL][2];
         PreBuf preA, preB;
@@ -2251,7 +2264,7 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
         }
         auto plane_step = [&](int xp, PreBuf& pre) {
             const int buf = (pbufs == 2) ? ((xp - xs + 1) & 1) : 0;
-            float* P = sP + buf * (MH_ROWS * 81);
+            float* P = sP + buf * (ROWS * 81);
             const bool inside = xp >= 0 && xp < X;
             if constexpr (NS > 0) {
                 if (!inside) load_plane(pre, xp + AHEAD);
@@ -2370,6 +2383,25 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
                 out[((((size_t)b * X + (xp - 1)) * Y + gyo) * Z + gzo) * 3 + co] = done;
             a_prev = a_cur + c1;
             a_cur = bco + c0;
+            if constexpr (OPT == 2) {   // the second output of this thread, the same way
+                float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+                if (inside && outthr1) {
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int dz = 0; dz < 3; ++dz) {
+                            const float* pr = P + ((vy1 + dy) * MH_HZ + vz1 + dz) * 81 + (dy * 3 + dz) * 3 + co1;
+                            d0 += pr[0];
+                            d1 += pr[27];
+                            d2 += pr[54];
+                        }
+                }
+                const float done1 = a_prev1 + d2;
+                if (ook1 && xp - 1 >= xs && xp - 1 < xe)
+                    out[((((size_t)b * X + (xp - 1)) * Y + gyo1) * Z + gzo1) * 3 + co1] = done1;
+                a_prev1 = a_cur1 + d1;
+                a_cur1 = bco1 + d0;
+            }
             if (pbufs == 1) __syncthreads();  // single P buffer (wide fp32x3 inputs): gather done before the next plane lands
         };
         if constexpr (DEEP) {
@@ -2866,7 +2898,8 @@ extern "C" int mmr_conv3d_k3_cout3_fwd(const void* in, const float* w_keras, con
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipSuccess;
-        const void* ks[10] = {reinterpret_cast<const void*>(flow_head_kernel<false>), reinterpret_cast<const void*>(flow_head_kernel<true>),
+        const void* ks[11] = {reinterpret_cast<const void*>(flow_head_march_kernel<false, 8, 16>),
+                             reinterpret_cast<const void*>(flow_head_kernel<false>), reinterpret_cast<const void*>(flow_head_kernel<true>),
                              reinterpret_cast<const void*>(flow_head_march_kernel<true, 4>),
                              reinterpret_cast<const void*>(flow_head_march_kernel<true, 2>),
                              reinterpret_cast<const void*>(flow_head_march_kernel<true, 1>),
@@ -2875,13 +2908,40 @@ extern "C" int mmr_conv3d_k3_cout3_fwd(const void* in, const float* w_keras, con
                              reinterpret_cast<const void*>(flow_head_march_kernel<false, 8>),
                              reinterpret_cast<const void*>(flow_head_march_kernel<false, 4>),
                              reinterpret_cast<const void*>(flow_head_march_kernel<false, 2>)};
-        for (int i = 0; i < 10 && e == hipSuccess; ++i)
+        for (int i = 0; i < 11 && e == hipSuccess; ++i)
             e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
         attr_set = true;
     }
-    // double-buffered P plane when it fits, else a single buffer (one more barrier per plane): fp32x3 at Cin = 256
     const int lds_w = npl * (Cin / 8) * 96 * 16;
+    // bf16 with 256 input channels (BASELINE configs[1]): 16 x 16-row patches, eight waves, one P plane (see the kernel's HY)
+    if (dtype == MMR_DT_BF16 && Cin == 256 && Y >= 28 && lds_w + 16 * MH_HZ * 81 * 4 <= 160 * 1024) {
+        constexpr int HY16 = 16;
+        const int nty = (Y + (HY16 - 2) - 1) / (HY16 - 2), ntz = (Z + MH_TZ - 1) / MH_TZ;
+        const int64_t tyz = (int64_t)B * nty * ntz;
+        const int gmax = 256;
+        int nseg = 1;
+        {
+            int64_t best = -1;
+            const int smax = (X + 3) / 4;
+            for (int c = 1; c <= smax && c <= 64; ++c) {
+                const int sl = (X + c - 1) / c;
+                const int ns = (X + sl - 1) / sl;
+                const int64_t per = (tyz * ns + gmax - 1) / gmax;
+                const int64_t cost = per * (sl + 2);
+                if (best < 0 || cost < best) { best = cost; nseg = ns; }
+            }
+        }
+        const int seglen = (X + nseg - 1) / nseg;
+        nseg = (X + seglen - 1) / seglen;
+        const int64_t nt = tyz * nseg;
+        if (nt > 0x7fffffff) return MMR_EINVAL;
+        const int grid = nt < gmax ? (int)nt : gmax;
+        hipLaunchKernelGGL((flow_head_march_kernel<false, 8, HY16>), dim3(grid), dim3(HY16 * 32), lds_w + HY16 * MH_HZ * 81 * 4,
+                           as_stream(stream), (const char*)in, w_keras, bias, out, B, X, Y, Z, Cin, nseg, seglen, nty, ntz, (int)nt, 1);
+        return check_launch();
+    }
+    // double-buffered P plane when it fits, else a single buffer (one more barrier per plane): fp32x3 at Cin = 256
     int pbufs = (lds_w + 2 * MH_ROWS * 81 * 4 <= 160 * 1024) ? 2 : 1;
     // narrow inputs: two workgroups per CU with a single P buffer each (one more barrier per plane, but a second workgroup
     // to cover it: 0.52 -> 0.40 ms for fp32x3 at 160^3 x 64)

@@ -161,7 +161,10 @@ def test_maxpool(dev, dtype):
 @pytest.mark.parametrize("shape,Cin,mode", [((5, 9, 7), 64, "bf16"), ((8, 8, 16), 256, "bf16"), ((2, 4, 8), 32, "fp32x3"),
                                             ((6, 7, 19), 64, "fp32x3"), ((4, 4, 8), 128, "fp32x3"),
                                             ((20, 13, 30), 64, "bf16"), ((17, 6, 14), 32, "fp32x3"),  # several x segments / tiles
-                                            ((9, 7, 15), 256, "fp32x3")])  # single P buffer
+                                            ((9, 7, 15), 256, "fp32x3"),  # single P buffer
+                                            # bf16, 256 channels, Y >= 28: the 16-row patches (14 x 14 outputs, eight waves, two outputs per
+                                            # thread): exact, ragged in y and z, several x segments and patches
+                                            ((13, 28, 14), 256, "bf16"), ((6, 30, 17), 256, "bf16"), ((21, 45, 33), 256, "bf16")])
 def test_flow_head_folded_taps(dev, shape, Cin, mode):
     """Flow head with the taps folded into the GEMM N axis vs the C oracle."""
     import mmr
