@@ -49,19 +49,49 @@ def _free_port():
         return sk.getsockname()[1]
 
 
+def visible_gpu_count():
+    """GPUs this process's children will see, WITHOUT a HIP / torch.cuda call in this process (the launcher parent must not
+    own a GPU runtime while it only polls children): the HIP_/ROCR_/CUDA_VISIBLE_DEVICES list if one is set, else the KFD
+    topology's GPU nodes (/sys/class/kfd/kfd/topology/nodes/*/properties with simd_count > 0), else a throw-away child
+    that asks torch.  Returns (count, how)."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            ids = [x for x in v.split(",") if x.strip() != ""]
+            if var != "ROCR_VISIBLE_DEVICES" or ids:
+                return len(ids), var
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        n = 0
+        for d in os.listdir(base):
+            props = dict(ln.split()[:2] for ln in open(os.path.join(base, d, "properties")) if len(ln.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        if n > 0:
+            return n, "kfd topology"
+    except (OSError, ValueError):
+        pass
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True,
+                             timeout=300, text=True)
+        return int(out.stdout.strip().splitlines()[-1]), "child process"
+    except Exception:
+        return 0, "unknown"
+
+
 def launch_ranks(n, argv):
     """Parent of an N-rank run started WITHOUT torchrun.  Nothing here initialises HIP (torch is imported, no
-    torch.cuda call is made): the children are fresh interpreters, not re-execs of a process that owns a GPU context."""
+    torch.cuda call is made -- the device count comes from the environment / sysfs, see visible_gpu_count): the children
+    are fresh interpreters, not re-execs of a process that owns a GPU context."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("mmr_build", os.path.join(ROOT, "multimodal-registration_amd", "build.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
     b.build()   # once, before the ranks start (they would otherwise queue on the build lock)
-    # counting devices does not create a GPU context on this image; an nccl group with two ranks on one device would
-    # hang in its first collective until the launch timeout instead of failing
-    ndev = torch.cuda.device_count()
+    # an nccl group with two ranks on one device would hang in its first collective until the launch timeout instead of failing
+    ndev, how = visible_gpu_count()
     if os.environ.get("MMR_BENCH_BACKEND", "nccl") == "nccl" and ndev < n:
-        sys.stderr.write(f"bench.py: --gpus {n} needs {n} visible GPUs, torch.cuda.device_count() = {ndev} "
+        sys.stderr.write(f"bench.py: --gpus {n} needs {n} visible GPUs, found {ndev} (from {how}) "
                          f"(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES = {os.environ.get('HIP_VISIBLE_DEVICES')!r} / "
                          f"{os.environ.get('ROCR_VISIBLE_DEVICES')!r}); for a rehearsal of the N-rank flow on fewer cards set "
                          "MMR_BENCH_BACKEND=gloo\n")
@@ -399,6 +429,9 @@ def main():
     ap.add_argument("--bwd", default=None, choices=["bf16"], help="train: opt-in bf16-product backward (not the default)")
     ap.add_argument("--no-render-ahead", action="store_true",
                     help="train: render each step's image pair inside the step instead of one step ahead on the generator stream")
+    ap.add_argument("--no-early-reduce", action="store_true",
+                    help="train: ONE gradient all-reduce after the backward instead of the two-bucket form whose first bucket "
+                         "runs under the encoder's backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="infer: skip the training leg reported under \"secondary\"")
     args = ap.parse_args()
@@ -452,8 +485,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def setup(wl, dtype_arg, feats_arg, shape_arg):
+    def setup(wl, dtype_arg, feats_arg, shape_arg, early_reduce=None):
         extra = {}
+        if early_reduce is None:
+            early_reduce = not args.no_early_reduce
         if wl == "infer":
             shape = tuple(shape_arg or (160, 160, 192))
             feats = feats_arg or 256
@@ -467,6 +502,7 @@ def main():
                         f"enc/dec={feats}, int_steps=5, svf/int_res=2, inputs resident in HBM, 1 pair/step")
             par = f"replicas x{world} (single-pair inference does not shard)"
             cpu_fn = lambda: cpu_baseline_infer(enc, dec, shape, mov, fix)
+            extra.update(model=model, mov=mov, fix=fix)
         elif wl == "cascade":
             # BASELINE configs[3]: two-step cascade of bids_two_steps_registration.py:311-325,484-499 on one pair --
             # model 1 on (moving, fixed), model 2 on (moved_1, fixed), compose the two half-res fields, rescale x2, warp
@@ -508,7 +544,9 @@ def main():
             model = mmr.networks.VxmDense(shape, nb_unet_features=(enc, dec), int_steps=5, int_resolution=2, svf_resolution=2,
                                           compute_dtype=dtype, device=dev, seed=0)
             tr = training.SynthMorphTrainer(model, g1, g2, reg_param=1.0, optimizer=training.Adam(1e-4),
-                                            world_size=world, rank=rank, backward_precision=args.bwd)
+                                            world_size=world, rank=rank, backward_precision=args.bwd, early_reduce=early_reduce)
+            tr.time_encoder_bwd = True
+            extra["trainer"] = tr
             src = torch.from_numpy(maps[0][None, ..., None]).to(dev)
             trg = src  # config/config.json: same_subj true -- the pair is two generator renderings of one label map
             # as SynthMorphTrainer.fit runs it: the next step's two renderings queued on the generator stream behind this step
@@ -516,8 +554,8 @@ def main():
             workload = (f"train_synthmorph.py step (BASELINE configs[2]): {shape[0]}^3, enc/dec={feats}, {L} labels, Dice + "
                         f"Grad-l2(reg 1), same_subj pairs, generators + fwd + bwd + all-reduce + Adam, 1 pair per GPU, label maps resident in HBM"
                         + (" [OPT-IN bf16-product backward]" if args.bwd else ""))
-            par = (f"dp{world} (batch sharded by rank, SUM all-reduce of {model._flat.numel() * 4 / 1e6:.1f} MB over RCCL in two buckets, "
-                   "the decoder's under the encoder's backward)")
+            par = (f"dp{world} (batch sharded by rank, SUM all-reduce of {model._flat.numel() * 4 / 1e6:.1f} MB over RCCL "
+                   + ("in two buckets, the decoder's under the encoder's backward)" if early_reduce else "in one bucket after the backward)"))
             cpu_fn = lambda: cpu_baseline_train(enc, dec, shape, L, maps[0])
             extra["allreduce_bytes"] = model._flat.numel() * 4
         else:  # ncc
@@ -529,8 +567,12 @@ def main():
             flow = torch.randn((1,) + shape + (3,), generator=g).to(dev)
 
             def step():
-                return mmr.ops.ncc_loss(I, J, 9) + mmr.ops.bending_energy(flow)
+                # the total loss assembled in place: NCC's reduction finishes inside its kernel (last-workgroup finalize), the
+                # bending kernel adds its mean onto the same [B] tensor -- two launches per step, no finalize / add launches
+                loss = mmr.ops.ncc_loss(I, J, 9)
+                return mmr.ops.bending_energy(flow, out=loss)
             workload = f"local NCC(win 9) + bending energy forward on {shape[0]}^3 fp32 (BASELINE configs[4])"
+            extra.update(I=I, J=J, flow=flow)
             par = f"replicas x{world}"
             cpu_fn = lambda: cpu_baseline_ncc(I, J, flow)
             extra["algorithmic_bytes_per_step"] = int(np.prod(shape)) * 4 * 5
@@ -555,14 +597,28 @@ def main():
         assert torch.isfinite(last).all()
         return dt, prof
 
-    def dist_info(fam, steps):
+    def dist_info(fam, steps, w=None):
         d = {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
              "backend": dist.get_backend() if dist.is_initialized() else None, "launched_by": launched,
              "visible_devices": torch.cuda.device_count(), "rank_devices": rank_devices}
+        tr = w["extra"].get("trainer") if w else None
+        if tr is not None:
+            d["early_reduce"] = bool(tr.early_reduce)
+            total = int(tr.gflat.numel() * 4)
+            early = total - int(tr.goff[2 * (tr._bucket_li + 1)]) * 4 if tr.early_reduce else 0
+            d["allreduce_bytes_total"] = total
+            d["early_bucket_bytes"] = early          # reduced asynchronously under the encoder's backward (never inside the timed region below)
+            ev = tr.encoder_bwd_events[-steps:] if tr.encoder_bwd_events else []
+            if ev:   # HIP events from the point where bucket 1 starts (or would start) to the end of the backward walk
+                d["encoder_bwd_ms"] = round(sum(a.elapsed_time(b) for a, b in ev) / len(ev), 4)
+            tr.encoder_bwd_events = []
         ar = fam.get("comm:allreduce_grads") if fam else None
         if ar:
-            d["allreduce_ms_per_step"] = round(ar[0] / max(steps, 1), 4)
-            d["allreduce_bytes"] = int(ar[1] / max(ar[2], 1))
+            # what the step WAITS for: with two buckets the encoder's bucket + the wait on the early handle; one bucket: all of it
+            d["allreduce_exposed_ms_per_step"] = round(ar[0] / max(steps, 1), 4)
+            d["allreduce_bytes_in_exposed_region"] = int(ar[1] / max(ar[2], 1))
+            d["allreduce_note"] = ("exposed = HIP events around the late bucket and the wait for the early one; the early bucket "
+                                   "overlaps the encoder's backward, so bytes / exposed time is NOT a bus bandwidth")
         return d
 
     def measure(w, steps, warmup):
@@ -582,21 +638,94 @@ def main():
         barrier()
         res["ms_per_step_without_events"] = (time.perf_counter() - t0) / steps * 1e3
         if w["wl"] == "ncc" and roof:
-            roof["whole_step_GBps"] = w["extra"]["algorithmic_bytes_per_step"] / (dt / steps) / 1e9   # incl. finalize launches
+            roof["whole_step_GBps"] = w["extra"]["algorithmic_bytes_per_step"] / (dt / steps) / 1e9   # incl. launch gaps
+            # configs[4] is a LOSS: its backward (d loss / d I, d J and d energy / d flow) timed with HIP events on the launch
+            # stream, K steps after a warm-up; algorithmic bytes = I, J read + dI, dJ written, the field read + its gradient written
+            try:
+                I_, J_, f_ = w["extra"]["I"], w["extra"]["J"], w["extra"]["flow"]
+                nv = float(I_.numel())
+                evs = []
+                for i in range(warmup + steps):
+                    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                    e[0].record()
+                    mmr.ops.ncc_loss_bwd(I_, J_)
+                    e[1].record()
+                    mmr.ops.bending_energy_bwd(f_)
+                    e[2].record()
+                    if i >= warmup:
+                        evs.append(e)
+                torch.cuda.synchronize()
+                t_ncc = float(np.mean([a.elapsed_time(b) for a, b, _ in evs]))
+                t_ben = float(np.mean([b.elapsed_time(c) for _, b, c in evs]))
+                b_ncc, b_ben = 4 * nv * 4, 6 * nv * 4
+                res["bwd"] = {"ms_per_step": t_ncc + t_ben, "steps": steps, "warmup": warmup,
+                              "ncc_bwd": {"ms": t_ncc, "algorithmic_bytes": b_ncc, "GBps": b_ncc / (t_ncc * 1e-3) / 1e9,
+                                          "frac_of_hbm_peak": b_ncc / (t_ncc * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                          "note": "two-pass form: zy box sums, x box + coefficients, x gradient (7 launches; the window sums exist as fields)"},
+                              "bending_bwd": {"ms": t_ben, "algorithmic_bytes": b_ben, "GBps": b_ben / (t_ben * 1e-3) / 1e9,
+                                              "frac_of_hbm_peak": b_ben / (t_ben * 1e-3) / 1e9 / PEAK_HBM_GBS},
+                              "fwd_plus_bwd_ms": res["ms_per_step_without_events"] + t_ncc + t_ben}
+            except Exception as e:
+                res["bwd"] = {"error": f"{type(e).__name__}: {e}"}
         if roof:
             res["roofline"] = roof
         if fam_ms:
             res["kernel_family_ms_per_step"] = fam_ms
-        res["dist"] = dist_info(fam, steps)
+        res["dist"] = dist_info(fam, steps, w)
         return res
+
+    def measure_predict(model, mov, fix, fwd_ms, calls=5, warm=2):
+        from mmr import hostio
+        a = mov.detach().cpu().double().numpy()   # what get_fdata() hands 3d_reg.py: float64, C-contiguous
+        b = fix.detach().cpu().double().numpy()
+        for _ in range(warm):
+            model.predict([a, b])
+        torch.cuda.synchronize()
+        ts, ins, outs = [], [], []
+        for _ in range(calls):
+            t0 = time.perf_counter()
+            moved, field = model.predict([a, b])
+            ts.append((time.perf_counter() - t0) * 1e3)
+            ins.append(dict(hostio.LAST.get("in", {})))
+            outs.append(dict(hostio.LAST.get("out", {})))
+        assert moved.dtype == np.float32 and field.dtype == np.float32 and np.isfinite(moved).all()
+        mean = lambda rows, k: round(float(np.mean([r.get(k, 0.0) for r in rows])), 3)
+        # the two directions alone (same code, nothing else queued): H2D = pin + cast kernel over PCIe, D2H = copy kernel + NumPy copy
+        h2d, d2h = [], []
+        y, f = model.forward(mov, fix)["y_source"], model.references.preint_flow
+        torch.cuda.synchronize()
+        for _ in range(calls):
+            t0 = time.perf_counter()
+            hostio.pair_to_device([a, b], dev)
+            h2d.append((time.perf_counter() - t0) * 1e3)
+            t0 = time.perf_counter()
+            hostio.many_to_host([y, f])
+            d2h.append((time.perf_counter() - t0) * 1e3)
+        return {"ms_per_pair": round(float(np.mean(ts)), 3), "ms_per_pair_median": round(float(np.median(ts)), 3),
+                "calls": calls, "warmup": warm, "runs_ms": [round(t, 2) for t in ts],
+                "input": "two float64 NumPy volumes [1,160,160,192,1] (39.3 MB each)", "output": "fp32 NumPy moved volume + half-res field",
+                "forward_ms_device_resident": round(fwd_ms, 3), "overhead_ms": round(float(np.mean(ts)) - fwd_ms, 3),
+                "h2d_ms": round(float(np.median(h2d)), 3), "d2h_ms": round(float(np.median(d2h)), 3),
+                "host_convert_ms": mean(ins, "host_copy_ms"),      # 0 when the caller's pages are pinned in place: the cast runs on the GPU
+                "host_pin_ms": mean(ins, "pin_ms"), "h2d_kernel_ms": mean(ins, "transfer_ms"),
+                "d2h_numpy_copy_ms": mean(outs, "host_copy_ms"), "mode_in": ins[-1].get("mode"), "mode_out": outs[-1].get("mode"),
+                "reference": "3d_reg.py:310-314"}
 
     w = setup(args.workload, args.dtype, args.features, args.shape)
     res = measure(w, args.steps, args.warmup)
+    w_keep_cpu = w["cpu_fn"]
     if forced and world == 1:
         res["config"]["collectives"] = "rccl (forced single-rank group)" if backend == "nccl" else backend + " (forced)"
     cpu_fns = [("cpu_baseline", w["cpu_fn"], res)]
 
     extras = args.workload == "infer" and not args.no_secondary
+    if args.workload == "infer" and rank == 0:
+        # The latency north_star names: model.predict([moving, fixed]) as 3d_reg.py:310-314 calls it -- float64 NumPy volumes in
+        # (nibabel get_fdata()), NumPy out -- PCIe and host work included.  Never part of `value`.
+        try:
+            res["predict"] = measure_predict(w["extra"]["model"], w["extra"]["mov"], w["extra"]["fix"], res["ms_per_step_without_events"])
+        except Exception as e:
+            res["predict"] = {"error": f"{type(e).__name__}: {e}"}
     if extras and w["dtype"] == "bf16":
         # the same workload at the drop-in API's default arithmetic (fp32x3: fp32 tensors, bf16 hi/lo-split products,
         # the 1e-4-grade path of north_star) -- reported beside the bf16 headline, never part of `value`
@@ -610,11 +739,22 @@ def main():
         except Exception as e:
             res["same_workload_fp32x3"] = {"error": f"{type(e).__name__}: {e}"}
     if extras:
+        # BASELINE configs[3] in the driver's hands: the two-step cascade on the same pair, 3 steps after 1 warm-up
+        try:
+            w.clear()
+            torch.cuda.empty_cache()
+            wc = setup("cascade", None, args.features, args.shape)
+            kc = 3
+            dtc, _ = timed(wc["step"], 1, kc)
+            res["cascade"] = {"ms_per_pair": dtc / kc * 1e3, "value": world * kc / dtc, "unit": "pairs/s", "steps": kc, "warmup": 1,
+                              "dtype": wc["dtype"], "workload": wc["workload"]}
+            del wc
+            torch.cuda.empty_cache()
+        except Exception as e:
+            res["cascade"] = {"error": f"{type(e).__name__}: {e}"}
+    if extras:
         # the other half of BASELINE.json's metric (configs[2]): the data-parallel training step with the SAME K / W,
         # its own roofline / dist / cpu_baseline; outside the timed region above, never part of `value`.
-        w_keep_cpu = w["cpu_fn"]
-        del w
-        torch.cuda.empty_cache()
         try:
             w2 = setup("train", None, None, None)
             sec = measure(w2, args.steps, args.warmup)
@@ -624,21 +764,40 @@ def main():
             # step without digging: whole-job pairs/s (= N x 1 pair per step / max-over-ranks step time) and the all-reduce
             res["dp_training"] = {"value": sec["value"], "unit": sec["unit"], "ms_per_step": sec["ms_per_step"], "n_gpus": world,
                                   "dtype": sec["dtype"], "scaling": "weak (1 pair per GPU)",
-                                  "allreduce_ms_per_step": sec["dist"].get("allreduce_ms_per_step"),
-                                  "allreduce_bytes": sec["dist"].get("allreduce_bytes", w2["extra"].get("allreduce_bytes")),
+                                  "early_reduce": sec["dist"].get("early_reduce"),
+                                  "allreduce_exposed_ms_per_step": sec["dist"].get("allreduce_exposed_ms_per_step"),
+                                  "allreduce_bytes_total": sec["dist"].get("allreduce_bytes_total", w2["extra"].get("allreduce_bytes")),
+                                  "early_bucket_bytes": sec["dist"].get("early_bucket_bytes"),
+                                  "encoder_bwd_ms": sec["dist"].get("encoder_bwd_ms"),
+                                  "ms_per_step_single_bucket": None, "encoder_bwd_ms_single_bucket": None,
                                   "backend": sec["dist"].get("backend")}
             cpu_fns.append(("cpu_baseline", w2["cpu_fn"], sec))
-            del w2
+            w2.clear()
             torch.cuda.empty_cache()
-            try:   # the same step in the reference's own arithmetic (train_synthmorph.py:308 trains in fp32): exact-fp32 MFMA
-                w4 = setup("train", "fp32", None, None)
-                k4 = max(2, min(args.steps, 3))
-                dt4, _ = timed(w4["step"], 1, k4)
-                sec["same_workload_fp32"] = {"dtype": "fp32", "ms_per_step": dt4 / k4 * 1e3, "value": world * k4 / dt4,
-                                             "unit": "pairs/s", "steps": k4, "warmup": 1}
-                del w4
-            except Exception as e:
-                sec["same_workload_fp32"] = {"error": f"{type(e).__name__}: {e}"}
+            if use_dist and not args.no_early_reduce:
+                # the A/B the first multi-GPU record needs: the same step with ONE all-reduce after the backward (3 steps after a
+                # warm-up), and the encoder-backward segment's HIP-event time without a collective in flight beside it
+                w5 = setup("train", None, None, None, early_reduce=False)
+                k5 = 3
+                dt5, prof5 = timed(w5["step"], 1, k5)
+                _, _, fam5 = roofline_from_profile(prof5, k5, "traffic_train.json")
+                d5 = dist_info(fam5, k5, w5)
+                res["dp_training"].update({"ms_per_step_single_bucket": dt5 / k5 * 1e3, "encoder_bwd_ms_single_bucket": d5.get("encoder_bwd_ms"),
+                                           "allreduce_exposed_ms_per_step_single_bucket": d5.get("allreduce_exposed_ms_per_step")})
+                w5.clear()
+                torch.cuda.empty_cache()
+            if world == 1:
+                # the same step in the reference's own arithmetic (train_synthmorph.py:308 trains in fp32): exact-fp32 MFMA.  One
+                # rank only: a leg whose failure (OOM) on one rank would leave the others in a collective has no place in an N-rank line
+                try:
+                    w4 = setup("train", "fp32", None, None)
+                    k4 = max(2, min(args.steps, 3))
+                    dt4, _ = timed(w4["step"], 1, k4)
+                    sec["same_workload_fp32"] = {"dtype": "fp32", "ms_per_step": dt4 / k4 * 1e3, "value": world * k4 / dt4,
+                                                 "unit": "pairs/s", "steps": k4, "warmup": 1}
+                    w4.clear()
+                except Exception as e:
+                    sec["same_workload_fp32"] = {"error": f"{type(e).__name__}: {e}"}
         except Exception as e:  # the headline line above must survive a failure of the extra leg
             res["secondary"] = {"error": f"{type(e).__name__}: {e}"}
         cpu_fns[0] = ("cpu_baseline", w_keep_cpu, res)

@@ -214,6 +214,16 @@ int mmr_ncc_fwd_f32(const float* I, const float* J, float* out, void* ws,
 int64_t mmr_bending_ws_bytes(int B, int X, int Y, int Z);
 int mmr_bending_fwd_f32(const float* flow, float* out, void* ws,
                         int B, int X, int Y, int Z, void* stream);
+/* The two losses with the final reduction INSIDE the kernel (no second launch): out[b] = (accumulate ? out[b] : 0) + scale * loss_b,
+ * so that `NCC + lambda * bending` lands in one tensor from two launches.  The workgroup that finishes last adds the per-workgroup
+ * partials in index order (bitwise reproducible, the same sum as the two-launch entry points).  `ticket`: one 32-bit word of
+ * DEVICE memory per concurrently running call; it must be ZERO when the call is issued and is zero again when its kernels have
+ * finished (calls ordered on one stream may share it). */
+int mmr_ncc_fwd_ticket_f32(const float* I, const float* J, float* out, void* ws, unsigned* ticket,
+                           int B, int X, int Y, int Z, int win, float eps, int ncc_form, float scale, int accumulate,
+                           void* stream);
+int mmr_bending_fwd_ticket_f32(const float* flow, float* out, void* ws, unsigned* ticket,
+                               int B, int X, int Y, int Z, float scale, int accumulate, void* stream);
 /* Backward of the two losses (SURVEY 8b families ncc_bwd / bending_bwd): gradients of out[b] scaled by gout[b]
  * (gout == NULL: 1).  NCC: dI and/or dJ [B,X,Y,Z] (either may be NULL); workspace mmr_ncc_bwd_ws_bytes. */
 int64_t mmr_ncc_bwd_ws_bytes(int B, int X, int Y, int Z);
@@ -370,6 +380,25 @@ int mmr_joint_hist_f64(const double* a, const double* b, const double* edges_a, 
 /* out6 = {sum m[f==1], sum m[f==0], #f==1, #f==0, sum m, n} (eval_reg_on_sc_seg.py:80-93) */
 int64_t mmr_overlap_ws_bytes(void);
 int mmr_overlap_sums_f64(const double* fixed, const double* moved, double* out6, void* ws, int64_t n, void* stream);
+
+/* ---- host <-> device hand-over of model.predict([moving, fixed]) (3d_reg.py:310-314: nibabel get_fdata() float64
+ * arrays in, NumPy arrays out).  The only entry points that touch HOST memory; they exist so that the host does no
+ * arithmetic and no write into uncached memory on the way in:
+ *   mmr_host_alloc      pinned, device-mapped staging memory; cached != 0 = CPU write-back pages (hipHostMallocNonCoherent)
+ *   mmr_host_register   pins the caller's own buffer for the duration of a call and returns its device-side address
+ *   mmr_cast_to_f32     kernel: n elements of MMR_HOST_* at src (pinned host OR device memory) -> fp32 in HBM, the
+ *                       dtype conversion of Keras' predict and the H2D transfer in one pass over PCIe
+ *   mmr_copy_to_host    kernel: device -> pinned host memory, bytes % 4 == 0                                          */
+#define MMR_HOST_F64 0
+#define MMR_HOST_F32 1
+#define MMR_HOST_U8 2
+#define MMR_HOST_I16 3
+int mmr_host_alloc(void** out, int64_t bytes, int cached);
+int mmr_host_free(void* p);
+int mmr_host_register(void* p, int64_t bytes, void** dev_ptr);
+int mmr_host_unregister(void* p);
+int mmr_cast_to_f32(const void* src, float* dst, int64_t n, int src_dtype, void* stream);
+int mmr_copy_to_host(const void* src_dev, void* dst_host, int64_t bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -60,6 +60,8 @@ SIGNATURES = {
     "mmr_grad_l2_fwd_f32": (I, [P, P, P, I, I, I, I, I, F, P]),
     "mmr_ncc_ws_bytes": (c_int64, [I, I, I, I]),
     "mmr_ncc_fwd_f32": (I, [P, P, P, P, I, I, I, I, I, F, I, P]),
+    "mmr_ncc_fwd_ticket_f32": (I, [P, P, P, P, P, I, I, I, I, I, F, I, F, I, P]),
+    "mmr_bending_fwd_ticket_f32": (I, [P, P, P, P, I, I, I, I, F, I, P]),
     "mmr_bending_ws_bytes": (c_int64, [I, I, I, I]),
     "mmr_bending_fwd_f32": (I, [P, P, P, I, I, I, I, P]),
     "mmr_philox_normal_f32": (I, [P, c_int64, c_uint64, c_uint32, F, F, P]),
@@ -122,6 +124,12 @@ SIGNATURES = {
     "mmr_joint_hist_f64": (I, [P, P, P, P, P, c_int64, I, P]),
     "mmr_overlap_ws_bytes": (c_int64, []),
     "mmr_overlap_sums_f64": (I, [P, P, P, P, c_int64, P]),
+    "mmr_host_alloc": (I, [P, c_int64, I]),
+    "mmr_host_free": (I, [P]),
+    "mmr_host_register": (I, [P, c_int64, P]),
+    "mmr_host_unregister": (I, [P]),
+    "mmr_cast_to_f32": (I, [P, P, c_int64, I, P]),
+    "mmr_copy_to_host": (I, [P, P, c_int64, P]),
 }
 
 

@@ -14,7 +14,7 @@ import subprocess
 import tempfile
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["api.hip", "tail.hip", "losses.hip", "conv3d.hip", "train.hip", "synth.hip", "eval.hip"]
+SOURCES = ["api.hip", "tail.hip", "losses.hip", "conv3d.hip", "train.hip", "synth.hip", "eval.hip", "hostio.hip"]
 LIB = os.path.join(CSRC, "libmmr_hip.so")
 STAMP = LIB + ".srchash"
 LOCK = os.path.join(CSRC, ".build.lock")

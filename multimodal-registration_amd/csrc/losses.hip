@@ -26,6 +26,49 @@ __device__ __forceinline__ double block_sum(double v, double* sh /* >= 4 doubles
     return r;
 }
 
+// In-kernel finalize of a per-workgroup-partials reduction (no second launch): every workgroup stores its double partial, then
+// takes a ticket; the workgroup that draws the LAST ticket sums all partials in index order (the same order whichever
+// workgroup that is -> bitwise reproducible, like mean_final_kernel) and writes out[b] = (+= when accumulate) sign * sum / denom.
+// `ticket` must be ZERO when the kernel starts and is zero again when it ends (one ticket word per concurrently running call).
+// The fences are at agent scope: partials written through another XCD's L2 are written back / this XCD's copies invalidated.
+struct TicketFin {
+    unsigned* ticket;   // nullptr: no in-kernel finalize (the caller launches mean_final_kernel)
+    float* out;
+    int nout;           // batch items covered by this launch: part[b * nb + k], k < nb
+    long long nb;
+    double denom;
+    float sign;         // -1 for -mean(cc), +1 for the bending mean; times the caller's scale
+    int accumulate;
+};
+
+// `scratch`: >= 256 B of shared memory, 8-B aligned, that no thread of the workgroup still reads or writes (the kernels pass
+// their own, no longer needed, tile: a static __shared__ here would push the 80-KB NCC tile past two workgroups per CU)
+__device__ __forceinline__ void ticket_finalize(const double* part, const TicketFin& f, char* scratch)
+{
+    if (f.ticket == nullptr) return;
+    int& s_last = *reinterpret_cast<int*>(scratch);
+    double* s_red = reinterpret_cast<double*>(scratch + 64);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();                                         // this workgroup's partial is visible device-wide ...
+        const unsigned t = atomicAdd(f.ticket, 1u);              // ... before its ticket is
+        s_last = (t == gridDim.x * gridDim.y - 1u) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    for (int b = 0; b < f.nout; ++b) {
+        double a = 0.0;
+        for (long long k = threadIdx.x; k < f.nb; k += blockDim.x) a += __builtin_nontemporal_load(part + (long long)b * f.nb + k);
+        const double r = block_sum(a, s_red);
+        if (threadIdx.x == 0) {
+            const float v = (float)((double)f.sign * r / f.denom);
+            f.out[b] = f.accumulate ? f.out[b] + v : v;
+        }
+    }
+    if (threadIdx.x == 0) atomicExch(f.ticket, 0u);
+}
+
 // ------------------------------ Dice ------------------------------------ //
 // y [B, nvox, L]; grid (nblk, B); threads >= T=(256/L)*L idle so that a
 // thread's label is fixed while the block still reads contiguous runs.
@@ -220,6 +263,41 @@ __device__ __forceinline__ NccTerms ncc_terms(const float* S, float ws, float ep
     return t;
 }
 
+// Forward only: the cc of FOUR windows from their box sums S[k][0..4] = (sum I, sum J, sum I^2, sum J^2, sum IJ), two windows per
+// packed instruction (v_pk_mul / v_pk_fma), with the window means eliminated algebraically:
+//   cross = S4 - S0 S1 / ws,  Iv = S2 - S0^2 / ws,  Jv = S3 - S1^2 / ws
+// (the same quantities as ncc_terms' uI / uJ form, A8: 6 packed + 1 reciprocal per pair instead of ~25 scalar per window).
+typedef float f2_t __attribute__((ext_vector_type(2)));
+template <int FORM>
+__device__ __forceinline__ float ncc_cc4_sum(const float (&S)[4][5], float eps)
+{
+    const f2_t k = {1.0f / 729.f, 1.0f / 729.f};
+    f2_t tot = {0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f2_t s0 = {S[2 * h][0], S[2 * h + 1][0]}, s1 = {S[2 * h][1], S[2 * h + 1][1]}, s2 = {S[2 * h][2], S[2 * h + 1][2]},
+                   s3 = {S[2 * h][3], S[2 * h + 1][3]}, s4 = {S[2 * h][4], S[2 * h + 1][4]};
+        const f2_t t0 = s0 * k, t1 = s1 * k;
+        f2_t cross = __builtin_elementwise_fma(-t0, s1, s4);
+        f2_t iv = __builtin_elementwise_fma(-t0, s0, s2);
+        f2_t jv = __builtin_elementwise_fma(-t1, s1, s3);
+        if (FORM == MMR_NCC_CLAMPED) {      // tf.maximum(., eps) on all three, cc = (cross / Iv) (cross / Jv)
+            cross = f2_t{fmaxf(cross.x, eps), fmaxf(cross.y, eps)};
+            iv = f2_t{fmaxf(iv.x, eps), fmaxf(iv.y, eps)};
+            jv = f2_t{fmaxf(jv.x, eps), fmaxf(jv.y, eps)};
+            const f2_t den = iv * jv;
+            const f2_t rc = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+            tot = __builtin_elementwise_fma(cross * cross, rc, tot);
+        } else {
+            const f2_t e2 = {eps, eps};
+            const f2_t den = __builtin_elementwise_fma(iv, jv, e2);
+            const f2_t rc = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+            tot = __builtin_elementwise_fma(cross * cross, rc, tot);
+        }
+    }
+    return tot.x + tot.y;
+}
+
 constexpr int NCC_ZOUT = 56;   // outputs per wave along z (lanes 4..59)
 constexpr int NCC_ROWS = 32;   // output rows per wave strip
 
@@ -378,7 +456,7 @@ __device__ __forceinline__ float box9_shr(float v)    // lane l: v[l-8] + ... + 
 
 __global__ void __launch_bounds__(NF_WAVES * 64)
 ncc_fused_kernel(const float* __restrict__ I, const float* __restrict__ J, double* __restrict__ part, int X, int Y, int Z,
-                 int xseg, int nxs, int nyt, int nzt, float eps, int form)
+                 int xseg, int nxs, int nyt, int nzt, float eps, int form, const TicketFin fin)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* zb = reinterpret_cast<float*>(smem);            // [2][NF_ROWS][5][64]
@@ -434,7 +512,15 @@ ncc_fused_kernel(const float* __restrict__ I, const float* __restrict__ J, doubl
 #pragma unroll
         for (int q = 0; q < 5; ++q) W[r][q] = 0.f;
     int slot = 0;                                           // ring slot of plane s = s % 9: the slot the leaving plane holds
+    // consecutive all-zero planes per row (see ncc_fused4_kernel): between two exact re-sums a window that has moved from bright
+    // tissue into a zero background keeps a rounding residual; with nine zero planes in the ring the sums ARE zero
+    int zrun[NF_RPW];
+#pragma unroll
+    for (int r = 0; r < NF_RPW; ++r) zrun[r] = 0;
     for (int s = 0; s < nstep; ++s) {
+#pragma unroll
+        for (int r = 0; r < NF_RPW; ++r)
+            zrun[r] = (((__float_as_uint(pa[r]) | __float_as_uint(pc[r])) << 1) == 0u) ? zrun[r] + 1 : 0;
         // slide the window sums (the leaving plane sits in the slot the new one takes) and take the prefetched plane.
         // The ring is addressed through a uniform switch over the slot: every case names its registers statically, so the
         // ring never moves (rotating it cost 80 v_mov per plane and wave).
@@ -483,6 +569,10 @@ ncc_fused_kernel(const float* __restrict__ I, const float* __restrict__ J, doubl
                 W[r][0] = sI; W[r][1] = sJ; W[r][2] = sII; W[r][3] = sJJ; W[r][4] = sIJ;
             }
         }
+#pragma unroll
+        for (int r = 0; r < NF_RPW; ++r)
+#pragma unroll
+            for (int q = 0; q < 5; ++q) W[r][q] = zrun[r] >= 9 ? 0.f : W[r][q];
         float* buf = zb + (size_t)(s & 1) * (NF_ROWS * 5 * 64);
 #pragma unroll
         for (int r = 0; r < NF_RPW; ++r) {
@@ -517,17 +607,21 @@ ncc_fused_kernel(const float* __restrict__ I, const float* __restrict__ J, doubl
         for (int i = 0; i < NF_WAVES; ++i) r += sh[i];
         part[blockIdx.x] = r;
     }
+    ticket_finalize(part, fin, smem);      // (its first __syncthreads separates this from the last tile reads)
 }
 
 __global__ void mean_final_kernel(const double* __restrict__ part, float* __restrict__ out, int B, int64_t nb,
-                                  double denom, float sign)
+                                  double denom, float sign, int accumulate = 0)
 {
     __shared__ double sh[4];
     const int b = blockIdx.x;
     double a = 0.0;
     for (int64_t k = threadIdx.x; k < nb; k += blockDim.x) a += part[(int64_t)b * nb + k];
     const double s = block_sum(a, sh);
-    if (threadIdx.x == 0) out[b] = (float)((double)sign * s / denom);
+    if (threadIdx.x == 0) {
+        const float v = (float)((double)sign * s / denom);
+        out[b] = accumulate ? out[b] + v : v;
+    }
 }
 
 // ------------------------------ bending --------------------------------- //
@@ -606,12 +700,11 @@ __device__ __forceinline__ void zwin4(const f4_t v, float& o0, float& o1, float&
 template <int FORM>
 __global__ void __launch_bounds__(N4_WAVES * 64, 4)
 ncc_fused4_kernel(const float* __restrict__ I, const float* __restrict__ J, double* __restrict__ part, int X, int Y, int Z,
-                   int xseg, int nxs, int nyt, float eps)
+                   int xseg, int nxs, int nyt, float eps, const TicketFin fin)
 {
-    constexpr int form = FORM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f4_t* buf = reinterpret_cast<f4_t*>(smem);             // [N4_ROWS][5][64]
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // w in an SGPR: uniform branches on it
     int t = blockIdx.x;
     // workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one L2): every XCD takes a contiguous run of logical
     // workgroups, so that y-neighbouring tiles, which share 8 of their 16 haloed rows, read them through one L2
@@ -652,47 +745,106 @@ ncc_fused4_kernel(const float* __restrict__ I, const float* __restrict__ J, doub
     for (int r = 0; r < N4_RPW; ++r)
 #pragma unroll
         for (int q = 0; q < 5; ++q) W[r][q] = zero4;
+    // Sliding sums cannot return to EXACT zero by themselves: once a voxel column's window has left bright tissue for a zero
+    // background, ((W + a) - a) keeps a rounding residual of ~1e-7 of what passed through, and for un-normalised intensities
+    // (0..255, 0..4095) that residual, squared into the variances, dwarfs eps: windows that lie wholly in the background would
+    // score O(1) garbage where the reference's conv-based sums are exactly 0 and cc = 0.  zrun[r] counts, per lane AND per z
+    // component (a 9^3 window can contain one z column of a lane's quad without its neighbours), the consecutive planes in which
+    // I and J were both zero (I^2 + J^2 == 0); the step at which the ninth such plane joins, that column's window IS all zero
+    // and its five sums are set to it.  From then on 0 + 0 - 0 stays exact.  Planes outside the volume arrive as hardware zeros.
+    typedef int i4_t __attribute__((ext_vector_type(4)));
+    i4_t zrun[N4_RPW];
+#pragma unroll
+    for (int r = 0; r < N4_RPW; ++r) zrun[r] = i4_t{0, 0, 0, 0};
+    auto join = [&](int r, const f4_t a, const f4_t c) {
+        W[r][0] += a; W[r][1] += c; W[r][2] += a * a; W[r][3] += c * c; W[r][4] += a * c;
+        const f4_t e = __builtin_elementwise_fma(c, c, a * a);
+        i4_t& z = zrun[r];
+        z.x = e.x == 0.f ? z.x + 1 : 0; z.y = e.y == 0.f ? z.y + 1 : 0; z.z = e.z == 0.f ? z.z + 1 : 0; z.w = e.w == 0.f ? z.w + 1 : 0;
+        const bool hit = (z.x == 9) | (z.y == 9) | (z.z == 9) | (z.w == 9);
+        if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {            // rare: some column's window has just become all zero
+            // divergent constant stores (exec-masked v_mov), not selects: a select reads the updated sums, hipcc then keeps those in
+            // fresh registers and pays ten 64-bit moves per row on the COMMON path to bring them back
+            if (z.x == 9) { W[r][0].x = 0.f; W[r][1].x = 0.f; W[r][2].x = 0.f; W[r][3].x = 0.f; W[r][4].x = 0.f; }
+            if (z.y == 9) { W[r][0].y = 0.f; W[r][1].y = 0.f; W[r][2].y = 0.f; W[r][3].y = 0.f; W[r][4].y = 0.f; }
+            if (z.z == 9) { W[r][0].z = 0.f; W[r][1].z = 0.f; W[r][2].z = 0.f; W[r][3].z = 0.f; W[r][4].z = 0.f; }
+            if (z.w == 9) { W[r][0].w = 0.f; W[r][1].w = 0.f; W[r][2].w = 0.f; W[r][3].w = 0.f; W[r][4].w = 0.f; }
+        }
+    };
     const bool oval = zin && (yt * N4_YOUT + w) < Y;
-    const float ws = 729.f;
     float acc = 0.f;
     const int xi0 = x0 - 4, nstep = (x1 - x0) + 8;
     f4_t na[N4_RPW], nc[N4_RPW], oa[N4_RPW], oc[N4_RPW];   // the plane that joins the window at this step / the one that leaves after it
+    // warm-up: the eight planes in front of the first complete window join in two batches of four whose loads are all in flight
+    // together (one plane per round trip, as the steady state does it, left a fresh workgroup waiting eight round trips)
 #pragma unroll
-    for (int r = 0; r < N4_RPW; ++r) {
-        na[r] = ldp(rsI, xi0, r, true);
-        nc[r] = ldp(rsJ, xi0, r, true);
-        oa[r] = oc[r] = zero4;
-    }
-    for (int s = 0; s < nstep; ++s) {
+    for (int h = 0; h < 2; ++h) {
+        f4_t pa[4][N4_RPW], pc[4][N4_RPW];
 #pragma unroll
-        for (int r = 0; r < N4_RPW; ++r) {
-            const f4_t a = na[r], c = nc[r];
-            W[r][0] += a; W[r][1] += c; W[r][2] += a * a; W[r][3] += c * c; W[r][4] += a * c;
-        }
-        const bool full = s >= 8;                           // window complete (uniform)
-        if (full) {
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                buf[(w * 5 + q) * 64 + lane] = W[0][q] + W[1][q];
-                buf[((8 + w) * 5 + q) * 64 + lane] = (w < 4) ? W[1][q] : W[0][q];
+            for (int r = 0; r < N4_RPW; ++r) {
+                pa[k][r] = ldp(rsI, xi0 + 4 * h + k, r, true);
+                pc[k][r] = ldp(rsJ, xi0 + 4 * h + k, r, true);
             }
+        if (h == 1) {
+#pragma unroll
+            for (int r = 0; r < N4_RPW; ++r) {     // the first steady step's planes ride behind the second batch
+                na[r] = ldp(rsI, xi0 + 8, r, true);
+                nc[r] = ldp(rsJ, xi0 + 8, r, true);
+                oa[r] = ldp(rsI, xi0, r, true);
+                oc[r] = ldp(rsJ, xi0, r, true);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int r = 0; r < N4_RPW; ++r) join(r, pa[k][r], pc[k][r]);
+    }
+    for (int s = 8; s < nstep; ++s) {
+#pragma unroll
+        for (int r = 0; r < N4_RPW; ++r) join(r, na[r], nc[r]);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) buf[(w * 5 + q) * 64 + lane] = W[0][q] + W[1][q];
+        if (w < 4) {      // (a select per element costs 20 v_cndmask per step)
+#pragma unroll
+            for (int q = 0; q < 5; ++q) buf[((8 + w) * 5 + q) * 64 + lane] = W[1][q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) buf[((8 + w) * 5 + q) * 64 + lane] = W[0][q];
         }
         // plane s - 8 leaves the window before the next step; then the next step's two planes are requested (a step ahead)
 #pragma unroll
         for (int r = 0; r < N4_RPW; ++r) {
+            // packed, in place, through the VOP3P neg modifiers (hipcc turns `W -= a` into four v_sub_f32 and negates the fma
+            // operands with v_xor; negated copies made with v_pk_mul cost registers the kernel does not have)
             const f4_t a = oa[r], c = oc[r];
-            W[r][0] -= a; W[r][1] -= c; W[r][2] -= a * a; W[r][3] -= c * c; W[r][4] -= a * c;
+            auto sub4 = [](f4_t& Wq, const f4_t v) {
+                f2_t lo = __builtin_shufflevector(Wq, Wq, 0, 1), hi = __builtin_shufflevector(Wq, Wq, 2, 3);
+                const f2_t vl = __builtin_shufflevector(v, v, 0, 1), vh = __builtin_shufflevector(v, v, 2, 3);
+                asm("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(lo) : "v"(vl));
+                asm("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(hi) : "v"(vh));
+                Wq = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+            };
+            auto fnma4 = [](f4_t& Wq, const f4_t u, const f4_t v) {      // Wq -= u * v
+                f2_t lo = __builtin_shufflevector(Wq, Wq, 0, 1), hi = __builtin_shufflevector(Wq, Wq, 2, 3);
+                const f2_t ul = __builtin_shufflevector(u, u, 0, 1), uh = __builtin_shufflevector(u, u, 2, 3);
+                const f2_t vl = __builtin_shufflevector(v, v, 0, 1), vh = __builtin_shufflevector(v, v, 2, 3);
+                asm("v_pk_fma_f32 %0, %1, %2, %0 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(lo) : "v"(ul), "v"(vl));
+                asm("v_pk_fma_f32 %0, %1, %2, %0 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(hi) : "v"(uh), "v"(vh));
+                Wq = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+            };
+            sub4(W[r][0], a); sub4(W[r][1], c); fnma4(W[r][2], a, a); fnma4(W[r][3], c, c); fnma4(W[r][4], a, c);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < N4_RPW; ++r) {
             na[r] = ldp(rsI, xi0 + s + 1, r, true);
             nc[r] = ldp(rsJ, xi0 + s + 1, r, true);
-            oa[r] = ldp(rsI, xi0 + s - 7, r, s >= 7);       // joined at step s - 7 >= 0, else nothing to take out
-            oc[r] = ldp(rsJ, xi0 + s - 7, r, s >= 7);
+            oa[r] = ldp(rsI, xi0 + s - 7, r, true);
+            oc[r] = ldp(rsJ, xi0 + s - 7, r, true);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (!full) continue;
         __syncthreads();
         const int p0 = (w + 1) >> 1;
         const int s1 = 8 + ((w & 1) ? (w >> 1) : (w >> 1) + 4);
@@ -705,10 +857,7 @@ ncc_fused4_kernel(const float* __restrict__ I, const float* __restrict__ J, doub
             zwin4(v, S[0][q], S[1][q], S[2][q], S[3][q]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (oval) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc += ncc_terms<true>(S[k], ws, eps, form).cc;
-        }
+        if (oval) acc += ncc_cc4_sum<FORM>(S, eps);
         __syncthreads();                                    // the tile is rewritten by the next plane
     }
     double v = wave_sum((double)acc);
@@ -721,6 +870,7 @@ ncc_fused4_kernel(const float* __restrict__ I, const float* __restrict__ J, doub
         for (int i = 0; i < N4_WAVES; ++i) r += sh[i];
         part[lblk] = r;
     }
+    ticket_finalize(part, fin, smem + 1024);
 }
 
 // x[lane + 1] + x[lane - 1] and x[lane + 1] - x[lane - 1] (0 beyond the wave's ends): one DPP move + one DPP-fused VOP2
@@ -746,9 +896,10 @@ struct F3 { float v[3]; };
 template <int BF_R>              // output rows per wave (BF_R + 2 rows loaded per plane)
 __global__ void __launch_bounds__(RED_BLOCK, 2)
 bending_fused_kernel(const float* __restrict__ u, double* __restrict__ part, int X, int Y, int Z, int xseg, int nxs, int nyg,
-                     int nzs, int64_t nwaves)
+                     int nzs, int64_t nwaves, const TicketFin fin)
 {
     __shared__ double sh[4];
+    __shared__ __attribute__((aligned(8))) char fin_scratch[256];
     const int lane = threadIdx.x & 63;
     const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // (an XCD-contiguous workgroup order measured no better)
     float acc = 0.f;
@@ -825,6 +976,7 @@ bending_fused_kernel(const float* __restrict__ u, double* __restrict__ part, int
     }
     const double r = block_sum((double)acc, sh);
     if (threadIdx.x == 0) part[blockIdx.x] = r;
+    ticket_finalize(part, fin, fin_scratch);
 }
 
 // ------------------------------ NCC backward ---------------------------- //
@@ -1174,14 +1326,21 @@ extern "C" int64_t mmr_ncc_ws_bytes(int B, int X, int Y, int Z)
     return n * (int64_t)sizeof(double);
 }
 
-extern "C" int mmr_ncc_fwd_f32(const float* I, const float* J, float* out, void* ws, int B, int X, int Y, int Z,
-                               int win, float eps, int ncc_form, void* stream)
+static int ncc_fwd_impl(const float* I, const float* J, float* out, void* ws, unsigned* ticket, int B, int X, int Y, int Z,
+                        int win, float eps, int ncc_form, float scale, int accumulate, void* stream)
 {
     if (!I || !J || !out || !ws || B < 1 || X < 1 || Y < 1 || Z < 1) return MMR_EINVAL;
     if (ncc_form != MMR_NCC_CLASSIC && ncc_form != MMR_NCC_CLAMPED) return MMR_EINVAL;
     if (win != 9) return MMR_EUNSUPPORTED;
     if ((int64_t)Y * Z > 0x7fffffff) return MMR_EINVAL;
     int nzt, nyt, nxs, xseg;
+    TicketFin fin;
+    fin.ticket = ticket;
+    fin.out = out;
+    fin.nout = B;
+    fin.denom = (double)X * Y * Z;
+    fin.sign = -scale;
+    fin.accumulate = accumulate;
     if (ncc_fused4_ok((int64_t)X * Y * Z, Z)) {
         ncc_fused4_geom(B, X, Y, nyt, nxs, xseg);
         const int64_t nblk4 = (int64_t)nyt * nxs;            // per batch item
@@ -1196,16 +1355,17 @@ extern "C" int mmr_ncc_fwd_f32(const float* I, const float* J, float* out, void*
             attr4 = true;
         }
         double* part4 = (double*)ws;
+        fin.nb = nblk4;
         if (ncc_form == MMR_NCC_CLAMPED)
             hipLaunchKernelGGL(ncc_fused4_kernel<MMR_NCC_CLAMPED>, dim3((unsigned)(B * nblk4)), dim3(N4_WAVES * 64), N4_LDS_BYTES,
-                               as_stream(stream), I, J, part4, X, Y, Z, xseg, nxs, nyt, eps);
+                               as_stream(stream), I, J, part4, X, Y, Z, xseg, nxs, nyt, eps, fin);
         else
             hipLaunchKernelGGL(ncc_fused4_kernel<MMR_NCC_CLASSIC>, dim3((unsigned)(B * nblk4)), dim3(N4_WAVES * 64), N4_LDS_BYTES,
-                               as_stream(stream), I, J, part4, X, Y, Z, xseg, nxs, nyt, eps);
+                               as_stream(stream), I, J, part4, X, Y, Z, xseg, nxs, nyt, eps, fin);
         int rc4 = check_launch();
-        if (rc4) return rc4;
+        if (rc4 || ticket) return rc4;
         hipLaunchKernelGGL(mean_final_kernel, dim3(B), dim3(RED_BLOCK), 0, as_stream(stream), (const double*)part4, out, B,
-                           nblk4, (double)X * Y * Z, -1.0f);
+                           nblk4, (double)X * Y * Z, -scale, accumulate);
         return check_launch();
     }
     ncc_fused_geom(B, X, Y, Z, nzt, nyt, nxs, xseg);
@@ -1219,13 +1379,27 @@ extern "C" int mmr_ncc_fwd_f32(const float* I, const float* J, float* out, void*
         attr_set = true;
     }
     double* part = (double*)ws;
+    fin.nb = nblk;
     hipLaunchKernelGGL(ncc_fused_kernel, dim3((unsigned)(B * nblk)), dim3(NF_WAVES * 64), NF_LDS_BYTES, as_stream(stream), I, J,
-                       part, X, Y, Z, xseg, nxs, nyt, nzt, eps, ncc_form);
+                       part, X, Y, Z, xseg, nxs, nyt, nzt, eps, ncc_form, fin);
     int rc = check_launch();
-    if (rc) return rc;
+    if (rc || ticket) return rc;
     hipLaunchKernelGGL(mean_final_kernel, dim3(B), dim3(RED_BLOCK), 0, as_stream(stream), (const double*)part, out, B, nblk,
-                       (double)X * Y * Z, -1.0f);
+                       (double)X * Y * Z, -scale, accumulate);
     return check_launch();
+}
+
+extern "C" int mmr_ncc_fwd_f32(const float* I, const float* J, float* out, void* ws, int B, int X, int Y, int Z,
+                               int win, float eps, int ncc_form, void* stream)
+{
+    return ncc_fwd_impl(I, J, out, ws, nullptr, B, X, Y, Z, win, eps, ncc_form, 1.0f, 0, stream);
+}
+
+extern "C" int mmr_ncc_fwd_ticket_f32(const float* I, const float* J, float* out, void* ws, unsigned* ticket, int B, int X, int Y,
+                                      int Z, int win, float eps, int ncc_form, float scale, int accumulate, void* stream)
+{
+    if (!ticket) return MMR_EINVAL;
+    return ncc_fwd_impl(I, J, out, ws, ticket, B, X, Y, Z, win, eps, ncc_form, scale, accumulate, stream);
 }
 
 namespace {
@@ -1250,7 +1424,8 @@ extern "C" int64_t mmr_bending_ws_bytes(int B, int X, int Y, int Z)
     return ((nwaves + 3) / 4 + B) * (int64_t)sizeof(double);
 }
 
-extern "C" int mmr_bending_fwd_f32(const float* flow, float* out, void* ws, int B, int X, int Y, int Z, void* stream)
+static int bending_fwd_impl(const float* flow, float* out, void* ws, unsigned* ticket, int B, int X, int Y, int Z, float scale,
+                            int accumulate, void* stream)
 {
     if (!flow || !out || !ws || B < 1 || X < 3 || Y < 3 || Z < 3) return MMR_EINVAL;
     if ((int64_t)Y * Z * 3 > 0x7fffffff) return MMR_EINVAL;
@@ -1262,14 +1437,35 @@ extern "C" int mmr_bending_fwd_f32(const float* flow, float* out, void* ws, int 
     const int64_t n = (int64_t)(X - 2) * (Y - 2) * (Z - 2) * 3;
     for (int b = 0; b < B; ++b) {
         double* part = (double*)ws + (int64_t)b * nblk;
+        TicketFin fin;       // one launch per batch item: each finalizes its own out[b] (the launches are ordered by the stream)
+        fin.ticket = ticket;
+        fin.out = out + b;
+        fin.nout = 1;
+        fin.nb = nblk;
+        fin.denom = (double)n;
+        fin.sign = scale;
+        fin.accumulate = accumulate;
         hipLaunchKernelGGL(bending_fused_kernel<BF_ROWS>, dim3((unsigned)nblk), dim3(RED_BLOCK), 0, as_stream(stream),
-                               flow + (size_t)b * X * Y * Z * 3, part, X, Y, Z, xseg, nxs, nyg, nzs, nwaves);
+                               flow + (size_t)b * X * Y * Z * 3, part, X, Y, Z, xseg, nxs, nyg, nzs, nwaves, fin);
         int rc = check_launch();
         if (rc) return rc;
     }
+    if (ticket) return MMR_OK;
     hipLaunchKernelGGL(mean_final_kernel, dim3(B), dim3(RED_BLOCK), 0, as_stream(stream), (const double*)ws, out, B, nblk,
-                       (double)n, 1.0f);
+                       (double)n, scale, accumulate);
     return check_launch();
+}
+
+extern "C" int mmr_bending_fwd_f32(const float* flow, float* out, void* ws, int B, int X, int Y, int Z, void* stream)
+{
+    return bending_fwd_impl(flow, out, ws, nullptr, B, X, Y, Z, 1.0f, 0, stream);
+}
+
+extern "C" int mmr_bending_fwd_ticket_f32(const float* flow, float* out, void* ws, unsigned* ticket, int B, int X, int Y, int Z,
+                                          float scale, int accumulate, void* stream)
+{
+    if (!ticket) return MMR_EINVAL;
+    return bending_fwd_impl(flow, out, ws, ticket, B, X, Y, Z, scale, accumulate, stream);
 }
 
 // d(-mean cc)/dI and /dJ, scaled by gout[b] (null = 1); dI / dJ may be null.  Workspace: 19 volumes of fp32.

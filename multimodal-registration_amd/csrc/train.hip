@@ -701,26 +701,27 @@ leaky_bwd_bias_kernel(const float* __restrict__ y, const float* __restrict__ dy,
                       double* __restrict__ part, int64_t nvox, int C, float alpha, int leaky, int nblk)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* s = reinterpret_cast<float*>(smem);  // [TB]
+    double* s = reinterpret_cast<double*>(smem);  // [TB]
     const int T = (TB / C) * C;  // C <= 256; threads >= T idle so that a thread's channel is fixed
     const int64_t nel = nvox * C;
     const int64_t chunk = (((nel + nblk - 1) / nblk + T - 1) / T) * T;
     const int64_t lo = (int64_t)blockIdx.x * chunk;
     const int64_t hi = lo + chunk < nel ? lo + chunk : nel;
-    float acc = 0.f;
+    // double from the first addition on: the flow head's bias gradient is this sum over every voxel with 40 - 80x cancellation
+    double acc = 0.0;
     if ((int)threadIdx.x < T) {
         for (int64_t e = lo + threadIdx.x; e < hi; e += T) {
             float g = dy[e];
             if (leaky && y[e] < 0.f) g *= alpha;
             dz[e] = g;
-            acc += g;
+            acc += (double)g;
         }
     }
     s[threadIdx.x] = acc;
     __syncthreads();
     if ((int)threadIdx.x < C) {
         double r = 0.0;
-        for (int k = threadIdx.x; k < T; k += C) r += (double)s[k];
+        for (int k = threadIdx.x; k < T; k += C) r += s[k];
         part[(int64_t)blockIdx.x * C + threadIdx.x] = r;
     }
 }
@@ -2778,7 +2779,7 @@ extern "C" int mmr_leaky_bwd_bias_f32(const float* y, const float* dy, float* dz
 {
     if (!dy || !dz || !dbias || !ws || nvox < 1 || C < 1 || C > 256 || (leaky && !y)) return MMR_EINVAL;
     const int nblk = rblocks(nvox * C);
-    hipLaunchKernelGGL(leaky_bwd_bias_kernel, dim3(nblk), dim3(TB), TB * sizeof(float), as_stream(stream), y, dy, dz,
+    hipLaunchKernelGGL(leaky_bwd_bias_kernel, dim3(nblk), dim3(TB), TB * sizeof(double), as_stream(stream), y, dy, dz,
                        (double*)ws, nvox, C, alpha, leaky, nblk);
     int rc = check_launch();
     if (rc) return rc;

@@ -71,12 +71,18 @@ def _pinned(shape, dtype, tag):
 
 
 def h2d_volume(a, device, dtype=torch.float32, tag=0):
-    """NumPy (any float dtype) / CPU tensor -> device tensor of ``dtype`` through a cached pinned buffer."""
+    """NumPy (any real dtype) / CPU tensor -> device tensor of ``dtype``.  fp32 targets go through hostio: the caller's
+    pages are pinned in place (or memcpy'd into cached pinned staging memory) and a kernel converts to fp32 while it
+    reads them over PCIe -- no host-side conversion, no write into uncached pinned memory."""
     if isinstance(a, torch.Tensor) and a.is_cuda:
         return a.to(dtype).contiguous()
-    t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
     if torch.device(device).type != "cuda":
+        t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
         return t.to(dtype).contiguous()
+    if dtype == torch.float32:
+        from . import hostio
+        return hostio.to_device_f32(a.numpy() if isinstance(a, torch.Tensor) else a, device, tag=tag)
+    t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
     pin = _pinned(t.shape, dtype, ("in", tag))
     pin.copy_(t)  # threaded conversion + copy on the host
     out = pin.to(device, non_blocking=True)
@@ -85,13 +91,11 @@ def h2d_volume(a, device, dtype=torch.float32, tag=0):
 
 
 def d2h_volume(t, tag=0):
-    """Device tensor -> fresh NumPy array through a cached pinned buffer."""
+    """Device tensor -> fresh NumPy array (through cached pinned staging memory, hostio.to_host)."""
     if not t.is_cuda:
         return t.detach().cpu().numpy()
-    pin = _pinned(t.shape, t.dtype, ("out", tag))
-    pin.copy_(t.detach(), non_blocking=True)
-    torch.cuda.current_stream().synchronize()
-    return pin.numpy().copy()
+    from . import hostio
+    return hostio.to_host(t, tag=tag)
 
 
 class SpatialTransformer:

@@ -117,6 +117,10 @@ class InputModel:
         return g1["image"], g2["image"]
 
 
+def _as_np(a):
+    return a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+
+
 class VxmDense:
     """VoxelMorph dense registration network, forward on gfx950 HIP kernels.
 
@@ -466,53 +470,66 @@ class VxmDense:
         for b in range(n):
             if self.input_model is not None:   # label maps in: the generators take NumPy uint8 or device tensors as they are
                 s, t = src[b:b + 1], trg[b:b + 1]
+            elif host_in and self.device.type == "cuda":
+                # both volumes pinned where they lie, converted to fp32 by a kernel that reads them over PCIe (hostio)
+                from . import hostio
+                s, t = hostio.pair_to_device([_as_np(src[b:b + 1]), _as_np(trg[b:b + 1])], self.device)
             else:
                 s = h2d_volume(src[b:b + 1], self.device, tag=0)
                 t = h2d_volume(trg[b:b + 1], self.device, tag=1)
             o = self.forward(s, t)
-            out_m.append(d2h_volume(o["y_source"], tag=0))
-            out_f.append(d2h_volume(o["preint_flow"], tag=1))
+            if self.device.type == "cuda":
+                from . import hostio
+                ym, yf = hostio.many_to_host([o["y_source"], o["preint_flow"]])
+            else:
+                ym, yf = d2h_volume(o["y_source"], tag=0), d2h_volume(o["preint_flow"], tag=1)
+            out_m.append(ym)
+            out_f.append(yf)
         if n == 1:
             return [out_m[0], out_f[0]]
         return [np.concatenate(out_m), np.concatenate(out_f)]
 
     def _predict_overlapped(self, src, trg, n):
-        """Pairs b - 1 / b / b + 1 in flight at once: while pair b is in the forward, pair b + 1 is converted to fp32 into a
-        pinned buffer and copied in, and pair b - 1's outputs are copied out, both on a side stream (two pinned slots per
-        direction; events order every hand-over).  Same kernels on the same inputs: results identical to the one-pair path."""
-        from .layers import _pinned
+        """Pairs b - 1 / b / b + 1 in flight at once: while pair b is in the forward, pair b + 1 is memcpy'd into cached pinned
+        staging memory and converted to fp32 by the cast kernel, and pair b - 1's outputs are copied out, both on a side
+        stream (two staging slots per direction; events order every hand-over).  Same kernels on the same inputs: results
+        identical to the one-pair path."""
+        import ctypes
+        from . import _lib, hostio
         dev = self.device
         main = torch.cuda.current_stream(dev)
         if getattr(self, "_copy_stream", None) is None:
             self._copy_stream = torch.cuda.Stream(device=dev)
         cs = self._copy_stream
-        as_t = lambda a: a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
-        in_done = [None, None]      # H2D events of the two input slots (the pinned buffers are rewritten by the host)
+        lib = _lib.load()
 
         def stage_in(b):
             slot = b & 1
-            if in_done[slot] is not None:
-                in_done[slot].synchronize()          # the copy that last read this slot's pinned buffers has finished
             devs = []
             for k, a in enumerate((src, trg)):
-                t = as_t(a[b:b + 1])
-                pin = _pinned(t.shape, torch.float32, ("in2", slot, k))
-                pin.copy_(t)                          # fp64 -> fp32 conversion on the host, while the GPU works on pair b - 1
+                a = _as_np(a[b:b + 1])
+                if a.dtype not in hostio._CODES:
+                    a = a.astype(np.float64)
+                st = hostio.staging(max(a.nbytes, 16), ("in2", slot, k))
+                st.wait()                             # the kernel that last read this slot has finished
+                np.copyto(st.view(a.dtype, a.shape), a)   # plain memcpy, while the GPU works on pair b - 1
                 with torch.cuda.stream(cs):
-                    d = pin.to(dev, non_blocking=True)
+                    d = torch.empty(a.shape, dtype=torch.float32, device=dev)
+                    _lib.check(lib.mmr_cast_to_f32(ctypes.c_void_p(st.ptr), d.data_ptr(), a.size, hostio._CODES[a.dtype],
+                                                   cs.cuda_stream), "mmr_cast_to_f32")
+                    ev = torch.cuda.Event()
+                    ev.record(cs)
+                st.event = ev
                 d.record_stream(main)
                 devs.append(d)
-            ev = torch.cuda.Event()
-            ev.record(cs)
-            in_done[slot] = ev
             return devs[0], devs[1], ev
         out_m, out_f, pending = [None] * n, [None] * n, [None, None]
 
         def collect(slot):
             if pending[slot] is not None:
-                b, ev, pm, pf = pending[slot]
+                b, ev, sm, sf, shm, shf = pending[slot]
                 ev.synchronize()
-                out_m[b], out_f[b] = pm.numpy().copy(), pf.numpy().copy()
+                out_m[b], out_f[b] = sm.view(np.float32, shm).copy(), sf.view(np.float32, shf).copy()
                 pending[slot] = None
         nxt = stage_in(0)
         for b in range(n):
@@ -525,18 +542,19 @@ class VxmDense:
             ev_c.record(main)
             slot = b & 1
             collect(slot)                            # pair b - 2 used this output slot
-            ym, yf = o["y_source"], o["preint_flow"]
-            pm = _pinned(ym.shape, ym.dtype, ("out2", slot, 0))
-            pf = _pinned(yf.shape, yf.dtype, ("out2", slot, 1))
+            ym, yf = o["y_source"].detach(), o["preint_flow"].detach()
+            sm = hostio.staging(ym.numel() * 4, ("out2", slot, 0))
+            sf = hostio.staging(yf.numel() * 4, ("out2", slot, 1))
             with torch.cuda.stream(cs):
                 cs.wait_event(ev_c)
-                pm.copy_(ym.detach(), non_blocking=True)
-                pf.copy_(yf.detach(), non_blocking=True)
+                for tns, st in ((ym, sm), (yf, sf)):
+                    _lib.check(lib.mmr_copy_to_host(tns.data_ptr(), ctypes.c_void_p(st.ptr), tns.numel() * 4, cs.cuda_stream),
+                               "mmr_copy_to_host")
                 ev_o = torch.cuda.Event()
                 ev_o.record(cs)
             ym.record_stream(cs)
             yf.record_stream(cs)
-            pending[slot] = (b, ev_o, pm, pf)
+            pending[slot] = (b, ev_o, sm, sf, tuple(ym.shape), tuple(yf.shape))
         collect(0)
         collect(1)
         return [np.concatenate(out_m), np.concatenate(out_f)]

@@ -547,8 +547,23 @@ def grad_l2_loss(flow, loss_mult=1.0):
     return out
 
 
-def ncc_loss(I, J, win=9, eps=1e-5, form=None):
-    """vxm.losses.NCC(win, eps).loss -> [B]; form: 'classic' | 'clamped' (None = mmr.semantics default)."""
+_TICKETS = {}   # (device index, stream handle) -> zeroed int32 word: the in-kernel finalize of the loss reductions (csrc/losses.hip,
+                # TicketFin) needs one per concurrently running call and leaves it zero; calls on one stream are ordered
+
+
+def _ticket(device):
+    key = (device.index, _stream())
+    t = _TICKETS.get(key)
+    if t is None:
+        if len(_TICKETS) >= 64:
+            _TICKETS.clear()
+        t = _TICKETS[key] = torch.zeros(4, dtype=torch.int32, device=device)
+    return t
+
+
+def ncc_loss(I, J, win=9, eps=1e-5, form=None, out=None, scale=1.0):
+    """vxm.losses.NCC(win, eps).loss -> [B]; form: 'classic' | 'clamped' (None = mmr.semantics default).
+    ``out`` [B] given: out += scale * loss (a total loss assembled in place); the reduction is finished inside the kernel."""
     _chk(I, torch.float32, "I")
     _chk(J, torch.float32, "J")
     if I.shape != J.shape or I.shape[-1] != 1:
@@ -556,27 +571,42 @@ def ncc_loss(I, J, win=9, eps=1e-5, form=None):
     B, X, Y, Z, _ = I.shape
     lib = _lib.load()
     ws = _ws(lib.mmr_ncc_ws_bytes(B, X, Y, Z), I.device)
-    out = torch.empty(B, dtype=torch.float32, device=I.device)
+    acc = out is not None
+    if acc:
+        _chk(out, torch.float32, "out")
+        if tuple(out.shape) != (B,):
+            raise _lib.MmrError("ncc: out must be [B]")
+    else:
+        out = torch.empty(B, dtype=torch.float32, device=I.device)
     # the kernel mmr_ncc_fwd_f32 picks (csrc/losses.hip: ncc_fused4_ok): four z per lane for whole rows, else one
     four = Z % 4 == 0 and Z <= 256 and X * Y * Z * 4 < 0xF0000000
     with _Timed("hbm:ncc_fused4_kernel" if four else "hbm:ncc_fused_kernel", (X, Y, Z), 2.0 * 4 * B * X * Y * Z):   # I, J read once
-        rc = lib.mmr_ncc_fwd_f32(I.data_ptr(), J.data_ptr(), out.data_ptr(), ws.data_ptr(), B, X, Y, Z, int(win), float(eps),
-                                 semantics.code("ncc_form", form), _stream())
-    _lib.check(rc, "mmr_ncc_fwd_f32")
+        rc = lib.mmr_ncc_fwd_ticket_f32(I.data_ptr(), J.data_ptr(), out.data_ptr(), ws.data_ptr(), _ticket(I.device).data_ptr(),
+                                        B, X, Y, Z, int(win), float(eps), semantics.code("ncc_form", form), float(scale), int(acc),
+                                        _stream())
+    _lib.check(rc, "mmr_ncc_fwd_ticket_f32")
     return out
 
 
-def bending_energy(flow):
+def bending_energy(flow, out=None, scale=1.0):
+    """Bending energy [B]; ``out`` [B] given: out += scale * energy (e.g. onto ``ncc_loss``'s result: two launches per step)."""
     _chk(flow, torch.float32, "flow")
     B, X, Y, Z, C = flow.shape
     if C != 3:
         raise _lib.MmrError("bending energy needs [B,X,Y,Z,3]")
     lib = _lib.load()
     ws = _ws(lib.mmr_bending_ws_bytes(B, X, Y, Z), flow.device)
-    out = torch.empty(B, dtype=torch.float32, device=flow.device)
+    acc = out is not None
+    if acc:
+        _chk(out, torch.float32, "out")
+        if tuple(out.shape) != (B,):
+            raise _lib.MmrError("bending: out must be [B]")
+    else:
+        out = torch.empty(B, dtype=torch.float32, device=flow.device)
     with _Timed("hbm:bending_fused_kernel", (X, Y, Z), 3.0 * 4 * B * X * Y * Z):   # the field read once
-        rc = lib.mmr_bending_fwd_f32(flow.data_ptr(), out.data_ptr(), ws.data_ptr(), B, X, Y, Z, _stream())
-    _lib.check(rc, "mmr_bending_fwd_f32")
+        rc = lib.mmr_bending_fwd_ticket_f32(flow.data_ptr(), out.data_ptr(), ws.data_ptr(), _ticket(flow.device).data_ptr(),
+                                            B, X, Y, Z, float(scale), int(acc), _stream())
+    _lib.check(rc, "mmr_bending_fwd_ticket_f32")
     return out
 
 

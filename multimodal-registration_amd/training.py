@@ -43,7 +43,7 @@ class SynthMorphTrainer:
 
     def __init__(self, model, gen_1=None, gen_2=None, reg_param=1.0, optimizer=None, zero_pad_dice=False,
                  process_group=None, world_size=1, rank=0, backward_precision=None, overlap_wgrad=False, fuse_pool_bwd=True,
-                 batch_repack=True):
+                 batch_repack=True, early_reduce=True):
         """gen_1 / gen_2 default to the generator pair of ``model.input_model`` (a model built the reference's way,
         ``VxmDense(..., input_model=InputModel(gen_1, gen_2))``, train_synthmorph.py:294-296).
         backward_precision: None = same arithmetic as the forward (fp32 / fp32x3); 'bf16' = dgrad and wgrad
@@ -58,7 +58,10 @@ class SynthMorphTrainer:
         fuse_pool_bwd: the MaxPooling3D backward of a skip tensor runs in the epilogue of the decoder conv's data gradient
         (ops.conv3d_k3_dgrad_masked(pool_grad=)) where that kernel supports it; False keeps the separate pooling-backward pass.
         batch_repack: after the optimizer step every weight image of the model (forward, folded, transposed) is rewritten by
-        one launch (VxmDense.repack); False marks them stale and each is packed by its own launch where the next step needs it."""
+        one launch (VxmDense.repack); False marks them stale and each is packed by its own launch where the next step needs it.
+        early_reduce: data parallel only -- True (default) all-reduces everything but the encoder's gradients asynchronously
+        from the point where the backward reaches the last encoder conv (two buckets); False = ONE all-reduce of the whole flat
+        buffer after the backward (bench.py --no-early-reduce: the A/B the first multi-GPU run needs)."""
         if model.dtype != torch.float32:
             raise NotImplementedError("training runs the fp32 path (the reference trains in fp32)")
         im = getattr(model, "input_model", None)
@@ -96,6 +99,10 @@ class SynthMorphTrainer:
         # conv -- their all-reduce starts there and runs under the encoder's backward (bucket 1); the rest follows the backward
         self._bucket_li = len(model.enc) - 1
         self._ar_early, self._reduce_early = None, False   # only train_step reduces; forward_backward leaves gflat unreduced
+        self.early_reduce = bool(early_reduce)
+        # HIP events around the encoder's part of the backward (from the point where bucket 1 would start to the end of the
+        # walk) when time_encoder_bwd is set: [(start, end)] per step -- does the in-flight collective slow those kernels?
+        self.time_encoder_bwd, self.encoder_bwd_events = False, []
         if self.world > 1 or parallel.forced():
             parallel.broadcast_(model._flat, 0, self.pg)
             model.invalidate_packed()
@@ -227,10 +234,14 @@ class SynthMorphTrainer:
                 fn()
             dz.record_stream(side)
 
+        enc_ev0 = None
         for rec in reversed(tape):
             kind = rec[0]
             if kind == "conv":
                 _, li, x, up0, in1, y, leaky = rec
+                if li == self._bucket_li and self.time_encoder_bwd:
+                    enc_ev0 = torch.cuda.Event(enable_timing=True)
+                    enc_ev0.record()
                 if (self._reduce_early and li == self._bucket_li and self._bucket_li > 0 and side is None
                         and (self.world > 1 or parallel.forced())):
                     # every layer > li has its weight and bias gradient by now (a layer's bias sums are closed before its own
@@ -352,6 +363,10 @@ class SynthMorphTrainer:
             done = torch.cuda.Event()
             done.record(side)
             torch.cuda.current_stream().wait_event(done)
+        if enc_ev0 is not None:
+            enc_ev1 = torch.cuda.Event(enable_timing=True)
+            enc_ev1.record()
+            self.encoder_bwd_events.append((enc_ev0, enc_ev1))
         return grads
 
     # ------------------------------------------------------------------ one step
@@ -423,15 +438,30 @@ class SynthMorphTrainer:
         if next_labels is not None and self.render_at != "tail":
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream())   # whatever produced next_labels is already queued
-        self._reduce_early = True
+        if self._ar_early is not None:   # a previous step died between issuing bucket 1 and waiting for it
+            raise RuntimeError("train_step: an asynchronous gradient all-reduce of an earlier step is still pending")
+        self._reduce_early = self.early_reduce
         try:
             out = self.forward_backward(src_labels, trg_labels, draws_1, draws_2, train=True, next_labels=next_labels)
+        except BaseException:
+            # bucket 1 may already be in flight on every rank: retire it before the error leaves this step, so that a caller
+            # who catches it does not issue the next collective against a stale work object
+            h, self._ar_early = self._ar_early, None
+            if h is not None:
+                try:
+                    h.wait()
+                except Exception:
+                    pass
+            raise
         finally:
             self._reduce_early = False
         if self.world > 1 or parallel.forced():
-            with ops._Timed("comm:allreduce_grads", (self.world,), float(self.gflat.numel() * 4)):
+            n_late = self.goff[2 * (self._bucket_li + 1)] if self._ar_early is not None else self.gflat.numel()
+            # the EXPOSED part of the exchange: with two buckets, the encoder's few hundred KB plus the wait for bucket 1
+            # (which has been running under the encoder's backward); tagged with the bytes reduced inside this region
+            with ops._Timed("comm:allreduce_grads", (self.world, int(self._ar_early is not None)), float(n_late * 4)):
                 if self._ar_early is not None:   # bucket 1 (5.4 of 5.8 MB at 64 f) has been running since the last encoder conv
-                    parallel.allreduce_sum_(self.gflat[:self.goff[2 * (self._bucket_li + 1)]], self.pg)
+                    parallel.allreduce_sum_(self.gflat[:n_late], self.pg)
                     self._ar_early.wait()
                     self._ar_early = None
                 else:

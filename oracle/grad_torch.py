@@ -12,15 +12,27 @@ import torch.nn.functional as F
 DT = torch.float64
 
 
-def interpn(vol, loc):
-    """vol [*S, C], loc [*O, 3] -> [*O, C]; linear, clamp-to-edge."""
+def interpn(vol, loc, pin=None):
+    """vol [*S, C], loc [*O, 3] -> [*O, C]; linear, clamp-to-edge.
+
+    ``pin``: ANOTHER evaluation of ``loc`` (the HIP path's fp32 locations, as float64 values).  interpn is piecewise
+    multilinear in ``loc`` with a kink at every integer (``floor``) and at the two clamp bounds; where the two evaluations
+    fall on different sides of a kink the VALUE still agrees to rounding (the interpolant is continuous) but the gradient
+    w.r.t. ``loc`` is the slope of another cell.  With ``pin`` the cell index and the inside / outside decision are taken
+    from that other evaluation, so autograd differentiates the SAME piece (the analogue of ``unet(kinks=)`` for the tail)."""
     S = vol.shape[:3]
     idx, wts = [], []
     for d in range(3):
         mx = float(S[d] - 1)
         l = loc[..., d]
-        clipped = torch.clamp(l, 0.0, mx)
-        l0 = torch.clamp(torch.floor(l.detach()), 0.0, mx)
+        if pin is not None:
+            pl = pin[..., d]
+            inside = (pl >= 0.0) & (pl <= mx)
+            clipped = torch.where(inside, l, torch.clamp(l.detach(), 0.0, mx))
+            l0 = torch.clamp(torch.floor(pl), 0.0, mx)
+        else:
+            clipped = torch.clamp(l, 0.0, mx)
+            l0 = torch.clamp(torch.floor(l.detach()), 0.0, mx)
         l1 = torch.clamp(l0 + 1, 0.0, mx)
         w0 = l1 - clipped
         idx.append((l0.long(), l1.long()))
@@ -36,8 +48,8 @@ def grid(shape):
     return torch.stack(torch.meshgrid(*[torch.arange(s, dtype=DT) for s in shape], indexing="ij"), -1)
 
 
-def transform(vol, shift):
-    return interpn(vol, grid(shift.shape[:3]) + shift)
+def transform(vol, shift, pin=None):
+    return interpn(vol, grid(shift.shape[:3]) + shift, pin)
 
 
 def resize(vol, new_shape, grid="align_corners", zoom=None):
@@ -49,10 +61,11 @@ def resize(vol, new_shape, grid="align_corners", zoom=None):
     return interpn(vol, torch.stack(torch.meshgrid(*lin, indexing="ij"), -1))
 
 
-def vecint(v, nsteps):
+def vecint(v, nsteps, pins=None):
+    """``pins``: one location tensor per squaring step (see ``interpn``)."""
     v = v / (2 ** nsteps)
-    for _ in range(nsteps):
-        v = v + transform(v, v)
+    for k in range(nsteps):
+        v = v + transform(v, v, None if pins is None else pins[k])
     return v
 
 
@@ -117,14 +130,16 @@ def up(x):
     return x.repeat_interleave(2, 1).repeat_interleave(2, 2).repeat_interleave(2, 3)
 
 
-def unet(src, trg, ws, enc, dec, kinks=None):
+def unet(src, trg, ws, enc, dec, kinks=None, collect=None):
     """``kinks``: optional list with one tensor per LeakyReLU conv layer (execution order) holding ANOTHER
     evaluation of that layer's activated output (the HIP forward's).  The network is piecewise linear; two fp32-grade
     evaluations that differ by 5e-6 sit on different linear pieces at the ~1e-5 of the activations that lie that
     close to a LeakyReLU kink or a max-pool tie, and their exact gradients then differ by O(1) there.  With
     ``kinks`` the LeakyReLU slope (1 where kinks > 0, else 0.2) and the max-pool routing are taken from that other
     evaluation, so autograd returns the exact float64 gradient of the SAME linear piece -- which is what a
-    gradient-parity test at 1e-4 has to compare with.  Forward values change by at most 0.8 * 5e-6."""
+    gradient-parity test at 1e-4 has to compare with.  Forward values change by at most 0.8 * 5e-6.
+    ``collect``: a list that receives every LeakyReLU layer's activated output in execution order (this evaluation's own
+    kink positions, for tests that compare them with another evaluation's)."""
     nlev = len(enc)
     it = iter(range(0, len(ws), 2))
     kit = iter(kinks) if kinks is not None else None
@@ -133,7 +148,10 @@ def unet(src, trg, ws, enc, dec, kinks=None):
     def c(x, leaky=True):
         i = next(it)
         if not leaky or kit is None:
-            return conv(x, ws[i], ws[i + 1], leaky)
+            y = conv(x, ws[i], ws[i + 1], leaky)
+            if leaky and collect is not None:
+                collect.append(y.detach())
+            return y
         k = next(kit)
         last_k[0] = k
         z = conv(x, ws[i], ws[i + 1], False)
@@ -152,19 +170,33 @@ def unet(src, trg, ws, enc, dec, kinks=None):
     return c(last, leaky=False)
 
 
-def synthmorph_loss(src, trg, onehot1, onehot2, ws, enc, dec, int_steps, reg_param, kinks=None):
+def tail_pins_from(svf, steps, pos, int_steps):
+    """The fp32 sample locations of the HIP tail, rebuilt from its own tensors exactly as its kernels form them
+    (csrc/tail.hip: ``(float)x + f`` in fp32): per batch item {"vecint": [int_steps location tensors at half resolution],
+    "warp": the full-resolution one}.  svf [B,*h,3], steps [int_steps - 1, B,*h,3] (inputs of squaring steps 1..), pos [B,*S,3]:
+    fp32 CPU tensors."""
+    out = []
+    gh = grid(svf.shape[1:4]).float()
+    gf = grid(pos.shape[1:4]).float()
+    for b in range(svf.shape[0]):
+        v = [gh + svf[b].float() * (1.0 / (1 << int_steps))] + [gh + steps[k][b].float() for k in range(int_steps - 1)]
+        out.append({"vecint": [t.double() for t in v], "warp": (gf + pos[b].float()).double()})
+    return out
+
+
+def synthmorph_loss(src, trg, onehot1, onehot2, ws, enc, dec, int_steps, reg_param, kinks=None, tail_pins=None):
     """Sum over the batch of (Dice + 1) + Grad-l2 (what Keras differentiates, Appendix A11).
-    Returns (total, dice, grad[B], pos_flow, flow).  ``kinks``: see ``unet``."""
+    Returns (total, dice, grad[B], pos_flow, flow).  ``kinks``: see ``unet``; ``tail_pins``: ``tail_pins_from`` (see ``interpn``)."""
     flow = unet(src, trg, ws, enc, dec, kinks)
     B = flow.shape[0]
     half = tuple(s // 2 for s in flow.shape[1:4])
     pos = []
     for b in range(B):
         svf = 0.5 * resize(flow[b], half)
-        v = vecint(svf, int_steps)
+        v = vecint(svf, int_steps, None if tail_pins is None else tail_pins[b]["vecint"])
         pos.append(resize(2 * v, flow.shape[1:4]))
     pos = torch.stack(pos)
-    pred = torch.stack([transform(onehot1[b], pos[b]) for b in range(B)])
+    pred = torch.stack([transform(onehot1[b], pos[b], None if tail_pins is None else tail_pins[b]["warp"]) for b in range(B)])
     dice = dice_loss(onehot2, pred)
     gl = grad_l2(pos, reg_param)
     total = (dice + 1) * B + gl.sum()

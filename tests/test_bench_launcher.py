@@ -22,7 +22,7 @@ def test_launcher_refuses_more_nccl_ranks_than_devices():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 2 and r.stdout.strip() == ""
-    assert "needs 2 visible GPUs" in r.stderr and "device_count() = " in r.stderr
+    assert "needs 2 visible GPUs" in r.stderr and "found " in r.stderr
     assert time.time() - t0 < 120
 
 
@@ -57,7 +57,11 @@ def test_rank_environment_of_the_children(monkeypatch, tmp_path):
     def fake_popen(cmd, **kw):           # run the stub in place of `python bench.py ...`, same env / pipes
         return real_popen([sys.executable, str(stub)], **kw)
     monkeypatch.setattr(bench.subprocess, "Popen", fake_popen)
-    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 3)
+    monkeypatch.setattr(bench, "visible_gpu_count", lambda: (3, "test"))
+    def no_hip(*a, **k):
+        raise AssertionError("the launcher parent must not call into torch.cuda")
+    monkeypatch.setattr(bench.torch.cuda, "device_count", no_hip)
+    monkeypatch.setattr(bench.torch.cuda, "is_available", no_hip)
     monkeypatch.setattr(bench.sys, "stdout", open(tmp_path / "stdout.txt", "w"))
     rc = bench.launch_ranks(3, ["--gpus", "3"])
     bench.sys.stdout.close()
@@ -68,3 +72,26 @@ def test_rank_environment_of_the_children(monkeypatch, tmp_path):
     assert all(e["WORLD_SIZE"] == "3" and e["MASTER_ADDR"] == "127.0.0.1" and e["MMR_BENCH_LAUNCHED"] == "self" for e in envs)
     assert len({e["MASTER_PORT"] for e in envs}) == 1
     assert open(tmp_path / "stdout.txt").read().strip() == '{"rank": 0}'     # only rank 0's line is relayed
+
+
+def test_visible_gpu_count_needs_no_hip_call(monkeypatch):
+    """The launcher counts devices from the environment / sysfs, never through torch.cuda in its own process."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+
+    def no_hip(*a, **k):
+        raise AssertionError("visible_gpu_count called torch.cuda in the parent")
+    monkeypatch.setattr(bench.torch.cuda, "device_count", no_hip)
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2,5")
+    assert bench.visible_gpu_count() == (3, "HIP_VISIBLE_DEVICES")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpu_count() == (0, "HIP_VISIBLE_DEVICES")
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
+    assert bench.visible_gpu_count() == (1, "ROCR_VISIBLE_DEVICES")
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
+    n, how = bench.visible_gpu_count()      # sysfs (no /dev/kfd here: zero GPU nodes -> falls through to the child) or the child
+    assert n >= 0 and how in ("kfd topology", "child process", "unknown")

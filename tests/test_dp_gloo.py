@@ -79,3 +79,78 @@ def test_shard_helpers():
     with pytest.raises(ValueError):
         parallel.shard_rows(3, 0, 2)
     assert parallel.map_indices(10, 1, 4) == [1, 5, 9]
+
+
+# ---- world 4, the two-bucket exchange of the real trainer's flat gradient buffer (host logic, CPU tensors) ----
+ARCHS = {"64f": ([64] * 4, [64] * 6), "256f": ([256] * 4, [256] * 6)}
+
+
+def _bucket_trainer(arch):
+    """SynthMorphTrainer over a CPU-resident VxmDense: enough for the buffer layout and the bucket boundary (no kernel runs)."""
+    sys.path.insert(0, ROOT)
+    import mmr
+    from mmr import training
+
+    class _Gen:
+        L = 4
+    enc, dec = ARCHS[arch]
+    model = mmr.networks.VxmDense((16, 16, 16), nb_unet_features=(enc, dec), int_steps=5, int_resolution=2, svf_resolution=2,
+                                  compute_dtype="fp32x3", device="cpu", seed=0)
+    return training.SynthMorphTrainer(model, _Gen(), _Gen(), world_size=1, rank=0)
+
+
+def _worker4(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from mmr import parallel
+    parallel.init_from_env(backend="gloo")
+    res = {}
+    for arch in ARCHS:
+        tr = _bucket_trainer(arch)
+        n = tr.gflat.numel()
+        cut = tr.goff[2 * (tr._bucket_li + 1)]
+        g = torch.Generator().manual_seed(1000 * rank + len(arch))
+        local = torch.randn(n, generator=g)
+        # as train_step does it: bucket 1 (everything behind the encoder) asynchronously, then the encoder's bucket, then wait
+        tr.gflat.copy_(local)
+        h = parallel.allreduce_sum_async(tr.gflat[cut:])
+        assert h is not None
+        parallel.allreduce_sum_(tr.gflat[:cut])
+        h.wait()
+        two = tr.gflat.clone()
+        tr.gflat.copy_(local)
+        parallel.allreduce_sum_(tr.gflat)
+        res[arch] = {"two": two, "one": tr.gflat.clone(), "local": local, "cut": cut, "n": n}
+    torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_boundary_of_both_architectures():
+    """Bucket 1 = every gradient behind the last encoder conv (layers bucket_li + 1 .. flow head), bucket 2 = the encoder's:
+    the cut is goff[2 * (bucket_li + 1)], the offset of the first decoder kernel in Keras order."""
+    for arch, (enc, dec) in ARCHS.items():
+        tr = _bucket_trainer(arch)
+        f = enc[0]
+        assert tr._bucket_li == len(enc) - 1 == 3
+        enc_params = (27 * 2 * f + f) + 3 * (27 * f * f + f)          # conv0 (2 -> f) + three f -> f convs, kernels + biases
+        assert tr.goff[2 * (tr._bucket_li + 1)] == enc_params
+        assert tr.goff[2 * tr._bucket_li] < enc_params < tr.gflat.numel()
+        total = enc_params + (27 * f * f + f) + 3 * (27 * 2 * f * f + f) + (27 * (2 * f) * f + f) + (27 * f * f + f) + (27 * f * 3 + 3)
+        assert tr.gflat.numel() == total and len(tr.goff) == 22
+        # sizes quoted in the docs: 5.8 MB at 64 f (5.4 behind the encoder), 92 MB at 256 f
+        mb = tr.gflat.numel() * 4 / 1e6
+        assert (5.7 < mb < 5.9) if arch == "64f" else (91 < mb < 93)
+
+
+def test_world_4_two_bucket_allreduce_equals_one_bucket(tmp_path):
+    world = 4
+    mp.spawn(_worker4, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
+    for arch in ARCHS:
+        want = sum(r[arch]["local"].double() for r in rs)
+        for r in rs:
+            assert torch.equal(r[arch]["two"], rs[0][arch]["two"])                # every rank ends with the same buffer
+            assert torch.allclose(r[arch]["two"].double(), want, rtol=0, atol=1e-5)
+            assert torch.allclose(r[arch]["two"], r[arch]["one"], rtol=0, atol=1e-5)   # same sums as the single all-reduce

@@ -54,6 +54,18 @@ def test_default_line_carries_both_halves_of_the_metric():
     dp = d["dp_training"]
     assert dp["value"] == sec["value"] and dp["n_gpus"] == 1 and dp["ms_per_step"] == sec["ms_per_step"]
     assert d["dist"]["visible_devices"] >= 1 and d["dist"]["rank_devices"]
+    assert dp["early_reduce"] is True and dp["ms_per_step_single_bucket"] is None     # the A/B leg needs a process group
+    # north_star's latency: predict() with float64 NumPy volumes in / NumPy out, with its PCIe / host split;
+    # and BASELINE configs[3], the two-step cascade -- both driver-timed, neither part of `value`
+    pr = d["predict"]
+    assert "error" not in pr, pr
+    assert pr["calls"] == 5 and pr["warmup"] == 2 and pr["ms_per_pair"] > 0 and len(pr["runs_ms"]) == 5
+    for k in ("h2d_ms", "d2h_ms", "host_convert_ms", "host_pin_ms", "forward_ms_device_resident", "overhead_ms"):
+        assert isinstance(pr[k], float), k
+    assert pr["mode_in"] in ("register", "staging") and pr["mode_out"] == "staging"
+    ca = d["cascade"]
+    assert "error" not in ca, ca
+    assert ca["steps"] == 3 and ca["ms_per_pair"] > d["ms_per_step_without_events"] and "cascade" in ca["workload"]
 
 
 def test_gpus_2_starts_two_ranks():
@@ -63,14 +75,24 @@ def test_gpus_2_starts_two_ranks():
     d = _run("--gpus", "2", "--workload", "train", "--shape", "32", "32", "32", "--features", "32", "--steps", "2", "--warmup", "1",
              env={"MMR_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["dist"] == {**d["dist"], "world_size": 2, "backend": "gloo", "launched_by": "self"}
-    assert d["dist"]["allreduce_ms_per_step"] > 0 and d["dist"]["allreduce_bytes"] > 0 and "dp2" in d["config"]["parallelism"]
+    assert d["dist"]["allreduce_exposed_ms_per_step"] > 0 and d["dist"]["allreduce_bytes_total"] > d["dist"]["early_bucket_bytes"] > 0
+    assert d["dist"]["early_reduce"] is True and d["dist"]["encoder_bwd_ms"] > 0 and "dp2" in d["config"]["parallelism"]
+    d1 = _run("--gpus", "2", "--workload", "train", "--shape", "32", "32", "32", "--features", "32", "--steps", "2", "--warmup", "1",
+              "--no-early-reduce", env={"MMR_BENCH_BACKEND": "gloo"})
+    assert d1["dist"]["early_reduce"] is False and d1["dist"]["early_bucket_bytes"] == 0
+    assert d1["dist"]["allreduce_bytes_in_exposed_region"] == d1["dist"]["allreduce_bytes_total"] and "one bucket" in d1["config"]["parallelism"]
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     d = _run("--gpus", "2", "--shape", "32", "32", "32", "--features", "32", "--steps", "2", "--warmup", "1",
              env={"MMR_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["dist"]["world_size"] == 2 and d["secondary"]["n_gpus"] == 2
-    assert d["secondary"]["dist"]["allreduce_ms_per_step"] > 0 and "cpu_baseline" not in d
+    assert d["secondary"]["dist"]["allreduce_exposed_ms_per_step"] > 0 and "cpu_baseline" not in d
     dp = d["dp_training"]
-    assert dp["n_gpus"] == 2 and dp["allreduce_ms_per_step"] > 0 and dp["allreduce_bytes"] > 0 and dp["backend"] == "gloo"
+    assert dp["n_gpus"] == 2 and dp["allreduce_exposed_ms_per_step"] > 0 and dp["allreduce_bytes_total"] > 0 and dp["backend"] == "gloo"
+    # the first multi-rank record answers "does the overlapped bucket help?" by itself: both forms timed, and the encoder's
+    # backward segment with and without the collective in flight
+    assert dp["early_reduce"] is True and dp["ms_per_step_single_bucket"] > 0
+    assert dp["encoder_bwd_ms"] > 0 and dp["encoder_bwd_ms_single_bucket"] > 0
+    assert "same_workload_fp32" not in d["secondary"]      # one-rank leg only
     assert [r["rank"] for r in d["dist"]["rank_devices"]] == [0, 1]
 
 
@@ -79,6 +101,10 @@ def test_train_and_ncc_lines_small():
     assert KEYS <= set(d) and d["dtype"] == "fp32x3" and d["value"] > 0 and "dp1" in d["config"]["parallelism"]
     d = _run("--workload", "ncc", "--shape", "64", "64", "64", "--steps", "3", "--warmup", "1")
     assert KEYS <= set(d) and d["roofline"]["bound"] == "hbm" and d["roofline"]["unit"] == "GB/s"
+    bw = d["bwd"]      # configs[4] is a loss: its backward is timed too
+    assert "error" not in bw, bw
+    assert bw["ncc_bwd"]["ms"] > 0 and bw["bending_bwd"]["ms"] > 0 and abs(bw["ms_per_step"] - bw["ncc_bwd"]["ms"] - bw["bending_bwd"]["ms"]) < 1e-9
+    assert 0 < bw["ncc_bwd"]["frac_of_hbm_peak"] < 1 and 0 < bw["bending_bwd"]["frac_of_hbm_peak"] < 1
 
 
 def test_torchrun_form_two_ranks():
@@ -98,7 +124,7 @@ def test_torchrun_form_two_ranks():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["dist"]["world_size"] == 2 and d["dist"]["launched_by"] == "torchrun" and d["dist"]["allreduce_ms_per_step"] > 0
+    assert d["n_gpus"] == 2 and d["dist"]["world_size"] == 2 and d["dist"]["launched_by"] == "torchrun" and d["dist"]["allreduce_exposed_ms_per_step"] > 0
 
 
 def test_default_line_over_rccl_world_1():
@@ -109,5 +135,6 @@ def test_default_line_over_rccl_world_1():
              env={"MMR_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1"})
     assert d["dist"]["backend"] == "nccl" and d["dist"]["world_size"] == 1 and d["dist"]["rank_devices"][0]["rank"] == 0
     dp = d["dp_training"]
-    assert dp["backend"] == "nccl" and dp["allreduce_ms_per_step"] > 0 and dp["allreduce_bytes"] > 0
+    assert dp["backend"] == "nccl" and dp["allreduce_exposed_ms_per_step"] > 0 and dp["allreduce_bytes_total"] > 0
+    assert dp["ms_per_step_single_bucket"] > 0      # forced group: the single-bucket A/B leg runs over RCCL too
     assert "rccl" in d["config"]["collectives"]

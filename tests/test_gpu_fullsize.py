@@ -286,3 +286,155 @@ def test_c3_thin_backward_kernels_full_size(dev):
     ref = torch.where(x < 0, 0.2 * dx3, dx3)
     assert torch.equal(fused, ref)
     assert rel(db, ref.double().sum(dim=(0, 1, 2, 3)).float()) < 1e-5
+
+
+def _host_gb():
+    avail = float("inf")
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                avail = int(ln.split()[1]) / 1e6
+        v = open("/sys/fs/cgroup/memory.max").read().strip()
+        if v.isdigit():
+            avail = min(avail, int(v) / 1e9)
+    except OSError:
+        pass
+    return avail
+
+
+def test_c3_step_gradients_full_size_vs_float64_oracle(dev):
+    """BASELINE configs[2]'s own size -- 160^3, enc/dec = 64 (config/config.json:44-45), 26 labels, fp32x3, every folded kernel and
+    the pooling-backward epilogue engaged (asserted through the kernel families) -- all 22 gradient tensors of one step
+    (train_synthmorph.py:296-308) against the float64 gradient oracle on the HIP evaluation's linear piece: LeakyReLU slopes
+    and max-pool routing (``kinks``) AND the tail's floor / clamp cells (``tail_pins``; round 4's tool had the flow head's
+    bias gradient at 1.25e-4 because 83 voxels of d loss / d flow sat in a neighbouring interpolation cell).  Gate: north_star's
+    1e-4 of each tensor's max.  About five minutes of float64 CPU convolutions and ~45 GB of host memory: skipped below 60 GB
+    or with MMR_SKIP_FULLSIZE_GRAD=1."""
+    import os
+    import sys
+    import time
+    if os.environ.get("MMR_SKIP_FULLSIZE_GRAD") == "1":
+        pytest.skip("MMR_SKIP_FULLSIZE_GRAD=1")
+    if _host_gb() < 60:
+        pytest.skip(f"needs ~45 GB of host memory for the float64 oracle, {_host_gb():.0f} GB available")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_gpu_train as T
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), len(os.sched_getaffinity(0)))))
+    t0 = time.time()
+    rep = []
+    T._check_step_gradients(dev, "fp32x3", True, 1e-4, [64] * 4, [64] * 6, shape=(160, 160, 160), L=26, B=1, block=8, int_steps=5,
+                            families=("_upfold", "_cinit", "_dgfold", "wgrad_mfma_f32x3_upfold"), report=rep, tail_pins=True)
+    errs = {n: v for n, v in rep if n.endswith((" kernel", " bias"))}
+    assert len(errs) == 22, sorted(errs)
+    worst = max(errs, key=errs.get)
+    other = {n: v for n, v in rep if n not in errs}
+    print(f"160^3 / 26-label step, 22 gradient tensors vs float64 oracle [fp32x3, folded, tail pinned]: worst {errs[worst]:.2e} ({worst}), "
+          f"flow bias {errs['flow bias']:.2e}; d loss / d flow elementwise {other.get('d loss / d flow, elementwise (rel. to max)', float('nan')):.2e}; "
+          f"{time.time() - t0:.0f} s")
+    for n, v in errs.items():
+        assert v < 1e-4, f"{n}: {v:.2e} (all: {errs})"
+
+
+def test_kink_masks_of_the_hip_forward_match_the_float64_oracles_own(dev):
+    """Independent check of what ``kinks`` takes on trust: the gradient oracle differentiates on the LeakyReLU slopes and
+    max-pool routing of the HIP forward's activations, so a wrong sign mask in the HIP forward would be inherited.  Here the
+    float64 oracle runs the SAME network on its own (no kinks) and its masks are compared with the HIP forward's (exact-fp32
+    path, 96 x 96 x 128, config.json's architecture): they may differ only where an activation lies within fp32 rounding of a
+    kink -- a fraction of order 1e-5.  Asserted: sign mismatches < 3e-5 of all activations and arg-max mismatches < 3e-5 of
+    all pooling windows, in every layer."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import mmr
+    from mmr import training
+    from oracle import grad_torch as G
+    from oracle import net_np
+    shape, enc, dec = (96, 96, 128), [64] * 4, [64] * 6
+    rng = np.random.default_rng(11)
+    import scipy.ndimage as ndi
+    n = lambda v: ((v - v.min()) / (v.max() - v.min())).astype(np.float32)
+    src = n(ndi.gaussian_filter(rng.random(shape, dtype=np.float32), 1.5))[None, ..., None]
+    trg = n(ndi.gaussian_filter(rng.random(shape, dtype=np.float32), 1.5))[None, ..., None]
+    ws = net_np.init_weights(enc, dec, seed=3, flow_std=3e-2)
+    for i in range(1, len(ws), 2):
+        ws[i] = (rng.standard_normal(ws[i].shape) * 0.05).astype(np.float32)
+    model = mmr.networks.VxmDense(shape, nb_unet_features=(enc, dec), int_steps=5, int_resolution=2, svf_resolution=2, compute_dtype="fp32")
+    model.set_weights(ws)
+
+    class _G:
+        L = 2
+    tr = training.SynthMorphTrainer(model, _G(), _G())
+    tape = []
+    tr._forward(torch.from_numpy(src).to(dev), torch.from_numpy(trg).to(dev), tape)
+    hip = [(r[4] if r[0] == "conv0" else r[5]) for r in tape if r[0] == "conv0" or (r[0] == "conv" and r[6])]
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), len(os.sched_getaffinity(0)))))
+    own = []
+    with torch.no_grad():
+        G.unet(torch.from_numpy(src).double(), torch.from_numpy(trg).double(), [torch.from_numpy(w).double() for w in ws], enc, dec, collect=own)
+    assert len(own) == len(hip) == 10
+    tot = bad = 0
+    wtot = wbad = 0
+    worst = 0.0
+    for li, (h, o) in enumerate(zip(hip, own)):
+        h = h.cpu().double()
+        assert h.shape == o.shape
+        m = int(((h > 0) != (o > 0)).sum())
+        worst = max(worst, m / h.numel())
+        bad, tot = bad + m, tot + h.numel()
+        if li < len(enc):      # these four feed a MaxPooling3D(2)
+            ah, ao = G._windows(h).argmax(-1), G._windows(o).argmax(-1)
+            wm = int((ah != ao).sum())
+            wbad, wtot = wbad + wm, wtot + ah.numel()
+            assert wm < 3e-5 * ah.numel() + 2, (li, wm, ah.numel())
+        assert m < 3e-5 * h.numel() + 2, (li, m, h.numel())
+        # where the signs agree the values agree to fp32-grade rounding of this layer's scale
+        assert float((h - o).abs().max() / o.abs().max()) < 2e-5, li
+    print(f"kink masks, HIP exact-fp32 forward vs the float64 oracle's own at {shape}: LeakyReLU sign mismatches {bad} of {tot} "
+          f"= {bad / tot:.2e} (worst layer {worst:.2e}), max-pool arg-max mismatches {wbad} of {wtot} = {wbad / max(wtot, 1):.2e}")
+
+
+def test_c4_cascade_full_size_properties(dev):
+    """BASELINE configs[3] at its own size (bids_two_steps_registration.py:311-325,484-499: model 1 on (moving, fixed), model 2 on
+    (moved_1, fixed), compose the half-resolution fields, rescale x2, warp the ORIGINAL moving image) -- 160x160x192, enc/dec = 256,
+    bf16 -- through size-independent properties: with a zero second flow head the composed field IS stage 1's (compose(a, 0) = a,
+    bit for bit) and the final image is stage 1's moved image; with both heads live the result is finite, differs from both
+    single stages and is reproducible bit for bit."""
+    import mmr
+    enc, dec = [256] * 4, [256] * 6
+    g = torch.Generator(device="cpu").manual_seed(3)
+    lo = torch.rand((2, 1, 20, 20, 24, 1), generator=g)
+    mk = lambda t: mmr.ops.resize_trilinear(t.to(dev).contiguous(), C2)
+    mov, fix = mk(lo[0]), mk(lo[1])
+    m1 = mmr.networks.VxmDense(C2, nb_unet_features=(enc, dec), int_steps=5, int_resolution=2, svf_resolution=2, compute_dtype="bf16", seed=0)
+    m2 = mmr.networks.VxmDense(C2, nb_unet_features=(enc, dec), int_steps=5, int_resolution=2, svf_resolution=2, compute_dtype="bf16", seed=1)
+    for m, sd in ((m1, 5), (m2, 6)):     # flow heads large enough to move voxels (the init's N(0, 1e-5) would not)
+        w = m.get_weights()
+        w[-2][:] = (np.random.default_rng(sd).standard_normal(w[-2].shape) * 2e-2).astype(np.float32)
+        m.set_weights(w)
+
+    def cascade():
+        o1 = m1.forward(mov, fix)
+        o2 = m2.forward(o1["y_source"], fix)
+        warp = mmr.ops.compose(o1["preint_flow"], o2["preint_flow"])
+        full = mmr.ops.rescale_transform(warp, 2)
+        return o1, o2, warp, mmr.ops.warp3d(mov, full, "linear", None)
+    o1, o2, warp, out = cascade()
+    assert torch.isfinite(out).all() and torch.isfinite(warp).all()
+    assert float(o1["preint_flow"].abs().max()) > 0.05 and float(o2["preint_flow"].abs().max()) > 0.05
+    assert not torch.equal(warp, o1["preint_flow"]) and not torch.equal(out, o1["y_source"])
+    _, _, warp_b, out_b = cascade()
+    assert torch.equal(warp, warp_b) and torch.equal(out, out_b)          # reproducible bit for bit
+    s1_field, s1_moved = o1["preint_flow"].clone(), o1["y_source"].clone()
+    w = m2.get_weights()
+    w[-2][:] = 0
+    w[-1][:] = 0
+    m2.set_weights(w)
+    o1z, o2z, warp_z, out_z = cascade()
+    assert float(o2z["preint_flow"].abs().max()) == 0.0
+    assert torch.equal(o1z["preint_flow"], s1_field)
+    assert torch.equal(warp_z, s1_field)                                   # compose(a, 0) = 0 + a o id = a, exactly
+    # the final image warps the ORIGINAL moving image by rescale(svf_1): NOT the integrated field of stage 1 (3d_reg.py:317-334
+    # applies the pre-integration field), so it differs from stage 1's moved image but must equal Transform's result
+    tr = mmr.networks.Transform(C2, interp_method="linear", rescale=2)
+    ref = tr.predict([mov.cpu().numpy(), s1_field.cpu().numpy()])
+    assert np.array_equal(out_z.cpu().numpy(), ref)

@@ -186,3 +186,74 @@ def test_ncc_bending(dev, shape):                                               
     lin = np.zeros((1,) + shape + (3,), np.float32)
     lin[..., 1] = 0.5 * np.arange(shape[0], dtype=np.float32)[None, :, None, None]
     assert float(mmr.losses.BendingEnergy().loss(None, lin)[0]) < 1e-10  # affine field has no bending
+
+
+@pytest.mark.parametrize("shape", [(64, 40, 64), (48, 26, 66), (70, 20, 256)])      # four-z kernel, one-z kernel, whole 256-z rows
+@pytest.mark.parametrize("form", ["classic", "clamped"])
+def test_ncc_unnormalised_intensities_with_zero_background(dev, shape, form):
+    """Raw scanner intensities (0 .. 4095) inside a block, exact zeros around it -- the shape of a skull-stripped volume.  The
+    x window sums slide (add the joining plane, subtract the leaving one): once a column has left the block the sums must be
+    EXACTLY zero again (the reference's conv-based sums are, and cc = 0 / (0 + eps) = 0 there); a rounding residual of 1e-7 of
+    4095^2 x 729 in the variances would score O(1) garbage over the whole background.  Against the float64 oracle."""
+    import mmr
+    from oracle import ops_np as O
+    rng = np.random.default_rng(21)
+    X, Y, Z = shape
+    I = np.zeros((2,) + shape + (1,), np.float32)
+    J = np.zeros_like(I)
+    bx, by, bz = slice(X // 8, X // 8 + X // 4), slice(Y // 4, Y // 4 + Y // 3), slice(Z // 3 + 1, Z // 3 + 1 + Z // 4 + 1)   # ragged in z: lanes straddle
+    blk = I[:, bx, by, bz].shape
+    I[:, bx, by, bz] = rng.integers(0, 4096, blk).astype(np.float32)
+    J[:, bx, by, bz] = np.clip(0.7 * I[:, bx, by, bz] + rng.integers(0, 1500, blk), 0, 4095).astype(np.float32)
+    ref = O.ncc_loss(I, J, 9, form=form)
+    got = _np(mmr.ops.ncc_loss(torch.from_numpy(I).to(dev), torch.from_numpy(J).to(dev), 9, form=form))
+    np.testing.assert_allclose(got, ref, rtol=2e-4)
+    # same volume, block pushed against the far x face: the window leaves it through the volume border
+    I2, J2 = np.ascontiguousarray(I[:, ::-1]), np.ascontiguousarray(J[:, ::-1])
+    got2 = _np(mmr.ops.ncc_loss(torch.from_numpy(I2).to(dev), torch.from_numpy(J2).to(dev), 9, form=form))
+    np.testing.assert_allclose(got2, O.ncc_loss(I2, J2, 9, form=form), rtol=2e-4)
+    if form == "classic":     # windows wholly in the background contribute exactly nothing: an all-zero pair scores exactly 0
+        z = torch.zeros((1,) + shape + (1,), device=dev)
+        assert float(mmr.ops.ncc_loss(z, z, 9)[0]) == 0.0
+    if form == "classic" and shape[2] % 4 == 0:
+        dI, dJ = mmr.ops.ncc_loss_bwd(torch.from_numpy(I).to(dev), torch.from_numpy(J).to(dev))
+        from oracle import grad_torch as G
+        It, Jt = torch.from_numpy(I).double().requires_grad_(True), torch.from_numpy(J).double().requires_grad_(True)
+        G.ncc_loss(It, Jt).sum().backward()
+        assert float((dI.cpu().double() - It.grad).abs().max() / It.grad.abs().max()) < 1e-3
+
+
+def test_loss_reductions_finish_in_kernel_and_accumulate(dev):
+    """mmr_ncc_fwd_ticket_f32 / mmr_bending_fwd_ticket_f32: the last workgroup adds the partials (no finalize launch), `out` may
+    carry a running total (out += scale * loss), the ticket word returns to zero so that the next call finds it so, and the sums
+    are reproducible bit for bit -- and equal to the two-launch entry points'."""
+    import ctypes
+    import mmr
+    from mmr import _lib
+    g = torch.Generator(device="cpu").manual_seed(4)
+    S = (40, 24, 64)
+    I, J = torch.rand((2,) + S + (1,), generator=g).to(dev), torch.rand((2,) + S + (1,), generator=g).to(dev)
+    flow = torch.randn((2,) + S + (3,), generator=g).to(dev)
+    a = mmr.ops.ncc_loss(I, J, 9)
+    b = mmr.ops.bending_energy(flow)
+    for _ in range(3):
+        assert torch.equal(mmr.ops.ncc_loss(I, J, 9), a) and torch.equal(mmr.ops.bending_energy(flow), b)
+    tot = mmr.ops.ncc_loss(I, J, 9)
+    mmr.ops.bending_energy(flow, out=tot, scale=0.25)
+    assert torch.allclose(tot, a + 0.25 * b, rtol=1e-6, atol=0)
+    tot2 = mmr.ops.bending_energy(flow)
+    mmr.ops.ncc_loss(I, J, 9, out=tot2, scale=2.0)
+    assert torch.allclose(tot2, b + 2.0 * a, rtol=1e-6, atol=0)
+    assert int(mmr.ops._ticket(I.device).abs().sum()) == 0
+    # the two-launch entry points of the C-ABI give the same bits
+    lib = _lib.load()
+    B, X, Y, Z = 2, *S
+    ws = torch.empty(int(lib.mmr_ncc_ws_bytes(B, X, Y, Z)) + 64, dtype=torch.uint8, device=dev)
+    out = torch.empty(B, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.mmr_ncc_fwd_f32(I.data_ptr(), J.data_ptr(), out.data_ptr(), ws.data_ptr(), B, X, Y, Z, 9, 1e-5, 0, st) == 0
+    assert torch.equal(out, a)
+    ws = torch.empty(int(lib.mmr_bending_ws_bytes(B, X, Y, Z)) + 64, dtype=torch.uint8, device=dev)
+    assert lib.mmr_bending_fwd_f32(flow.data_ptr(), out.data_ptr(), ws.data_ptr(), B, X, Y, Z, st) == 0
+    assert torch.equal(out, b)
+    assert lib.mmr_ncc_fwd_ticket_f32(I.data_ptr(), J.data_ptr(), out.data_ptr(), ws.data_ptr(), None, B, X, Y, Z, 9, 1e-5, 0, 1.0, 0, st) == -1

@@ -310,7 +310,8 @@ def test_full_training_step_gradients(dev, cdt, kinks, tol, enc, dec):
     _check_step_gradients(dev, cdt, kinks, tol, enc, dec)
 
 
-def _check_step_gradients(dev, cdt, kinks, tol, enc, dec, shape=(16, 16, 32), L=5, B=2, block=4, int_steps=3, families=(), report=None):
+def _check_step_gradients(dev, cdt, kinks, tol, enc, dec, shape=(16, 16, 32), L=5, B=2, block=4, int_steps=3, families=(), report=None,
+                          tail_pins=False):
     """Every gradient tensor of one SynthMorph step (train_synthmorph.py:296-308) against oracle/grad_torch.synthmorph_loss;
     ``families``: kernel-family suffixes that must have run (ops.PROFILE) -- the folded launches at sizes where they engage."""
     import mmr
@@ -361,8 +362,11 @@ def _check_step_gradients(dev, cdt, kinks, tol, enc, dec, shape=(16, 16, 32), L=
     if kinks:  # activated outputs of the LeakyReLU layers, execution order (tape: conv0 / conv records)
         kk = [(r[4] if r[0] == "conv0" else r[5]).cpu().double() for r in tape
               if r[0] == "conv0" or (r[0] == "conv" and r[6])]
+    tp = None
+    if tail_pins:   # the tail's floor / clamp pieces of the HIP evaluation (oracle/grad_torch.interpn(pin=))
+        tp = G.tail_pins_from(svf.cpu(), steps.cpu(), pos.cpu(), int_steps)
     total, rdice, rgl, rpos, rflow = G.synthmorph_loss(ima1.cpu().double(), ima2.cpu().double(), gen1["onehot"].cpu().double(),
-                                                      gen2["onehot"].cpu().double(), wt, enc, dec, int_steps, 0.8, kinks=kk)
+                                                      gen2["onehot"].cpu().double(), wt, enc, dec, int_steps, 0.8, kinks=kk, tail_pins=tp)
     if report is not None:
         rflow.retain_grad()
     total.backward()

@@ -317,3 +317,36 @@ def test_cpu_training_step_restatement_runs_and_learns():
     assert all(np.isfinite(l) for l in losses) and G.DT == torch.float64   # the dtype switch is restored
     assert any(not torch.equal(a, b.detach()) for a, b in zip(w0, st.ws))
     assert 0.0 < losses[-1] < 2.0
+
+
+def test_gradient_oracle_interpn_pin_selects_the_cell_not_the_value():
+    """oracle/grad_torch.interpn(pin=): with the cell taken from another evaluation of the location the VALUE is unchanged
+    (the interpolant is continuous across a cell boundary) while the gradient w.r.t. the location is the pinned cell's slope."""
+    import torch
+    from oracle import grad_torch as G
+    vol = torch.tensor([0.0, 1.0, 3.0, 6.0], dtype=torch.float64).view(4, 1, 1, 1).expand(4, 2, 2, 1).contiguous()
+    for x, pin_x, slope in ((1.0 - 1e-9, 1.0 + 1e-9, 2.0), (1.0 + 1e-9, 1.0 - 1e-9, 1.0), (1.5, 1.5, 2.0)):
+        loc = torch.tensor([[x, 0.0, 0.0]], dtype=torch.float64, requires_grad=True)
+        pin = torch.tensor([[pin_x, 0.0, 0.0]], dtype=torch.float64)
+        v = G.interpn(vol, loc, pin)
+        v.sum().backward()
+        free = G.interpn(vol, loc.detach())
+        assert abs(float(v) - float(free)) < 1e-8              # same value up to the 1e-9 offset times a slope
+        assert abs(float(loc.grad[0, 0]) - slope) < 1e-12       # ... but the slope of the PINNED cell
+    # outside the volume on the pinned side: clamp-to-edge, no gradient
+    loc = torch.tensor([[1e-9, 0.0, 0.0]], dtype=torch.float64, requires_grad=True)
+    v = G.interpn(vol, loc, torch.tensor([[-1e-9, 0.0, 0.0]], dtype=torch.float64))
+    v.sum().backward()
+    assert float(loc.grad[0, 0]) == 0.0 and abs(float(v)) < 1e-8
+    # pin == own location: identical to the unpinned call, values and gradients
+    g = torch.Generator().manual_seed(0)
+    vol = torch.rand((5, 6, 7, 2), generator=g, dtype=torch.float64)
+    shift = (torch.rand((5, 6, 7, 3), generator=g, dtype=torch.float64) - 0.5) * 4
+    a = shift.clone().requires_grad_(True)
+    b = shift.clone().requires_grad_(True)
+    G.transform(vol, a).sum().backward()
+    G.transform(vol, b, G.grid((5, 6, 7)) + shift).sum().backward()
+    assert torch.equal(a.grad, b.grad)
+    pins = G.tail_pins_from(torch.zeros(1, 4, 4, 4, 3), torch.zeros(2, 1, 4, 4, 4, 3), torch.zeros(1, 8, 8, 8, 3), 3)
+    assert len(pins) == 1 and len(pins[0]["vecint"]) == 3 and pins[0]["warp"].shape == (8, 8, 8, 3)
+    assert torch.equal(pins[0]["vecint"][1], G.grid((4, 4, 4)))
