@@ -399,6 +399,8 @@ int mmr_host_register(void* p, int64_t bytes, void** dev_ptr);
 int mmr_host_unregister(void* p);
 int mmr_cast_to_f32(const void* src, float* dst, int64_t n, int src_dtype, void* stream);
 int mmr_copy_to_host(const void* src_dev, void* dst_host, int64_t bytes, void* stream);
+/* copy-engine transfer (no compute unit): pinned / registered host memory <-> device; kind 0 = host -> device, 1 = device -> host */
+int mmr_memcpy_async(void* dst, const void* src, int64_t bytes, int kind, void* stream);
 
 #ifdef __cplusplus
 }

@@ -130,6 +130,7 @@ SIGNATURES = {
     "mmr_host_unregister": (I, [P]),
     "mmr_cast_to_f32": (I, [P, P, c_int64, I, P]),
     "mmr_copy_to_host": (I, [P, P, c_int64, P]),
+    "mmr_memcpy_async": (I, [P, P, c_int64, I, P]),
 }
 
 

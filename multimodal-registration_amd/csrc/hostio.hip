@@ -128,3 +128,14 @@ extern "C" int mmr_copy_to_host(const void* src_dev, void* dst_host, int64_t byt
                                                           static_cast<uint32_t*>(dst_host), nw);
     return check_launch();
 }
+
+// Copy-engine transfer between pinned (mmr_host_alloc / mmr_host_register) host memory and the device: no compute unit is
+// involved, which matters beside kernels that own whole CUs (a PCIe-reading kernel on a side stream kept the 512-thread conv
+// workgroups off every CU it sat on: predict() on a batch of pairs ran SLOWER overlapped than serial).  kind 0 = host -> device,
+// 1 = device -> host.
+extern "C" int mmr_memcpy_async(void* dst, const void* src, int64_t bytes, int kind, void* stream)
+{
+    if (!dst || !src || bytes < 0 || (kind != 0 && kind != 1)) return MMR_EINVAL;
+    if (bytes == 0) return MMR_OK;
+    return hip_rc(hipMemcpyAsync(dst, src, (size_t)bytes, kind == 0 ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, as_stream(stream)));
+}

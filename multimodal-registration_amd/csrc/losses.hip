@@ -26,11 +26,14 @@ __device__ __forceinline__ double block_sum(double v, double* sh /* >= 4 doubles
     return r;
 }
 
-// In-kernel finalize of a per-workgroup-partials reduction (no second launch): every workgroup stores its double partial, then
-// takes a ticket; the workgroup that draws the LAST ticket sums all partials in index order (the same order whichever
+// In-kernel finalize of a per-workgroup-partials reduction (no second launch): every workgroup publishes its double partial,
+// then takes a ticket; the workgroup that draws the LAST ticket sums all partials in index order (the same order whichever
 // workgroup that is -> bitwise reproducible, like mean_final_kernel) and writes out[b] = (+= when accumulate) sign * sum / denom.
 // `ticket` must be ZERO when the kernel starts and is zero again when it ends (one ticket word per concurrently running call).
-// The fences are at agent scope: partials written through another XCD's L2 are written back / this XCD's copies invalidated.
+// Cross-XCD visibility WITHOUT fences: the partial is stored, the ticket bumped and the partials read back with agent-scope
+// atomics (write-through / L2-bypassing accesses), ordered by an explicit vmcnt(0) between the store and the ticket.  A
+// `__threadfence()` per workgroup measured 57 -> 110 us on the bending kernel: its `buffer_inv sc1` empties the L2 the other
+// workgroups are streaming through.
 struct TicketFin {
     unsigned* ticket;   // nullptr: no in-kernel finalize (the caller launches mean_final_kernel)
     float* out;
@@ -41,8 +44,16 @@ struct TicketFin {
     int accumulate;
 };
 
+// this workgroup's partial: a plain store without a ticket, an agent-scope (write-through) one with
+__device__ __forceinline__ void publish_partial(double* part, long long idx, double r, const TicketFin& f)
+{
+    if (f.ticket) __hip_atomic_store(part + idx, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else part[idx] = r;
+}
+
 // `scratch`: >= 256 B of shared memory, 8-B aligned, that no thread of the workgroup still reads or writes (the kernels pass
-// their own, no longer needed, tile: a static __shared__ here would push the 80-KB NCC tile past two workgroups per CU)
+// their own, no longer needed, tile: a static __shared__ here would push the 80-KB NCC tile past two workgroups per CU).
+// Call after thread 0 has run publish_partial.
 __device__ __forceinline__ void ticket_finalize(const double* part, const TicketFin& f, char* scratch)
 {
     if (f.ticket == nullptr) return;
@@ -50,23 +61,23 @@ __device__ __forceinline__ void ticket_finalize(const double* part, const Ticket
     double* s_red = reinterpret_cast<double*>(scratch + 64);
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();                                         // this workgroup's partial is visible device-wide ...
-        const unsigned t = atomicAdd(f.ticket, 1u);              // ... before its ticket is
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the partial has been written through ...
+        const unsigned t = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the ticket counts it
         s_last = (t == gridDim.x * gridDim.y - 1u) ? 1 : 0;
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     for (int b = 0; b < f.nout; ++b) {
         double a = 0.0;
-        for (long long k = threadIdx.x; k < f.nb; k += blockDim.x) a += __builtin_nontemporal_load(part + (long long)b * f.nb + k);
+        for (long long k = threadIdx.x; k < f.nb; k += blockDim.x)
+            a += __hip_atomic_load(part + (long long)b * f.nb + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const double r = block_sum(a, s_red);
         if (threadIdx.x == 0) {
             const float v = (float)((double)f.sign * r / f.denom);
             f.out[b] = f.accumulate ? f.out[b] + v : v;
         }
     }
-    if (threadIdx.x == 0) atomicExch(f.ticket, 0u);
+    if (threadIdx.x == 0) __hip_atomic_store(f.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------ Dice ------------------------------------ //
@@ -605,7 +616,7 @@ ncc_fused_kernel(const float* __restrict__ I, const float* __restrict__ J, doubl
         double r = 0.0;
 #pragma unroll
         for (int i = 0; i < NF_WAVES; ++i) r += sh[i];
-        part[blockIdx.x] = r;
+        publish_partial(part, blockIdx.x, r, fin);
     }
     ticket_finalize(part, fin, smem);      // (its first __syncthreads separates this from the last tile reads)
 }
@@ -868,7 +879,7 @@ ncc_fused4_kernel(const float* __restrict__ I, const float* __restrict__ J, doub
         double r = 0.0;
 #pragma unroll
         for (int i = 0; i < N4_WAVES; ++i) r += sh[i];
-        part[lblk] = r;
+        publish_partial(part, lblk, r, fin);
     }
     ticket_finalize(part, fin, smem + 1024);
 }
@@ -975,7 +986,7 @@ bending_fused_kernel(const float* __restrict__ u, double* __restrict__ part, int
         }
     }
     const double r = block_sum((double)acc, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = r;
+    if (threadIdx.x == 0) publish_partial(part, blockIdx.x, r, fin);
     ticket_finalize(part, fin, fin_scratch);
 }
 

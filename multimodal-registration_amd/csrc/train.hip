@@ -2018,7 +2018,9 @@ smallch_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ 
 // three v_mfma_f32_32x32x16_bf16 of bf16 (hi, lo) halves.  The contraction runs over voxels, so both operands need 8
 // consecutive voxels per lane: a k-step is two z-rows of 8 voxels and LDS holds, per operand, 16-byte cells of 8
 // z-consecutive bf16 -- one ds_read_b128 per fragment, no transposing read:
-//   sD [hi|lo][d = 64][z-row = 16] cells (+16 B per d: lanes = consecutive d, conflict-free)
+//   sD [hi|lo][d = 64][z-row = 16] cells, 256 B per d, the z-row XOR-swizzled with tw_dswz(d): conflict-free for the fragment
+//      reads (lanes = consecutive d) AND for the staging stores (lanes = every fourth d; with the round-2 layout, +16 B per d and
+//      no swizzle, those were 4-way conflicted: 58 % of the kernel's LDS cycles, profiles/r04k_train_pmc_sq.json)
 //   sS [hi|lo][c][dz = 3][haloed (x, y) row = 40] cells: the z window of every tap shift is stored as its own
 //      aligned cell, so the gather G[v][tap, c] = S[v +- off(tap)][c] is a lane-constant offset + the row.
 // Tile = 2 x 8 x 8 voxels (16 z-rows = 8 k-steps, two per wave); the next tile's dense operand (8 x 16 B per thread)
@@ -2026,9 +2028,19 @@ smallch_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ 
 // wave partials are summed in a fixed order through LDS: one [64][96] partial per workgroup.
 constexpr int TW_TX = 2, TW_TY = 8, TW_TZ = 8;
 constexpr int TW_HX = TW_TX + 2, TW_HY = TW_TY + 2;
-constexpr int TW_DSTR = 16 * 16 + 16;                 // bytes per dense channel
+constexpr int TW_DSTR = 16 * 16;                      // bytes per dense channel
 constexpr int TW_DHL = 64 * TW_DSTR;                  // hi -> lo plane
-constexpr int TW_D_BYTES = 2 * TW_DHL;                // 34,816
+constexpr int TW_D_BYTES = 2 * TW_DHL;                // 32,768
+// z-row swizzle of dense channel d.  A ds_read_b128 lane group holds 16 channels with distinct d mod 16 ({0-3, 12-15, 20-27} /
+// {4-11, 16-19, 28-31}): pi(d & 15) ^ (bit 4 of d) << 2 with pi = swap of the two 2-bit halves is a bijection onto the 16 slots
+// for both groups.  A ds_write_b128 group is 8 lanes with d = 4 k + j (k = 0 .. 7): pi puts k & 3 into the low bits and bit 4 of d
+// (= k >> 2) flips bit 2, so the 8 lanes take the 8 slots of the 32 banks.
+__host__ __device__ inline int tw_dswz(int d) { return (((d >> 2) & 3) | ((d & 3) << 2)) ^ (((d >> 4) & 1) << 2); }
+// Column order of the small operand.  Column position j = n * 32 + li of the three N tiles holds the (tap, c) combination
+// g[j] & 127; bit 7 marks a padding column (it re-reads the cell of another lane of its group: a broadcast).  The host deals
+// the 27 Cs real columns over the six ds_read_b128 lane groups so that no two lanes of a group fall on the same 4-bank slot
+// (in natural order the S fragment reads were 2-way conflicted); the partials are stored back in natural order.
+struct TwPerm { unsigned char g[96]; };
 constexpr int TW_SPL = TW_HX * TW_HY * 16 + 16;       // bytes per (c, dz) plane of S
 constexpr int TW_SHL = 9 * TW_SPL;                    // hi -> lo plane (Cs <= 3)
 constexpr int TW_S_BYTES = 2 * TW_SHL;                // 11,808
@@ -2050,7 +2062,7 @@ __device__ __forceinline__ void tw_split_pair(float a, float b, unsigned& hi, un
 __global__ void __launch_bounds__(SM_THREADS, 2)
 thin_wgrad_x3_kernel(const float* __restrict__ dense, int Cd, const float* __restrict__ s0, const float* __restrict__ s1,
                      int Cs, int sign, float* __restrict__ part, int B, int X, int Y, int Z, int ntx, int nty, int ntz,
-                     int ntiles)
+                     int ntiles, const TwPerm perm)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sD = smem;
@@ -2064,9 +2076,10 @@ thin_wgrad_x3_kernel(const float* __restrict__ dense, int Cd, const float* __res
     int aoff[2], boff[3];
 #pragma unroll
     for (int m = 0; m < 2; ++m) aoff[m] = (m * 32 + li) * TW_DSTR;
+    const int dsw = tw_dswz(li);                    // = tw_dswz(32 + li)
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
-        const int g = n * 32 + li;
+        const int g = perm.g[n * 32 + li] & 127;
         int o = 0;
         if (g < KG) {
             const int tap = g / Cs, c = g - tap * Cs;
@@ -2163,7 +2176,7 @@ thin_wgrad_x3_kernel(const float* __restrict__ dense, int Cd, const float* __res
         __syncthreads();   // every wave has finished the previous tile's fragments
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            char* o = sD + (dc4 * 4 + j) * TW_DSTR + drow * 16;
+            char* o = sD + (dc4 * 4 + j) * TW_DSTR + ((drow ^ tw_dswz(dc4 * 4 + j)) << 4);
             *reinterpret_cast<tw_u32x4*>(o) = dh[j];
             *reinterpret_cast<tw_u32x4*>(o + TW_DHL) = dl[j];
         }
@@ -2181,7 +2194,7 @@ thin_wgrad_x3_kernel(const float* __restrict__ dense, int Cd, const float* __res
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int row = wave * 4 + e * 2 + h;
-            const char* ap = sD + row * 16;
+            const char* ap = sD + ((row ^ dsw) << 4);
             const char* bp = sS + ((row >> 3) * TW_HY + (row & 7)) * 16;
             bf16x8_t ah[2], al[2], bh[3], bl[3];
 #pragma unroll
@@ -2223,7 +2236,54 @@ thin_wgrad_x3_kernel(const float* __restrict__ dense, int Cd, const float* __res
     }
     __syncthreads();
     float* o = part + ((size_t)blockIdx.x * gridDim.y + cb) * (64 * 96);
-    for (int i = tid; i < 64 * 96; i += SM_THREADS) o[i] = red[i];
+    for (int i = tid; i < 64 * 96; i += SM_THREADS) {     // back to natural column order (padding columns are dropped)
+        const int d = i / 96, j = i - d * 96;
+        const int g = perm.g[j];
+        if (g < 128) o[d * 96 + g] = red[i];
+    }
+}
+
+// Deal the KG = 27 Cs real columns over the six 16-lane groups of the S fragment reads (positions n * 32 + {0-3, 12-15, 20-27}
+// and n * 32 + {4-11, 16-19, 28-31}) so that the 16-B cells of a group lie in distinct 4-bank slots: slot = (byte offset / 16)
+// mod 16 of the lane-constant part of the address (the row-dependent part is the same for the whole group).
+static TwPerm tw_make_perm(int Cs, int sign)
+{
+    const int KG = 27 * Cs;
+    static const int G1[16] = {0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27};
+    static const int G2[16] = {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31};
+    int slot[96], cnt[6] = {0, 0, 0, 0, 0, 0}, member[6][16];
+    bool used[6][16] = {};
+    for (int g = 0; g < KG; ++g) {
+        const int tap = g / Cs, c = g - tap * Cs;
+        const int ox = sign * (tap / 9 - 1), oy = sign * ((tap / 3) % 3 - 1), oz = sign * (tap % 3 - 1);
+        slot[g] = (((c * 3 + oz + 1) * TW_SPL + ((ox + 1) * TW_HY + (oy + 1)) * 16) / 16) & 15;
+    }
+    bool ok = true;
+    for (int sl = 0; sl < 16 && ok; ++sl)
+        for (int g = 0; g < KG && ok; ++g) {
+            if (slot[g] != sl) continue;
+            int best = -1;
+            for (int k = 0; k < 6; ++k)
+                if (!used[k][sl] && cnt[k] < 16 && (best < 0 || cnt[k] < cnt[best])) best = k;
+            if (best < 0) { ok = false; break; }
+            used[best][sl] = true;
+            member[best][cnt[best]++] = g;
+        }
+    TwPerm p;
+    if (!ok) {   // (never for Cs = 2, 3; any order is correct, only slower)
+        for (int j = 0; j < 96; ++j) p.g[j] = (unsigned char)(j < KG ? j : 128);
+        return p;
+    }
+    for (int k = 0; k < 6; ++k) {
+        const int n = k >> 1;
+        const int* lanes = (k & 1) ? G2 : G1;
+        for (int i = 0; i < 16; ++i) {
+            const int j = n * 32 + lanes[i];
+            if (i < cnt[k]) p.g[j] = (unsigned char)member[k][i];
+            else p.g[j] = (unsigned char)(128 | (cnt[k] ? member[k][0] : 0));   // padding: broadcast of the group's first cell
+        }
+    }
+    return p;
 }
 
 static int launch_thin_wgrad_x3(const float* dense, int Cd, const float* s0, const float* s1, int Cs, int sign, float* dw,
@@ -2235,8 +2295,9 @@ static int launch_thin_wgrad_x3(const float* dense, int Cd, const float* s0, con
     int gx = 512 / ncb;
     if (gx > ntiles) gx = ntiles;
     if (gx < 1) gx = 1;
+    const TwPerm perm = tw_make_perm(Cs, sign);
     hipLaunchKernelGGL(thin_wgrad_x3_kernel, dim3(gx, ncb), dim3(SM_THREADS), TW_LDS, as_stream(stream), dense, Cd, s0, s1,
-                       Cs, sign, (float*)ws, B, X, Y, Z, ntx, nty, ntz, ntiles);
+                       Cs, sign, (float*)ws, B, X, Y, Z, ntx, nty, ntz, ntiles, perm);
     int rc = check_launch();
     if (rc) return rc;
     hipLaunchKernelGGL(smallch_wgrad_reduce_kernel, dim3(Cd * 27 * Cs), dim3(64), 0, as_stream(stream), (const float*)ws, dw,

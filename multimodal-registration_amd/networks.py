@@ -490,74 +490,90 @@ class VxmDense:
         return [np.concatenate(out_m), np.concatenate(out_f)]
 
     def _predict_overlapped(self, src, trg, n):
-        """Pairs b - 1 / b / b + 1 in flight at once: while pair b is in the forward, pair b + 1 is memcpy'd into cached pinned
-        staging memory and converted to fp32 by the cast kernel, and pair b - 1's outputs are copied out, both on a side
-        stream (two staging slots per direction; events order every hand-over).  Same kernels on the same inputs: results
-        identical to the one-pair path."""
+        """Pairs b - 1 / b / b + 1 in flight at once.  The four host arrays of the whole call (both inputs, both outputs) are pinned
+        where they lie for its duration; on a side stream the cast kernel reads pair b + 1 over PCIe and the copy kernel writes
+        pair b - 1's outputs straight into the result arrays while pair b is in the forward (events order every hand-over) -- by
+        the copy engines (mmr_memcpy_async), not by kernels: nothing competes with the forward for compute units.  The host only
+        enqueues.  Same kernels on the same inputs: results identical to the one-pair path; if the runtime refuses to
+        pin an array, the pairs go through that path one by one."""
         import ctypes
         from . import _lib, hostio
         dev = self.device
-        main = torch.cuda.current_stream(dev)
-        if getattr(self, "_copy_stream", None) is None:
-            self._copy_stream = torch.cuda.Stream(device=dev)
-        cs = self._copy_stream
-        lib = _lib.load()
+        prep = []
+        for a in (src, trg):
+            a = _as_np(a)
+            if a.dtype not in hostio._CODES:
+                a = a.astype(np.float64)
+            prep.append(np.ascontiguousarray(a))
+        half = tuple(s // self.svf_resolution for s in self.inshape)
+        out_m = np.empty((n,) + self.inshape + (1,), np.float32)
+        out_f = np.empty((n,) + half + (3,), np.float32)
+        regs = [hostio.Registered(a).__enter__() for a in (prep[0], prep[1], out_m, out_f)]
+        try:
+            if not all(r.ok for r in regs) or any(r.dev % 16 for r in regs):
+                res = [self.predict([prep[0][b:b + 1], prep[1][b:b + 1]]) for b in range(n)]
+                return [np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res])]
+            main = torch.cuda.current_stream(dev)
+            if getattr(self, "_copy_stream", None) is None:
+                self._copy_stream = torch.cuda.Stream(device=dev)
+            cs = self._copy_stream
+            cs.wait_stream(main)
+            lib = _lib.load()
+            per = [a[0:1].size for a in prep]
+            code = [hostio._CODES[a.dtype] for a in prep]
 
-        def stage_in(b):
-            slot = b & 1
-            devs = []
-            for k, a in enumerate((src, trg)):
-                a = _as_np(a[b:b + 1])
-                if a.dtype not in hostio._CODES:
-                    a = a.astype(np.float64)
-                st = hostio.staging(max(a.nbytes, 16), ("in2", slot, k))
-                st.wait()                             # the kernel that last read this slot has finished
-                np.copyto(st.view(a.dtype, a.shape), a)   # plain memcpy, while the GPU works on pair b - 1
+            tdt = {hostio.F64: torch.float64, hostio.F32: torch.float32, hostio.U8: torch.uint8, hostio.I16: torch.int16}
+
+            def stage_in(b):
+                # copy ENGINE into a device buffer of the caller's dtype, then a device-side cast (microseconds): a kernel that
+                # reads PCIe for a millisecond would sit on every CU and keep the forward's 512-thread workgroups off them
+                devs = []
                 with torch.cuda.stream(cs):
-                    d = torch.empty(a.shape, dtype=torch.float32, device=dev)
-                    _lib.check(lib.mmr_cast_to_f32(ctypes.c_void_p(st.ptr), d.data_ptr(), a.size, hostio._CODES[a.dtype],
-                                                   cs.cuda_stream), "mmr_cast_to_f32")
+                    for k in range(2):
+                        raw = torch.empty((1,) + prep[k].shape[1:], dtype=tdt[code[k]], device=dev)
+                        srcp = prep[k].ctypes.data + b * per[k] * prep[k].itemsize
+                        _lib.check(lib.mmr_memcpy_async(raw.data_ptr(), ctypes.c_void_p(srcp), per[k] * prep[k].itemsize, 0, cs.cuda_stream),
+                                   "mmr_memcpy_async")
+                        if code[k] == hostio.F32:
+                            d = raw
+                        else:
+                            d = torch.empty(raw.shape, dtype=torch.float32, device=dev)
+                            _lib.check(lib.mmr_cast_to_f32(raw.data_ptr(), d.data_ptr(), per[k], code[k], cs.cuda_stream), "mmr_cast_to_f32")
+                        d.record_stream(main)
+                        devs.append(d)
                     ev = torch.cuda.Event()
                     ev.record(cs)
-                st.event = ev
-                d.record_stream(main)
-                devs.append(d)
-            return devs[0], devs[1], ev
-        out_m, out_f, pending = [None] * n, [None] * n, [None, None]
-
-        def collect(slot):
-            if pending[slot] is not None:
-                b, ev, sm, sf, shm, shf = pending[slot]
-                ev.synchronize()
-                out_m[b], out_f[b] = sm.view(np.float32, shm).copy(), sf.view(np.float32, shf).copy()
-                pending[slot] = None
-        nxt = stage_in(0)
-        for b in range(n):
-            s, t, ev_in = nxt
-            main.wait_event(ev_in)
-            if b + 1 < n:
-                nxt = stage_in(b + 1)
-            o = self.forward(s, t)
-            ev_c = torch.cuda.Event()
-            ev_c.record(main)
-            slot = b & 1
-            collect(slot)                            # pair b - 2 used this output slot
-            ym, yf = o["y_source"].detach(), o["preint_flow"].detach()
-            sm = hostio.staging(ym.numel() * 4, ("out2", slot, 0))
-            sf = hostio.staging(yf.numel() * 4, ("out2", slot, 1))
-            with torch.cuda.stream(cs):
-                cs.wait_event(ev_c)
-                for tns, st in ((ym, sm), (yf, sf)):
-                    _lib.check(lib.mmr_copy_to_host(tns.data_ptr(), ctypes.c_void_p(st.ptr), tns.numel() * 4, cs.cuda_stream),
-                               "mmr_copy_to_host")
-                ev_o = torch.cuda.Event()
-                ev_o.record(cs)
-            ym.record_stream(cs)
-            yf.record_stream(cs)
-            pending[slot] = (b, ev_o, sm, sf, tuple(ym.shape), tuple(yf.shape))
-        collect(0)
-        collect(1)
-        return [np.concatenate(out_m), np.concatenate(out_f)]
+                return devs[0], devs[1], ev
+            def copy_out(b, ym, yf, ev_c):
+                with torch.cuda.stream(cs):
+                    cs.wait_event(ev_c)
+                    for tns, arr in ((ym, out_m), (yf, out_f)):
+                        dst = arr.ctypes.data + b * arr[0:1].nbytes
+                        _lib.check(lib.mmr_memcpy_async(ctypes.c_void_p(dst), tns.data_ptr(), tns.numel() * 4, 1, cs.cuda_stream),
+                                   "mmr_memcpy_async")
+                ym.record_stream(cs)
+                yf.record_stream(cs)
+            nxt = stage_in(0)
+            prev = None
+            for b in range(n):
+                s, t, ev_in = nxt
+                main.wait_event(ev_in)
+                o = self.forward(s, t)                   # queued FIRST: whatever the copies below make the host wait for (a copy
+                ev_c = torch.cuda.Event()                # to or from registered -- not hipHostMalloc'd -- memory may return only
+                ev_c.record(main)                        # when it has run), the GPU already has this pair's forward to work on
+                if b + 1 < n:
+                    nxt = stage_in(b + 1)
+                if prev is not None:
+                    copy_out(*prev)                      # pair b - 1's outputs leave while pair b is in the forward
+                prev = (b, o["y_source"].detach(), o["preint_flow"].detach(), ev_c)
+            copy_out(*prev)
+            cs.synchronize()
+            main.synchronize()
+        finally:
+            torch.cuda.synchronize(dev)                   # nothing may still read or write the pages when they are unpinned
+            for r in regs:
+                r.__exit__(None, None, None)
+        return [out_m, out_f]
 
 
 class Transform:

@@ -62,7 +62,7 @@ def test_default_line_carries_both_halves_of_the_metric():
     assert pr["calls"] == 5 and pr["warmup"] == 2 and pr["ms_per_pair"] > 0 and len(pr["runs_ms"]) == 5
     for k in ("h2d_ms", "d2h_ms", "host_convert_ms", "host_pin_ms", "forward_ms_device_resident", "overhead_ms"):
         assert isinstance(pr[k], float), k
-    assert pr["mode_in"] in ("register", "staging") and pr["mode_out"] == "staging"
+    assert pr["mode_in"] in ("register", "staging") and pr["mode_out"] in ("register", "staging")
     ca = d["cascade"]
     assert "error" not in ca, ca
     assert ca["steps"] == 3 and ca["ms_per_pair"] > d["ms_per_step_without_events"] and "cascade" in ca["workload"]
