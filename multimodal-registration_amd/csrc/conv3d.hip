@@ -126,12 +126,6 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 // the gradient lands compact at low resolution (no full-resolution intermediate, no 2x2x2 pooling pass), and the masked
 // epilogue (LeakyReLU backward + bias sums of the layer that produced x) applies unchanged.  fp32x3 / x1 tensors only.
 constexpr int CV_DGFOLD = 1 << 19;
-// CV_UPFOLD with a CLASS LOOP (round 5): a workgroup walks UPL_NCL parity classes of its tile one after the other instead of one
-// workgroup per (tile, class).  A class is only 8 taps x C0 / 64 slices (32 tap steps at C0 = 256 against 108 for a plain 256 -> 256
-// conv), so what a workgroup pays once -- dispatch of the next workgroup onto the CU (one fits), the offset table of the A restage,
-// a cold first A tile -- is a visible share of it; the classes of one tile share the table, and their A tiles hit the XCD's L2.
-constexpr int CV_UPLOOP = 1 << 20;
-constexpr int UPL_NCL = 4;           // classes per workgroup: 2 400 tiles x 2 = 18.75 rounds of 256 CUs at dec_final_0 (8 would be 9.4)
 
 #ifdef MMR_DIAG
 int g_diag_stamps = 0;   // host switch of the stamped instantiations (conv and wgrad), set by mmr_debug_set_stamps
@@ -295,9 +289,8 @@ conv3d_k3_kernel(const ConvParams p)
     const int txi = bid % p.ntx;
     const int b = bid / p.ntx;
     const int x0 = txi * TXT, y0 = tyi * TY, z0 = tzi * TZ;
-    constexpr bool UPLOOP = UPF && (VAR & CV_UPLOOP) != 0;
     const int ntn = UPF ? (p.Cout + BN - 1) / BN : 1;
-    int cls = UPF ? ((int)blockIdx.y / ntn) * (UPLOOP ? UPL_NCL : 1) : 0;   // parity class (px, py, pz) = bits 2, 1, 0
+    const int cls = UPF ? (int)blockIdx.y / ntn : 0;                 // parity class (px, py, pz) = bits 2, 1, 0
     const int ntile = UPF ? (int)blockIdx.y % ntn : (int)blockIdx.y;
 
     const int pv = row_perm(lane & 31);
@@ -391,7 +384,7 @@ conv3d_k3_kernel(const ConvParams p)
     const int ncs = (p.C0 + p.C1) / KC;              // channel slices of the input
     const int nslices = DGF ? 8 * ncs : ncs;         // dgrad fold: (parity class, dz-channel slice) pairs
     const int G = nslices * TAPS;
-    const char* wtile = p.wp + (size_t)(UPF ? cls * ntn + ntile : (int)blockIdx.y) * G * B_BYTES;   // UPF: [class][n-tile], else [n-tile]
+    const char* wtile = p.wp + (size_t)blockIdx.y * G * B_BYTES;   // UPF: [class][n-tile], else [n-tile]
     const int X2 = p.X >> 1, Y2 = p.Y >> 1, Z2 = p.Z >> 1;
 
     // global load of item `it` of this thread's share of the haloed tile of channel slice s.
@@ -629,24 +622,6 @@ conv3d_k3_kernel(const ConvParams p)
     const int g0 = p.kpart ? (int)blockIdx.z * p.gsplit : 0;
     const int g1 = p.kpart ? min(g0 + p.gsplit, G) : G;
     int cur = 0, tap = g0 % TAPS, s = g0 / TAPS;
-    // CV_UPLOOP: classes cls .. cls + UPL_NCL - 1 of this tile, one after the other (ucl counts them); everything below up to the
-    // folded epilogue runs once per class, the first class with the prologue above
-    for (int ucl = 0; ucl < (UPLOOP ? UPL_NCL : 1); ++ucl) {
-    if constexpr (UPLOOP) {
-        if (ucl > 0) {
-            ++cls;
-            wtile = p.wp + (size_t)(cls * ntn + ntile) * G * B_BYTES;
-            cur = 0; tap = 0; s = 0;
-#pragma unroll
-            for (int mi = 0; mi < (M16 ? 2 * MT : 1); ++mi)
-#pragma unroll
-                for (int ni = 0; ni < (M16 ? 2 * NT : 1); ++ni) acc16[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (ATAB) {
-                issue_b(0, 0);
-                if (atab_ok) dma_stage_a(0);
-            }
-        }
-    }
     if constexpr (!ATAB) issue_b(g0, 0);
     // a macro, not a lambda: wrapped in one more closure, hipcc no longer scalarises the by-value kernel argument
     // struct and every instantiation reads ConvParams from scratch (288 B/lane; the bn64 convs ran 1.8x slower)
@@ -690,7 +665,7 @@ conv3d_k3_kernel(const ConvParams p)
         } \
     } while (0)
     if constexpr (DMA_A) {
-        if (!(ATAB && atab_ok)) dma_stage_a(s);   // table kernels: already issued while the table was written (class loop: above)
+        if (!(ATAB && atab_ok)) dma_stage_a(s);   // table kernels: already issued while the table was written
     } else {
         MMR_STAGE_A_REGS(s);
     }
@@ -1020,11 +995,7 @@ conv3d_k3_kernel(const ConvParams p)
                     }
                 }
             }
-            if constexpr (UPLOOP) {
-                continue;      // next class of this tile (every wave is past the last tap's barrier: sA / sB are free)
-            } else {
-                return;
-            }
+            return;
         }
         const int cs = p.csplit;
         const bool second = cs > 0 && co >= cs;
@@ -1214,7 +1185,6 @@ conv3d_k3_kernel(const ConvParams p)
             p.part[(size_t)(ntile * BN + tid) * gridDim.x + blockIdx.x] = t;
         }
     }
-    }   // for ucl (CV_UPLOOP; one pass otherwise)
 }
 
 // one wave per channel over part[channel][tile] (the conv epilogues store their column sums transposed, so that a channel's
@@ -1596,8 +1566,7 @@ int launch_conv(const ConvParams& p, int ntiles_n, hipStream_t st, int64_t* nblk
         return check_launch();
     }
     q.kpart = nullptr;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, ((VAR & CV_UPFOLD) != 0 ? ((VAR & CV_UPLOOP) != 0 ? 8 / UPL_NCL : 8) : 1) * ntiles_n),
-                       dim3(CONV_THREADS), LDS, st, q);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, ((VAR & CV_UPFOLD) != 0 ? 8 : 1) * ntiles_n), dim3(CONV_THREADS), LDS, st, q);
     return check_launch();
 }
 
@@ -1650,12 +1619,7 @@ int dispatch_conv_fold(const ConvParams& p, hipStream_t st, int64_t* nblk_out = 
     static_assert(!((EXTRA & CV_PART16) != 0 && F32T), "half partial: bf16 layers only");
     constexpr int V_FULL = CV_M16 | CV_PIPE | CV_DMA_A;
     switch (BN) {
-        case 256:
-#ifdef MMR_UPLOOP
-            if constexpr (DT == MMR_DT_BF16 && (EXTRA & CV_UPFOLD) != 0)
-                return launch_conv<DT, 2, 4, 4, 2, V_FULL | EXTRA | CV_UPLOOP>(p, nt, st, nblk_out);
-#endif
-            return launch_conv<DT, 2, 4, 4, 2, V_FULL | (F32T ? CV_BATCHA : 0) | EXTRA>(p, nt, st, nblk_out);
+        case 256: return launch_conv<DT, 2, 4, 4, 2, V_FULL | (F32T ? CV_BATCHA : 0) | EXTRA>(p, nt, st, nblk_out);
         case 128:
             if constexpr (DT == MMR_DT_BF16) return launch_conv<DT, 4, 2, 4, 2, CV_M16 | EXTRA>(p, nt, st, nblk_out);
             else return launch_conv<DT, 4, 2, 4, 2, V_FULL | CV_BATCHA | EXTRA>(p, nt, st, nblk_out);
@@ -2239,11 +2203,7 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
     // 2-way conflicts on every read (SQ_LDS_BANK_CONFLICT 29 % of the LDS cycles, profiles/r04k_infer_pmc_sq.json).  Now a
     // 32-lane group is ONE channel of TWO y rows x 14 z (28 lanes, 4 idle): its rows are hz .. hz + 13 and hz + 16 .. hz + 29,
     // distinct mod 32, times the odd pitch 81 -> 28 distinct banks.  21 such (channel, row pair) items over the 16 groups.
-#ifdef MMR_FH_NOCF
-    constexpr bool CF = false;
-#else
     constexpr bool CF = HY == 16;
-#endif
     const int cf_l = tid & 31, cf_g = tid >> 5;
     const int cf_i1 = cf_g + 16;                                     // second item of groups 0 .. 4
     const int co = CF ? cf_g % 3 : tid % 3, ov = tid / 3;
@@ -2294,16 +2254,7 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
         // (bf16 only: the narrow fp32x3 inputs run two workgroups per CU, which already doubles the bytes in flight; two planes
         // ahead cost them 5 %)
         constexpr bool DEEP = !X3 && HY == MH_HY;   // HY = 16: eight waves already hold twice the bytes in flight; a second buffer spills (52 B)
-        // HY = 16 (round 5): two prefetch buffers consumed IN PLACE -- no masked copy (`allraw`) of the plane being multiplied, the
-        // mask is applied where a fragment is used, and the buffer is reloaded with plane xp + 2 as soon as its last MFMA has been
-        // issued: a plane is in flight for the gather of one step and the whole next one (~1.5 steps instead of 1) at the register
-        // cost of the copy it replaces.
-#ifdef MMR_FH_NOINPLACE
-        constexpr bool INPLACE = false;
-#else
-        constexpr bool INPLACE = !X3 && NS > 0 && HY == 16;
-#endif
-        constexpr int AHEAD = (DEEP || INPLACE) ? 2 : 1;
+        constexpr int AHEAD = DEEP ? 2 : 1;
         typedef u32x4_t PreBuf[NL][2];
         PreBuf preA, preB;
         auto load_plane = [&](PreBuf& pre, int xq) {
@@ -2318,7 +2269,7 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
         };
         if constexpr (NS > 0) {
             load_plane(preA, xs - 1);
-            if constexpr (DEEP || INPLACE) load_plane(preB, xs);
+            if constexpr (DEEP) load_plane(preB, xs);
         }
         auto plane_step = [&](int xp, PreBuf& pre) {
             const int buf = (pbufs == 2) ? ((xp - xs + 1) & 1) : 0;
@@ -2346,9 +2297,8 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
                         }
                     }
                 };
-                u32x4_t allraw[INPLACE ? 1 : NL][2];
-                if constexpr (INPLACE) {
-                } else if constexpr (NS > 0) {
+                u32x4_t allraw[NL][2];
+                if constexpr (NS > 0) {
 #pragma unroll
                     for (int s2 = 0; s2 < NL; ++s2)
 #pragma unroll
@@ -2362,10 +2312,7 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
                     uint4 ah[2], al[2];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        if constexpr (INPLACE) {
-                            const u32x4_t m = pre[s][j] & rowmask[j];
-                            ah[j] = make_uint4(m.x, m.y, m.z, m.w);
-                        } else if constexpr (NS > 0 && !X3) {
+                        if constexpr (NS > 0 && !X3) {
                             ah[j] = make_uint4(allraw[s][j].x, allraw[s][j].y, allraw[s][j].z, allraw[s][j].w);
                         } else if constexpr (X3) {
                             if constexpr (NS > 0) {
@@ -2415,7 +2362,6 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
                         }
                     }
                 }
-                if constexpr (INPLACE) load_plane(pre, xp + AHEAD);   // every fragment of this buffer has been handed to its MFMA
                 // C/D layout of the 16x16 tile: lane holds rows q16*4 + r (= halo z), column r16
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -2467,7 +2413,7 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
             }
             if (pbufs == 1) __syncthreads();  // single P buffer (wide fp32x3 inputs): gather done before the next plane lands
         };
-        if constexpr (DEEP || INPLACE) {
+        if constexpr (DEEP) {
             for (int xp = xs - 1; xp <= xe; xp += 2) {
                 plane_step(xp, preA);
                 if (xp + 1 <= xe) plane_step(xp + 1, preB);

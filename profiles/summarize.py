@@ -4,7 +4,8 @@
   python profiles/summarize.py stats  <kernel_stats.csv>              -> top kernels table (stdout)
   python profiles/summarize.py pmc    <fetch_counter.csv> <write_counter.csv> <out.json> [kernel-substring]
   python profiles/summarize.py sq     <counter_collection.csv> <out.json> [kernel-substring]
-  python profiles/summarize.py round  <tag>     (everything tools/profile_round.sh wrote under gpurun_out/<tag>_* -> profiles/)
+  python profiles/summarize.py round  <tag> [git sha of the profiled tree]   (everything tools/profile_round.sh wrote under
+                                                                               gpurun_out/<tag>_* -> profiles/)
 
 PMC units and corrections (MI355X_MICROARCH.md section HBM): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950
 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced (16 B/lane) streaming read -> doubled here;
@@ -99,7 +100,28 @@ def sq(counter_csv, out_json, sub=None):
         print(k[-70:], {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items() if a != "counters_per_launch"})
 
 
-def round_(tag):
+def calib(counter_csv, out_json):
+    """tools/ubench/fetch_calib: FETCH_SIZE (KiB, raw) of kernels whose traffic is known -> raw bytes / known bytes per kernel.
+    0.5 for stream_b128 means the gfx950 'x 2' correction applies to raw_buffer_load_b128 (the NCC kernel's instruction)."""
+    known = {"stream_b128": 256 << 20, "stream_dword": 256 << 20, "reread_b128": 256 << 20}
+    acc = defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(counter_csv)):
+        if r["Counter_Name"] == "FETCH_SIZE":
+            a = acc[r["Kernel_Name"].split("(")[0]]
+            a[0] += float(r["Counter_Value"])
+            a[1] += 1
+    out = {}
+    for k, (v, n) in acc.items():
+        for name, b in known.items():
+            if name in k:
+                out[name] = {"launches": n, "fetch_KiB_raw_per_launch": v / n, "requested_bytes": b,
+                             "raw_over_requested": v / n * 1024 / b,
+                             "unique_bytes": (32 << 20) if name == "reread_b128" else b}
+    json.dump(out, open(out_json, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+def round_(tag, head=None):
     import glob
     import os
     import shutil
@@ -107,7 +129,11 @@ def round_(tag):
     here = os.path.dirname(os.path.abspath(__file__))
     root = os.path.dirname(here)
     g = lambda pat: sorted(glob.glob(os.path.join(root, "gpurun_out", pat)))
-    head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=root, capture_output=True, text=True).stdout.strip()
+    # the commit that was PROFILED (the GPU box has no .git: pass it; default = HEAD now, right only if nothing was committed since)
+    head = head or subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=root, capture_output=True, text=True).stdout.strip()
+    cal = g(f"{tag}_pmc_calib/*/*counter_collection.csv")
+    if cal:
+        calib(cal[0], os.path.join(here, f"{tag}_fetch_calibration.json"))
     for wl in ("infer", "train", "ncc"):
         st = g(f"{tag}_stats_{wl}/*/*kernel_stats.csv")
         if st:
@@ -160,6 +186,6 @@ if __name__ == "__main__":
     elif sys.argv[1] == "sq":
         sq(*sys.argv[2:])
     elif sys.argv[1] == "round":
-        round_(sys.argv[2])
+        round_(*sys.argv[2:4])
     else:
         pmc(*sys.argv[2:])

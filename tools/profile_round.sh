@@ -36,4 +36,9 @@ done
 # 4. the NCC / bending kernels are VALU / LDS machines, not matrix-core ones: instruction counts and VALU-active cycles
 step "pmc SQ: ncc"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/${tag}_pmc_ncc_SQ -- python3 bench.py --workload ncc --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/${tag}_pmc_ncc_SQ.err || exit 1
+# 5. does the x2 FETCH_SIZE correction apply to the NCC kernel's loads (raw_buffer_load_b128)?  kernels of KNOWN traffic
+if [ -x tools/ubench/fetch_calib ]; then
+  step "pmc FETCH_SIZE: calibration kernels"
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/${tag}_pmc_calib -- ./tools/ubench/fetch_calib > $out/${tag}_fetch_calib.txt 2> $out/${tag}_fetch_calib.err || exit 1
+fi
 step done
