@@ -690,7 +690,8 @@ def main():
             outs.append(dict(hostio.LAST.get("out", {})))
         assert moved.dtype == np.float32 and field.dtype == np.float32 and np.isfinite(moved).all()
         mean = lambda rows, k: round(float(np.mean([r.get(k, 0.0) for r in rows])), 3)
-        # the two directions alone (same code, nothing else queued): H2D = pin + cast kernel over PCIe, D2H = copy kernel + NumPy copy
+        # the two directions alone (same code, nothing else queued): H2D = pin + cast kernel over PCIe, D2H = copy kernel into the
+        # pinned result arrays
         h2d, d2h = [], []
         y, f = model.forward(mov, fix)["y_source"], model.references.preint_flow
         torch.cuda.synchronize()
@@ -701,10 +702,15 @@ def main():
             t0 = time.perf_counter()
             hostio.many_to_host([y, f])
             d2h.append((time.perf_counter() - t0) * 1e3)
-        return {"ms_per_pair": round(float(np.mean(ts)), 3), "ms_per_pair_median": round(float(np.median(ts)), 3),
-                "calls": calls, "warmup": warm, "runs_ms": [round(t, 2) for t in ts],
+        med = float(np.median(ts))
+        # per call: total = host -> device + (enqueue of the forward + wait for it + device -> host); a call far above the median
+        # is a host stall (first touch of the fresh result arrays, allocator), visible in which part grew
+        per_call = [{"ms": round(t, 2), "in_ms": round(i.get("total_ms", 0.0), 2), "forward_and_out_ms": round(t - i.get("total_ms", 0.0), 2),
+                     "out_wait_ms": round(o.get("wait_ms", 0.0), 2)} for t, i, o in zip(ts, ins, outs)]
+        return {"ms_per_pair": round(med, 3), "ms_per_pair_is": f"median of {calls} calls after {warm} warm-ups", "ms_per_pair_mean": round(float(np.mean(ts)), 3),
+                "ms_per_pair_max": round(max(ts), 3), "calls": calls, "warmup": warm, "runs_ms": [round(t, 2) for t in ts], "per_call": per_call,
                 "input": "two float64 NumPy volumes [1,160,160,192,1] (39.3 MB each)", "output": "fp32 NumPy moved volume + half-res field",
-                "forward_ms_device_resident": round(fwd_ms, 3), "overhead_ms": round(float(np.mean(ts)) - fwd_ms, 3),
+                "forward_ms_device_resident": round(fwd_ms, 3), "overhead_ms": round(med - fwd_ms, 3),
                 "h2d_ms": round(float(np.median(h2d)), 3), "d2h_ms": round(float(np.median(d2h)), 3),
                 "host_convert_ms": mean(ins, "host_copy_ms"),      # 0 when the caller's pages are pinned in place: the cast runs on the GPU
                 "host_pin_ms": mean(ins, "pin_ms"), "h2d_kernel_ms": mean(ins, "transfer_ms"),
