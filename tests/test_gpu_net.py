@@ -259,3 +259,55 @@ def test_input_model_wires_the_generator_pair(dev):
     assert tr.gen_1 is g1 and tr.gen_2 is g2 and np.isfinite(float(tr.train_step(lab, lab)["loss"]))
     with pytest.raises(TypeError):
         mmr.networks.VxmDense(shape, nb_unet_features=feats, input_model=object())
+
+
+def test_predict_host_handover_every_input_kind_and_fallback(dev):
+    """mmr.hostio (3d_reg.py:310-314's hand-over): the caller's pages pinned in place and cast on the GPU must give what Keras'
+    host-side cast gives, for every dtype / layout a caller can hold -- float64, float32, uint8, int16, another dtype (int32 ->
+    float64 on the host), Fortran-ordered and strided views, an unaligned buffer -- through each strategy ('register', the
+    'staging' fallback the runtime's refusal leads to, 'torch'), and the outputs of each output strategy are the device values bit
+    for bit.  predict() itself is then identical whichever strategy carried the volumes."""
+    import mmr
+    from mmr import hostio
+    rng = np.random.default_rng(3)
+    shape = (1, 16, 32, 16, 1)
+    base = rng.random(shape) * 200.0
+    raw = np.frombuffer(bytearray(base.nbytes + 8), dtype=np.uint8)[8:8 + base.nbytes].view(np.float64).reshape(shape)   # 8-B aligned only
+    raw[...] = base
+    cases = {"float64": base, "float32": base.astype(np.float32), "uint8": base.astype(np.uint8), "int16": (base * 50).astype(np.int16),
+             "int32": (base * 1000).astype(np.int32), "fortran": np.asfortranarray(base), "strided": np.repeat(base, 2, axis=3)[:, :, :, ::2],
+             "unaligned": raw, "readonly": base.copy()}
+    cases["readonly"].setflags(write=False)
+    for name, a in cases.items():
+        want = torch.from_numpy(np.ascontiguousarray(a).astype(np.float64)).float()
+        for mode in ("register", "staging", "torch"):
+            got = hostio.to_device_f32(a, dev, mode=mode).cpu()
+            assert got.shape == want.shape and torch.equal(got, want), (name, mode)
+        pair = hostio.pair_to_device([a, a], dev)
+        assert torch.equal(pair[0].cpu(), want) and torch.equal(pair[1].cpu(), want), name
+    t = torch.randn((1, 16, 32, 16, 3), device=dev)
+    for mode in ("register", "staging", "torch"):
+        assert np.array_equal(hostio.to_host(t, mode=mode), t.cpu().numpy()), mode
+        outs = hostio.many_to_host([t, t[..., :1].contiguous()], mode=mode)
+        assert np.array_equal(outs[0], t.cpu().numpy()) and np.array_equal(outs[1], t[..., :1].cpu().numpy()), mode
+    m = mmr.networks.VxmDense((16, 32, 16), nb_unet_features=([32, 32], [32, 32, 32]), int_steps=5, int_resolution=2, svf_resolution=2,
+                              compute_dtype="fp32x3", seed=2)
+    w = m.get_weights()
+    w[-2] = (np.random.default_rng(1).standard_normal(w[-2].shape) * 3e-2).astype(np.float32)
+    m.set_weights(w)
+    mov, fix = rng.random(shape), rng.random(shape)
+    keep = (hostio.MODE_IN, hostio.MODE_OUT)
+    res = {}
+    try:
+        for mi, mo in (("register", "register"), ("staging", "staging"), ("torch", "torch")):
+            hostio.MODE_IN, hostio.MODE_OUT = mi, mo
+            res[mi] = m.predict([mov, fix])
+    finally:
+        hostio.MODE_IN, hostio.MODE_OUT = keep
+    for k in ("staging", "torch"):
+        assert np.array_equal(res[k][0], res["register"][0]) and np.array_equal(res[k][1], res["register"][1]), k
+    # a registration the runtime refuses (the same pages pinned twice) falls back to the staging copy, silently and correctly
+    with hostio.Registered(mov) as r:
+        assert r.ok
+        again = m.predict([mov, fix])
+    assert np.array_equal(again[0], res["register"][0])
