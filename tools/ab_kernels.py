@@ -67,14 +67,15 @@ if "upfold" in which:
     # launch A of dec_final_0 at C2: the upsampled half of concat([up2(256 ch @ 80x80x96), skip]) -> 256 on the low-resolution grid,
     # 8 parity classes x 8 taps, IEEE-half partial at 160x160x192 (mmr_conv3d_k3_upfold_fwd)
     for (S2, C0, Cout, dt, half, tag) in (((80, 80, 96), 256, 256, 1, 1, "bf16 256 -> 256, partial at 160x160x192 (C2 dec_final_0)"),
-                                          ((40, 40, 48), 256, 256, 1, 1, "bf16 256 -> 256, partial at 80x80x96 (C2 dec_conv_3)")):
-        xl = (torch.randn((1,) + S2 + (C0,), generator=g) * 0.5).to(torch.bfloat16).to(dev)
+                                          ((40, 40, 48), 256, 256, 1, 1, "bf16 256 -> 256, partial at 80x80x96 (C2 dec_conv_3)"),
+                                          ((80, 80, 80), 64, 64, 2, 0, "fp32x3 64 -> 64, partial at 160^3 (C3 dec_final_0)")):
+        xl = (torch.randn((1,) + S2 + (C0,), generator=g) * 0.5).to(torch.bfloat16 if dt == 1 else torch.float32).to(dev)
         wk = (torch.randn((27, C0, Cout), generator=g) * 0.02).to(dev)
         nb = int(new.mmr_conv3d_k3_upfold_packed_bytes(C0, Cout, dt))
         wp = torch.empty(nb, dtype=torch.uint8, device=dev)
         assert new.mmr_conv3d_k3_upfold_pack(wk.data_ptr(), wp.data_ptr(), C0, Cout, dt, st()) == 0
         full = tuple(2 * v for v in S2)
-        p1 = torch.empty((1,) + full + (Cout,), dtype=torch.float16, device=dev)
+        p1 = torch.empty((1,) + full + (Cout,), dtype=torch.float16 if half else torch.float32, device=dev)
         p2 = torch.empty_like(p1)
         call = lambda lib, o: lib.mmr_conv3d_k3_upfold_fwd(xl.data_ptr(), C0, wp.data_ptr(), o.data_ptr(), half, 1, *S2, Cout, dt, st())
 
@@ -84,6 +85,8 @@ if "upfold" in which:
         for vn, vl in VARIANTS.items():
             if "uploop" in vn:
                 ab(f"  ... variant {vn}", lambda: call(old, p1), lambda: call(vl, p2), check=chk, n=10)
+            if "skip" in vn:    # timing-only builds (wrong results): bounds on what fewer A restages could buy
+                ab(f"  ... TIMING-ONLY {vn}", lambda: call(old, p1), lambda: call(vl, p2), check=None, n=10)
         del xl, p1, p2
 if "flow" in which:
     S, C = (160, 160, 192), 256
