@@ -873,13 +873,7 @@ conv3d_k3_kernel(const ConvParams p)
         if (tap == TAPS) {
             tap = 0;
             ++s;
-#if defined(MMR_TIMING_SKIP_RESTAGE)
-            // TIMING-ONLY experiment (wrong results, never the shipped build): bound on what halving / removing the folded
-            // launch's A restages could buy -- 1: every other restage skipped, 2: all skipped
-            if (s < nslices && more && !(UPF && (MMR_TIMING_SKIP_RESTAGE == 2 || (s & 1)))) {
-#else
             if (s < nslices && more) {  // every wave is past its last read of sA: install the next slice
-#endif
                 if constexpr (DMA_A) {
                     dma_stage_a(s);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
