@@ -211,6 +211,8 @@ def pair_to_device(arrays, device, mode=None):
         torch.cuda.current_stream().synchronize()
         t2 = time.perf_counter()
     finally:
+        if regs:
+            torch.cuda.current_stream().synchronize()   # also on an error path: no kernel may still read pages that are being unpinned
         for r in regs:
             r.__exit__(None, None, None)
     t3 = time.perf_counter()
