@@ -1145,64 +1145,174 @@ ncc_xgrad_kernel(const float* __restrict__ zy, const float* __restrict__ I, cons
 }
 
 // ------------------------------ bending backward ------------------------ //
-// E = 1/M sum_{c interior,k} dxx^2 + dyy^2 + dzz^2 + 2 (dxy^2 + dxz^2 + dyz^2); gather form of dE/du[w,k]: every
-// second difference that touches w, recomputed from u (all reads hit L1/L2; this is not on the training path of
-// the reference, which uses Dice + Grad-l2).
-struct BendCtx { const float* u; int X, Y, Z, k; };
-__device__ __forceinline__ bool bend_interior(const BendCtx& c, int x, int y, int z)
-{
-    return x >= 1 && x < c.X - 1 && y >= 1 && y < c.Y - 1 && z >= 1 && z < c.Z - 1;
-}
-__device__ __forceinline__ float bend_at(const BendCtx& c, int x, int y, int z)
-{
-    return c.u[(((size_t)x * c.Y + y) * c.Z + z) * 3 + c.k];
-}
-// pure second difference along axis a (0,1,2) at centre (x,y,z), 0 outside the interior
-__device__ __forceinline__ float bend_daa(const BendCtx& c, int x, int y, int z, int a)
-{
-    if (!bend_interior(c, x, y, z)) return 0.f;
-    const int ex = a == 0, ey = a == 1, ez = a == 2;
-    return bend_at(c, x + ex, y + ey, z + ez) - 2.f * bend_at(c, x, y, z) + bend_at(c, x - ex, y - ey, z - ez);
-}
-// mixed difference for the axis pair (a,b), including its 1/4
-__device__ __forceinline__ float bend_dab(const BendCtx& c, int x, int y, int z, int a, int b)
-{
-    if (!bend_interior(c, x, y, z)) return 0.f;
-    const int ax = a == 0, ay = a == 1, az = a == 2, bx = b == 0, by = b == 1, bz = b == 2;
-    return 0.25f * (bend_at(c, x + ax + bx, y + ay + by, z + az + bz) - bend_at(c, x + ax - bx, y + ay - by, z + az - bz) -
-                    bend_at(c, x - ax + bx, y - ay + by, z - az + bz) + bend_at(c, x - ax - bx, y - ay - by, z - az - bz));
-}
+// E = 1/M sum_{c interior,k} dxx^2 + dyy^2 + dzz^2 + 2 (dxy^2 + dxz^2 + dyz^2).  Until round 4 a gather kernel recomputed every
+// second difference that touches an output from global memory:
+// ~75 loads and ~1 000 lane-instructions per output element, 1.38 ms at 256^3 = 0.04 of the HBM roofline for a 403-MB
+// read-and-write.  Tiled form (round 5): a workgroup owns a 4 x 8 x 32 tile and puts the field with a halo of 2 into LDS once
+// ([k][x][y][z] planes, 41 KB: three workgroups per CU); every thread owns the x column of four outputs at its (y, z).
+//   dE/du = 1/M [ 2 sum_pure D^T Q + 4 sum_mixed D^T Q ],  Q = D u where the centre is an interior voxel of the volume, else 0
+// (the energy sums interior centres only); D^T has D's stencil (pure: symmetric; mixed, with its 1/4: symmetric under
+// (a, b) -> (-a, -b)).  Two paths, chosen per tile (uniform):
+//   * tiles at least two voxels from every face: every Q they touch is unmasked and D^T D collapses to ONE 25-point stencil on u
+//       g = 39 u(0) - 8 sum_{+-1 on an axis} u + sum_{+-2 on an axis} u + 1/4 sum_{(+-2, +-2) in a coordinate plane} u
+//     (2 (1, -4, 6, -4, 1) per axis; 4 / 16 (corners - 2 edge midpoints + 4 centre) per axis pair);
+//   * the others: the 21 masked second differences that touch an output, each recomputed from the LDS tile.
+constexpr int BB_TX = 4, BB_TY = 8, BB_TZ = 32;
+constexpr int BB_UX = BB_TX + 4, BB_UY = BB_TY + 4, BB_UZ = BB_TZ + 4;      // 8 x 12 x 36
+constexpr int BB_UN = BB_UX * BB_UY * BB_UZ;                                 // 3 456
+constexpr int BB_LDS = 3 * BB_UN * (int)sizeof(float);                       // 41 472 B
 
-__global__ void __launch_bounds__(256)
-bending_bwd_kernel(const float* __restrict__ u, const float* __restrict__ gout, float* __restrict__ du, int B, int X, int Y,
-                   int Z, int accumulate)
+__global__ void __launch_bounds__(256, 3)
+bending_bwd_tiled_kernel(const float* __restrict__ u, const float* __restrict__ gout, float* __restrict__ du, int X, int Y, int Z,
+                         int ntx, int nty, int ntz, int accumulate)
 {
-    const int64_t nvox = (int64_t)X * Y * Z;
-    const int64_t total = (int64_t)B * nvox * 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* su = reinterpret_cast<float*>(smem);          // [3][BB_UN]
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int tzi = t % ntz; t /= ntz;
+    const int tyi = t % nty; t /= nty;
+    const int txi = t % ntx;
+    const int b = t / ntx;
+    const int x0 = txi * BB_TX, y0 = tyi * BB_TY, z0 = tzi * BB_TZ;
+    const size_t nvox = (size_t)X * Y * Z;
+    const float* ub = u + (size_t)b * nvox * 3;
+    struct F3 { float v[3]; };
+    // field + halo 2: one 12-B load per voxel from a clamped, always valid address, zeroed outside the volume afterwards (never
+    // read by a Q whose centre is interior).  A thread keeps ONE z of the 36 and walks the 96 (x, y) rows seven at a time (252 of
+    // the 256 threads): the z part of the address and the bounds test is computed once, a row costs a handful of integer
+    // instructions (decomposing a linear index per item cost ~80 and was as much VALU work as the stencils), and all 14 loads
+    // of a thread are issued before the first is used (as a loop they ran as dependent round trips, ~14 us per tile).
+    constexpr int NROW = BB_UX * BB_UY, RPP = 256 / BB_UZ, NLD = (NROW + RPP - 1) / RPP;     // 96 rows, 7 per pass, 14 passes
+    const int zq = tid % BB_UZ, r0 = tid / BB_UZ;
+    const int gzl = z0 + zq - 2;
+    const bool zin = gzl >= 0 && gzl < Z && r0 < RPP;
+    const int czl = min(max(gzl, 0), Z - 1);
+    F3 ld[NLD];
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        const int r = min(it * RPP + r0, NROW - 1);
+        const int hx = r / BB_UY, hy = r - hx * BB_UY;
+        const int cx = min(max(x0 + hx - 2, 0), X - 1), cy = min(max(y0 + hy - 2, 0), Y - 1);
+        ld[it] = *reinterpret_cast<const F3*>(ub + (((size_t)cx * Y + cy) * Z + czl) * 3);
+    }
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        const int r = it * RPP + r0;
+        if (r0 < RPP && r < NROW) {
+            const int hx = r / BB_UY, hy = r - hx * BB_UY;
+            const int gx = x0 + hx - 2, gy = y0 + hy - 2;
+            const bool in = zin && gx >= 0 && gx < X && gy >= 0 && gy < Y;
+            const int i = r * BB_UZ + zq;
+            su[i] = in ? ld[it].v[0] : 0.f;
+            su[BB_UN + i] = in ? ld[it].v[1] : 0.f;
+            su[2 * BB_UN + i] = in ? ld[it].v[2] : 0.f;
+        }
+    }
+    const int ty = tid >> 5, tz = tid & 31;
+    constexpr int SX = BB_UY * BB_UZ, SY = BB_UZ;          // strides of su in floats (z stride 1)
+    float acc[BB_TX][3];
+    __syncthreads();
+    const bool deep = x0 >= 2 && x0 + BB_TX <= X - 2 && y0 >= 2 && y0 + BB_TY <= Y - 2 && z0 >= 2 && z0 + BB_TZ <= Z - 2;
+    if (deep) {
+        // x columns of the tile + halo at the 13 (y, z) offsets the stencil touches, read ONCE per channel for the thread's four
+        // outputs (72 LDS reads issued together, then arithmetic; written per output hipcc interleaved 131 reads with 69 waits)
+#pragma unroll 1
+        for (int k = 0; k < 3; ++k) {
+            const float* s = su + k * BB_UN + (ty + 2) * BB_UZ + (tz + 2);      // (hx = 0, y, z); output xi sits at hx = xi + 2
+            float c0[8], yp2[8], ym2[8], zp2[8], zm2[8], yp1[4], ym1[4], zp1[4], zm1[4], pp[4], pm[4], mp[4], mm[4];
+#pragma unroll
+            for (int hx = 0; hx < 8; ++hx) {
+                c0[hx] = s[hx * SX];
+                yp2[hx] = s[hx * SX + 2 * SY]; ym2[hx] = s[hx * SX - 2 * SY];
+                zp2[hx] = s[hx * SX + 2]; zm2[hx] = s[hx * SX - 2];
+            }
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) {
+                const int o = (xi + 2) * SX;
+                yp1[xi] = s[o + SY]; ym1[xi] = s[o - SY]; zp1[xi] = s[o + 1]; zm1[xi] = s[o - 1];
+                pp[xi] = s[o + 2 * SY + 2]; pm[xi] = s[o + 2 * SY - 2]; mp[xi] = s[o - 2 * SY + 2]; mm[xi] = s[o - 2 * SY - 2];
+            }
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) {
+                const int h = xi + 2;
+                const float ax1 = (c0[h + 1] + c0[h - 1]) + (yp1[xi] + ym1[xi]) + (zp1[xi] + zm1[xi]);
+                const float ax2 = (c0[h + 2] + c0[h - 2]) + (yp2[h] + ym2[h]) + (zp2[h] + zm2[h]);
+                const float cxy = (yp2[h + 2] + ym2[h + 2]) + (yp2[h - 2] + ym2[h - 2]);
+                const float cxz = (zp2[h + 2] + zm2[h + 2]) + (zp2[h - 2] + zm2[h - 2]);
+                const float cyz = (pp[xi] + pm[xi]) + (mp[xi] + mm[xi]);
+                const float g = 39.f * c0[h] - 8.f * ax1 + ax2 + 0.25f * ((cxy + cxz) + cyz);
+#pragma unroll
+                for (int k2 = 0; k2 < 3; ++k2)
+                    if (k2 == k) acc[xi][k2] = g;
+            }
+        }
+    } else {
+        // interior flags of the centres at offsets -1, 0, +1 from an output, per axis (bit o + 1)
+        const int gy = y0 + ty, gz = z0 + tz;
+        unsigned my = 0, mz = 0;
+#pragma unroll
+        for (int o = -1; o <= 1; ++o) {
+            my |= (gy + o >= 1 && gy + o < Y - 1) ? 1u << (o + 1) : 0u;
+            mz |= (gz + o >= 1 && gz + o < Z - 1) ? 1u << (o + 1) : 0u;
+        }
+#pragma unroll 1
+        for (int xi = 0; xi < BB_TX; ++xi) {   // (not unrolled: 21 stencils x 3 channels x 4 outputs in flight spill)
+            const int gx = x0 + xi;
+            unsigned mx = 0;
+#pragma unroll
+            for (int o = -1; o <= 1; ++o) mx |= (gx + o >= 1 && gx + o < X - 1) ? 1u << (o + 1) : 0u;
+            // 1.0 where the centre at offset (ox, oy, oz) is an interior voxel, else 0.0 -- a FACTOR, not a branch: behind
+            // `m ? stencil : 0` hipcc put each of the 21 stencils into its own exec-masked block with its own LDS wait, 252
+            // dependent round trips per tile (boundary tiles ran 8x longer than interior ones)
+            auto inside = [&](int ox, int oy, int oz) {
+                return ((mx >> (ox + 1)) & (my >> (oy + 1)) & (mz >> (oz + 1)) & 1u) ? 1.f : 0.f;
+            };
+#pragma unroll 1
+            for (int k = 0; k < 3; ++k) {
+                const float* s = su + k * BB_UN + ((xi + 2) * BB_UY + (ty + 2)) * BB_UZ + (tz + 2);
+                // masked pure second difference along stride a at centre offset c (in floats), factor m
+                auto daa = [&](int c, int a, float m) { return m * (s[c + a] - 2.f * s[c] + s[c - a]); };
+                auto dab = [&](int c, int a, int bq, float m) {
+                    return (0.25f * m) * (s[c + a + bq] - s[c + a - bq] - s[c - a + bq] + s[c - a - bq]);
+                };
+                float g = 0.f;
+                g += 2.f * (daa(-SX, SX, inside(-1, 0, 0)) - 2.f * daa(0, SX, inside(0, 0, 0)) + daa(SX, SX, inside(1, 0, 0)));
+                g += 2.f * (daa(-SY, SY, inside(0, -1, 0)) - 2.f * daa(0, SY, inside(0, 0, 0)) + daa(SY, SY, inside(0, 1, 0)));
+                g += 2.f * (daa(-1, 1, inside(0, 0, -1)) - 2.f * daa(0, 1, inside(0, 0, 0)) + daa(1, 1, inside(0, 0, 1)));
+                g += dab(-SX - SY, SX, SY, inside(-1, -1, 0)) - dab(-SX + SY, SX, SY, inside(-1, 1, 0)) -
+                     dab(SX - SY, SX, SY, inside(1, -1, 0)) + dab(SX + SY, SX, SY, inside(1, 1, 0));
+                g += dab(-SX - 1, SX, 1, inside(-1, 0, -1)) - dab(-SX + 1, SX, 1, inside(-1, 0, 1)) -
+                     dab(SX - 1, SX, 1, inside(1, 0, -1)) + dab(SX + 1, SX, 1, inside(1, 0, 1));
+                g += dab(-SY - 1, SY, 1, inside(0, -1, -1)) - dab(-SY + 1, SY, 1, inside(0, -1, 1)) -
+                     dab(SY - 1, SY, 1, inside(0, 1, -1)) + dab(SY + 1, SY, 1, inside(0, 1, 1));
+#pragma unroll
+                for (int a2 = 0; a2 < BB_TX; ++a2)
+#pragma unroll
+                    for (int k2 = 0; k2 < 3; ++k2)
+                        if (a2 == xi && k2 == k) acc[a2][k2] = g;     // static register names (a dynamic index would go to scratch)
+            }
+        }
+    }
     const double M = (double)(X - 2) * (Y - 2) * (Z - 2) * 3;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int k = (int)(i % 3);
-        int64_t v = i / 3;
-        const int b = (int)(v / nvox);
-        v -= (int64_t)b * nvox;
-        const int z = (int)(v % Z), y = (int)((v / Z) % Y), x = (int)(v / ((int64_t)Y * Z));
-        BendCtx c{u + (size_t)b * nvox * 3, X, Y, Z, k};
-        float g = 0.f;
+    const float sc = (float)((double)(gout ? gout[b] : 1.f) / M);
+    const int gy = y0 + ty, gz = z0 + tz;
+    if (gy < Y && gz < Z) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const int ex = a == 0, ey = a == 1, ez = a == 2;
-            g += 2.f * (bend_daa(c, x - ex, y - ey, z - ez, a) - 2.f * bend_daa(c, x, y, z, a) + bend_daa(c, x + ex, y + ey, z + ez, a));
+        for (int xi = 0; xi < BB_TX; ++xi) {
+            const int gx = x0 + xi;
+            if (gx < X) {
+                float* o = du + ((size_t)b * nvox + ((size_t)gx * Y + gy) * Z + gz) * 3;
+                F3 r;
+                if (accumulate) {
+                    const F3 old = *reinterpret_cast<const F3*>(o);
+                    r.v[0] = old.v[0] + sc * acc[xi][0]; r.v[1] = old.v[1] + sc * acc[xi][1]; r.v[2] = old.v[2] + sc * acc[xi][2];
+                } else {
+                    r.v[0] = sc * acc[xi][0]; r.v[1] = sc * acc[xi][1]; r.v[2] = sc * acc[xi][2];
+                }
+                *reinterpret_cast<F3*>(o) = r;
+            }
         }
-#pragma unroll
-        for (int pr = 0; pr < 3; ++pr) {
-            const int a = pr == 2 ? 1 : 0, bb = pr == 0 ? 1 : 2;  // (x,y), (x,z), (y,z)
-            const int ax = a == 0, ay = a == 1, bx = 0, by = bb == 1, bz = bb == 2, az = 0;
-            // e has 2 d_ab^2 -> 4 d_ab * (+-1/4)
-            g += (bend_dab(c, x - ax - bx, y - ay - by, z - az - bz, a, bb) - bend_dab(c, x - ax + bx, y - ay + by, z - az + bz, a, bb) -
-                  bend_dab(c, x + ax - bx, y + ay - by, z + az - bz, a, bb) + bend_dab(c, x + ax + bx, y + ay + by, z + az + bz, a, bb));
-        }
-        const float val = (float)((double)(gout ? gout[b] : 1.f) / M) * g;
-        if (accumulate) du[i] += val; else du[i] = val;
     }
 }
 
@@ -1516,8 +1626,18 @@ extern "C" int mmr_bending_bwd_f32(const float* flow, const float* gout, float* 
                                    int accumulate, void* stream)
 {
     if (!flow || !dflow || B < 1 || X < 3 || Y < 3 || Z < 3) return MMR_EINVAL;
-    hipLaunchKernelGGL(bending_bwd_kernel, dim3(stream_grid((int64_t)B * X * Y * Z * 3, 256)), dim3(256), 0,
-                       as_stream(stream), flow, gout, dflow, B, X, Y, Z, accumulate);
+    const int ntx = (X + BB_TX - 1) / BB_TX, nty = (Y + BB_TY - 1) / BB_TY, ntz = (Z + BB_TZ - 1) / BB_TZ;
+    const int64_t nblk = (int64_t)B * ntx * nty * ntz;
+    if (nblk > 0x7fffffff) return MMR_EINVAL;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bending_bwd_tiled_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, BB_LDS);
+        if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(bending_bwd_tiled_kernel, dim3((unsigned)nblk), dim3(256), BB_LDS, as_stream(stream), flow, gout, dflow, X, Y,
+                       Z, ntx, nty, ntz, accumulate);
     return check_launch();
 }
 

@@ -869,3 +869,41 @@ def test_folded_wgrad_of_concat_layer(dev, shape, C0, C1, Cout, x3):
     one = torch.zeros_like(dw)
     ops.conv3d_k3_wgrad(_t(xl, dev), _t(dz, dev), one, in1=_t(sk, dev), up0=True, x3=x3)
     assert _rel(dw, 2 * one) < (2e-5 if x3 is True else 2e-2)
+
+
+@pytest.mark.parametrize("shape", [(3, 3, 3), (4, 8, 32), (5, 9, 33), (8, 16, 64), (7, 11, 40), (6, 3, 70), (16, 24, 100), (13, 27, 131)])
+def test_bending_backward_tiled_shapes(dev, shape):
+    """The tiled bending-energy gradient (4 x 8 x 32 tiles, field + halo 2 in LDS; tiles two voxels away from every face take the
+    collapsed 25-point stencil, the others the 21 masked second differences) at the smallest volume, exactly one tile, one voxel
+    past a tile in every axis, several tiles, thin volumes and volumes with both kinds of tile, vs float64 autograd."""
+    import mmr
+    from oracle import grad_torch as G
+    rng = np.random.default_rng(17)
+    u = (rng.standard_normal((2,) + shape + (3,)) * 2).astype(np.float32)
+    gout = np.array([0.7, -1.3], np.float32)
+    ut = torch.from_numpy(u).double().requires_grad_(True)
+    (G.bending_energy(ut) * torch.from_numpy(gout).double()).sum().backward()
+    du = mmr.ops.bending_energy_bwd(_t(u, dev), _t(gout, dev))
+    assert _rel(du, ut.grad) < 1e-5
+    assert _rel(mmr.ops.bending_energy_bwd(_t(u, dev)), torch.autograd.grad(G.bending_energy(ut).sum(), ut)[0]) < 1e-5
+
+
+def test_bending_backward_full_size_properties(dev):
+    """256^3 (BASELINE configs[4]): an affine field has no bending -> zero gradient; and the gradient is the derivative of the
+    forward kernel's energy along a random direction (central difference of two forward evaluations, fp32: 2e-3)."""
+    import mmr
+    S = (256, 256, 256)
+    x = torch.arange(S[0], dtype=torch.float32, device=dev).view(-1, 1, 1, 1)
+    y = torch.arange(S[1], dtype=torch.float32, device=dev).view(1, -1, 1, 1)
+    z = torch.arange(S[2], dtype=torch.float32, device=dev).view(1, 1, -1, 1)
+    aff = (0.5 * x - 0.25 * y + 0.125 * z + torch.tensor([1.0, -2.0, 3.0], device=dev)).contiguous()[None]
+    assert float(mmr.ops.bending_energy_bwd(aff).abs().max()) < 1e-9
+    g = torch.Generator(device="cpu").manual_seed(2)
+    lo = torch.randn((1, 32, 32, 32, 3), generator=g).to(dev)
+    u = mmr.ops.resize_trilinear(lo.contiguous(), S, mul=3.0)          # smooth field: second differences well above fp32 noise
+    d = mmr.ops.resize_trilinear(torch.randn((1, 32, 32, 32, 3), generator=g).to(dev).contiguous(), S)
+    grad = mmr.ops.bending_energy_bwd(u)
+    eps = 0.5
+    fd = (float(mmr.ops.bending_energy(u + eps * d)) - float(mmr.ops.bending_energy(u - eps * d))) / (2 * eps)   # exact: E is quadratic
+    an = float((grad.double() * d.double()).sum())
+    assert abs(fd - an) < 2e-3 * abs(an), (fd, an)

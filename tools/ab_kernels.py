@@ -152,3 +152,13 @@ if "ncc" in which or "bending" in which:
         def chk():
             assert float(o1) == float(o2), (float(o1), float(o2))
         ab("bending energy forward 256^3 (kernel + finalize | in-kernel)", f_old, f_new, check=chk)
+        g1, g2 = torch.empty_like(flow), torch.empty_like(flow)
+        f_old = lambda: old.mmr_bending_bwd_f32(flow.data_ptr(), None, g1.data_ptr(), 1, *S, 0, st())
+        f_new = lambda: new.mmr_bending_bwd_f32(flow.data_ptr(), None, g2.data_ptr(), 1, *S, 0, st())
+
+        def chk():
+            assert float((g1 - g2).abs().max() / g1.abs().max()) < 1e-5, float((g1 - g2).abs().max() / g1.abs().max())
+        ab("bending energy BACKWARD 256^3 (gather | tiled)", f_old, f_new, check=chk, n=5)
+        for vn, vl in VARIANTS.items():
+            if vn.startswith("bb"):
+                ab(f"  ... TIMING-ONLY {vn}", f_old, lambda: vl.mmr_bending_bwd_f32(flow.data_ptr(), None, g2.data_ptr(), 1, *S, 0, st()), n=5)
