@@ -309,6 +309,46 @@ __device__ __forceinline__ float ncc_cc4_sum(const float (&S)[4][5], float eps)
     return tot.x + tot.y;
 }
 
+// Backward: the five per-window coefficient fields of FOUR windows from their box sums, means eliminated as above.  With
+//   A = d cc / d cross,  Bc = d cc / d Iv,  Cc = d cc / d Jv   (ncc_terms)   and   d cross / d I_p = J_p - uJ,  d Iv / d I_p = 2 (I_p - uI):
+//   d cc_c / d I_p = J_p A + I_p (2 Bc) - (A uJ + 2 Bc uI),     d cc_c / d J_p = I_p A + J_p (2 Cc) - (A uI + 2 Cc uJ)
+// for every window c that contains p, i.e. FIVE fields to box-filter (A, 2 Bc, 2 Cc and the two mean terms), not seven.
+typedef float f4_t __attribute__((ext_vector_type(4)));
+template <int FORM>
+__device__ __forceinline__ void ncc_coef4(const float (&S)[4][5], float eps, f4_t (&C)[5])
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float uI = S[k][0] * (1.0f / 729.f), uJ = S[k][1] * (1.0f / 729.f);
+        float cross = __builtin_fmaf(-uI, S[k][1], S[k][4]);
+        float iv = __builtin_fmaf(-uI, S[k][0], S[k][2]);
+        float jv = __builtin_fmaf(-uJ, S[k][1], S[k][3]);
+        float A, B2, C2;
+        if (FORM == MMR_NCC_CLAMPED) {     // tf.maximum passes the gradient to the larger side (ncc_terms)
+            const bool kc = cross > eps, ki = iv > eps, kj = jv > eps;
+            cross = kc ? cross : eps;
+            iv = ki ? iv : eps;
+            jv = kj ? jv : eps;
+            const float qi = __builtin_amdgcn_rcpf(iv), qj = __builtin_amdgcn_rcpf(jv);
+            const float ri = cross * qi, rj = cross * qj, m = -2.f * ri * rj;
+            A = kc ? 2.f * ri * qj : 0.f;
+            B2 = ki ? m * qi : 0.f;
+            C2 = kj ? m * qj : 0.f;
+        } else {
+            const float r = cross * __builtin_amdgcn_rcpf(__builtin_fmaf(iv, jv, eps));
+            const float m = -2.f * r * r;
+            A = 2.f * r;
+            B2 = m * jv;
+            C2 = m * iv;
+        }
+        C[0][k] = A;
+        C[1][k] = B2;
+        C[2][k] = C2;
+        C[3][k] = __builtin_fmaf(A, uJ, B2 * uI);
+        C[4][k] = __builtin_fmaf(A, uI, C2 * uJ);
+    }
+}
+
 constexpr int NCC_ZOUT = 56;   // outputs per wave along z (lanes 4..59)
 constexpr int NCC_ROWS = 32;   // output rows per wave strip
 
@@ -669,7 +709,6 @@ __device__ __forceinline__ float wave_shl1(float v)   // lane l <- lane l+1, lan
 // over that many add / subtract pairs stays two orders below the rounding of the 729-term window sum it feeds.
 constexpr int N4_WAVES = 8, N4_RPW = 2, N4_ROWS = N4_WAVES * N4_RPW, N4_YOUT = N4_ROWS - 8;
 constexpr int N4_TILE_BYTES = N4_ROWS * 5 * 64 * 16;                  // 81,920: the published x-sums
-typedef float f4_t __attribute__((ext_vector_type(4)));
 // y + x[lane - 1] / y + x[lane + 1] (0 beyond the wave's ends) as ONE v_add_f32_dpp.  Written out because hipcc kept the
 // shifts of this kernel as v_mov_b32_dpp + a separate add (40 extra VALU per plane step); the s_nop covers the two wait
 // states a DPP read needs after a VALU write of its source (the hazard recogniser does not look inside inline asm).
@@ -708,10 +747,13 @@ __device__ __forceinline__ void zwin4(const f4_t v, float& o0, float& o1, float&
         : "v"(P), "v"(s123), "v"(s23), "v"(v.w), "v"(v.x), "v"(p01), "v"(p012));
 }
 
-template <int FORM>
+// COEF (the backward's first pass): the same march, but instead of reducing cc every wave writes the five coefficient fields of
+// ncc_coef4 for its output row to coef [B][5][X][Y][Z]; nothing is reduced and `part` / `fin` are unused.
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+template <int FORM, bool COEF = false>
 __global__ void __launch_bounds__(N4_WAVES * 64, 4)
 ncc_fused4_kernel(const float* __restrict__ I, const float* __restrict__ J, double* __restrict__ part, int X, int Y, int Z,
-                   int xseg, int nxs, int nyt, float eps, const TicketFin fin)
+                   int xseg, int nxs, int nyt, float eps, const TicketFin fin, float* __restrict__ coef = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f4_t* buf = reinterpret_cast<f4_t*>(smem);             // [N4_ROWS][5][64]
@@ -785,6 +827,14 @@ ncc_fused4_kernel(const float* __restrict__ I, const float* __restrict__ J, doub
     const bool oval = zin && (yt * N4_YOUT + w) < Y;
     float acc = 0.f;
     const int xi0 = x0 - 4, nstep = (x1 - x0) + 8;
+    __amdgpu_buffer_rsrc_t rsC[5];
+    unsigned cofs = 0xF0000000u;
+    if (COEF) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+            rsC[q] = __builtin_amdgcn_make_buffer_rsrc(coef + ((size_t)b * 5 + q) * nvox, 0, (int)vol_bytes, 0x00020000);
+        if (oval) cofs = (unsigned)((yt * N4_YOUT + w) * Z + 4 * lane) * 4u;      // else beyond num_records: the store is dropped
+    }
     f4_t na[N4_RPW], nc[N4_RPW], oa[N4_RPW], oc[N4_RPW];   // the plane that joins the window at this step / the one that leaves after it
     // warm-up: the eight planes in front of the first complete window join in two batches of four whose loads are all in flight
     // together (one plane per round trip, as the steady state does it, left a fresh workgroup waiting eight round trips)
@@ -868,9 +918,19 @@ ncc_fused4_kernel(const float* __restrict__ I, const float* __restrict__ J, doub
             zwin4(v, S[0][q], S[1][q], S[2][q], S[3][q]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (oval) acc += ncc_cc4_sum<FORM>(S, eps);
+        if (COEF) {
+            f4_t C[5];
+            ncc_coef4<FORM>(S, eps, C);
+            const unsigned soff = (unsigned)(x0 + s - 8) * (unsigned)(Y * Z) * 4u;       // the window's centre plane
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, C[q]), rsC[q], cofs, soff, 0);
+        } else if (oval) {
+            acc += ncc_cc4_sum<FORM>(S, eps);
+        }
         __syncthreads();                                    // the tile is rewritten by the next plane
     }
+    if (COEF) return;
     double v = wave_sum((double)acc);
     double* sh = reinterpret_cast<double*>(smem);
     if (lane == 0) sh[w] = v;
@@ -882,6 +942,215 @@ ncc_fused4_kernel(const float* __restrict__ I, const float* __restrict__ J, doub
         publish_partial(part, lblk, r, fin);
     }
     ticket_finalize(part, fin, smem + 1024);
+}
+
+// The backward's second pass: the 9^3 box filter (zero padded) of the coefficient fields, with the SAME march as the forward (x:
+// sliding sums with the leaving plane loaded again; y: pair sums through LDS; z: DPP), combined at the voxel with
+// I_p, J_p into the gradients:   dI_p = s (J_p [A] + I_p [2 Bc] - [A uJ + 2 Bc uI]),   dJ_p = s (I_p [A] + J_p [2 Cc] - [A uI + 2 Cc uJ]),
+// s = -gout[b] / N, [.] = box sum.  NF = 3: ONE gradient (its three fields; `only` = 0: dI, 1: dJ; a doubled grid, only = -1, gives
+// both and was measured slower than NF = 5), every load of the next step in flight a step ahead as in the forward.  NF = 5: both gradients
+// from one filter of all five fields; 2 rows x 5 fields x (joining + leaving plane) would be 80 registers of loads in flight, so
+// the leaving plane is requested into the joining plane's registers once those have been added (two round trips per step, the
+// second one under the y / z sums).  Sliding sums of coefficient fields return to exact zero the same way as the forward's: a
+// per-lane, per-z counter of consecutive planes in which every field was zero.
+struct NccGradArgs { const float* C; const float* I; const float* J; const float* gout; float* dI; float* dJ; };
+
+template <int NF>
+__global__ void __launch_bounds__(N4_WAVES * 64, 4)
+ncc_boxgrad4_kernel(const NccGradArgs a, int X, int Y, int Z, int xseg, int nxs, int nyt, int nblk, int only)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f4_t* buf = reinterpret_cast<f4_t*>(smem);             // [N4_ROWS][NF][64]
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int t = blockIdx.x;
+    {   // XCD-contiguous runs of logical workgroups (see ncc_fused4_kernel)
+        const int nwg = gridDim.x, xcd = t & 7, qd = nwg >> 3, rm = nwg & 7;
+        t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (t >> 3);
+    }
+    const int which = NF == 5 ? 0 : (only >= 0 ? only : t / nblk);      // NF == 3: 0 = dI, 1 = dJ
+    t %= nblk;
+    const int yt = t % nyt; t /= nyt;
+    const int xs = t % nxs;
+    const int b = t / nxs;
+    const int x0 = xs * xseg;
+    const int x1 = (x0 + xseg < X) ? x0 + xseg : X;
+    const bool zin = 4 * lane < Z;
+    const size_t nvox = (size_t)X * Y * Z;
+    unsigned rofs[N4_RPW];
+#pragma unroll
+    for (int r = 0; r < N4_RPW; ++r) {
+        const int y = yt * N4_YOUT - 4 + w * N4_RPW + r;
+        const bool in = zin && y >= 0 && y < Y;
+        rofs[r] = in ? (unsigned)(y * Z + 4 * lane) * 4u : 0xF0000000u;
+    }
+    const int yo = yt * N4_YOUT + w;
+    const unsigned oofs = (zin && yo < Y) ? (unsigned)(yo * Z + 4 * lane) * 4u : 0xF0000000u;   // this wave's output row
+    const unsigned vol_bytes = (unsigned)(nvox * 4);
+    const unsigned plane_bytes = (unsigned)(Y * Z) * 4u;
+    auto rsrc = [&](const float* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)vol_bytes, 0x00020000); };
+    __amdgpu_buffer_rsrc_t rsC[NF];
+    const float* Cb = a.C + (size_t)b * 5 * nvox;
+#pragma unroll
+    for (int q = 0; q < NF; ++q) {
+        const int f = NF == 5 ? q : (q == 0 ? 0 : (q == 1 ? 1 + which : 3 + which));
+        rsC[q] = rsrc(Cb + (size_t)f * nvox);
+    }
+    // P multiplies [A], Q the second field: (J, I) for dI, (I, J) for dJ; with NF == 5: P = J, Q = I
+    const __amdgpu_buffer_rsrc_t rsP = rsrc((which == 0 ? a.J : a.I) + (size_t)b * nvox);
+    const __amdgpu_buffer_rsrc_t rsQ = rsrc((which == 0 ? a.I : a.J) + (size_t)b * nvox);
+    const __amdgpu_buffer_rsrc_t rsO0 = rsrc((which == 0 ? a.dI : a.dJ) + (size_t)b * nvox);
+    const __amdgpu_buffer_rsrc_t rsO1 = rsrc((NF == 5 ? a.dJ : a.dI) + (size_t)b * nvox);       // used with NF == 5 only
+    const float sc = -(a.gout ? a.gout[b] : 1.f) / (float)nvox;          // loss_b = -mean(cc)
+    auto ldp = [&](const __amdgpu_buffer_rsrc_t& rs, int xq, unsigned row) -> f4_t {
+        const bool xin = xq >= 0 && xq < X;
+        const unsigned soff = xin ? (unsigned)xq * plane_bytes : 0u;
+        const unsigned voff = xin ? row : 0xF0000000u;
+        return __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+    };
+    const f4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+    f4_t W[N4_RPW][NF];
+#pragma unroll
+    for (int r = 0; r < N4_RPW; ++r)
+#pragma unroll
+        for (int q = 0; q < NF; ++q) W[r][q] = zero4;
+    typedef int i4_t __attribute__((ext_vector_type(4)));
+    i4_t zrun[N4_RPW];
+#pragma unroll
+    for (int r = 0; r < N4_RPW; ++r) zrun[r] = i4_t{0, 0, 0, 0};
+    auto join = [&](int r, const f4_t (&v)[NF]) {
+        i4_t any = __builtin_bit_cast(i4_t, v[0]);
+#pragma unroll
+        for (int q = 0; q < NF; ++q) W[r][q] += v[q];
+#pragma unroll
+        for (int q = 1; q < NF; ++q) any |= __builtin_bit_cast(i4_t, v[q]);
+        any &= 0x7fffffff;
+        i4_t& z = zrun[r];
+        z.x = any.x == 0 ? z.x + 1 : 0; z.y = any.y == 0 ? z.y + 1 : 0; z.z = any.z == 0 ? z.z + 1 : 0; z.w = any.w == 0 ? z.w + 1 : 0;
+        const bool hit = (z.x == 9) | (z.y == 9) | (z.z == 9) | (z.w == 9);
+        if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {            // rare: some column's window has just become all zero
+#pragma unroll
+            for (int q = 0; q < NF; ++q) {
+                if (z.x == 9) W[r][q].x = 0.f;
+                if (z.y == 9) W[r][q].y = 0.f;
+                if (z.z == 9) W[r][q].z = 0.f;
+                if (z.w == 9) W[r][q].w = 0.f;
+            }
+        }
+    };
+    auto sub4 = [](f4_t& Wq, const f4_t v) {      // packed, in place (see ncc_fused4_kernel)
+        f2_t lo = __builtin_shufflevector(Wq, Wq, 0, 1), hi = __builtin_shufflevector(Wq, Wq, 2, 3);
+        const f2_t vl = __builtin_shufflevector(v, v, 0, 1), vh = __builtin_shufflevector(v, v, 2, 3);
+        asm("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(lo) : "v"(vl));
+        asm("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(hi) : "v"(vh));
+        Wq = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+    };
+    const int xi0 = x0 - 4, nstep = (x1 - x0) + 8;
+    constexpr bool TWOPHASE = NF == 5;
+    constexpr int WB = NF == 5 ? 1 : 2;                    // planes per warm-up batch (their loads are in flight together)
+    f4_t nw[N4_RPW][NF], ol[TWOPHASE ? 1 : N4_RPW][NF];    // the joining plane / the leaving one (TWOPHASE: `nw` serves both)
+    f4_t ip, iq;                                           // the images at this wave's output row, a step ahead
+#pragma unroll 1
+    for (int h = 0; h < 8 / WB; ++h) {
+        f4_t pv[WB][N4_RPW][NF];
+#pragma unroll
+        for (int k = 0; k < WB; ++k)
+#pragma unroll
+            for (int r = 0; r < N4_RPW; ++r)
+#pragma unroll
+                for (int q = 0; q < NF; ++q) pv[k][r][q] = ldp(rsC[q], xi0 + WB * h + k, rofs[r]);
+#pragma unroll
+        for (int k = 0; k < WB; ++k)
+#pragma unroll
+            for (int r = 0; r < N4_RPW; ++r) join(r, pv[k][r]);
+    }
+#pragma unroll
+    for (int r = 0; r < N4_RPW; ++r)
+#pragma unroll
+        for (int q = 0; q < NF; ++q) {
+            nw[r][q] = ldp(rsC[q], xi0 + 8, rofs[r]);
+            if (!TWOPHASE) ol[r][q] = ldp(rsC[q], xi0, rofs[r]);
+        }
+    ip = ldp(rsP, x0, oofs);
+    iq = ldp(rsQ, x0, oofs);
+    for (int s = 8; s < nstep; ++s) {
+#pragma unroll
+        for (int r = 0; r < N4_RPW; ++r) join(r, nw[r]);
+        if (TWOPHASE) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < N4_RPW; ++r)
+#pragma unroll
+                for (int q = 0; q < NF; ++q) nw[r][q] = ldp(rsC[q], xi0 + s - 8, rofs[r]);      // the plane that leaves after this step
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < NF; ++q) buf[(w * NF + q) * 64 + lane] = W[0][q] + W[1][q];
+        if (w < 4) {
+#pragma unroll
+            for (int q = 0; q < NF; ++q) buf[((8 + w) * NF + q) * 64 + lane] = W[1][q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < NF; ++q) buf[((8 + w) * NF + q) * 64 + lane] = W[0][q];
+        }
+        const f4_t pcur = ip, qcur = iq;
+        if (!TWOPHASE) {
+#pragma unroll
+            for (int r = 0; r < N4_RPW; ++r)
+#pragma unroll
+                for (int q = 0; q < NF; ++q) sub4(W[r][q], ol[r][q]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < N4_RPW; ++r)
+#pragma unroll
+                for (int q = 0; q < NF; ++q) {
+                    nw[r][q] = ldp(rsC[q], xi0 + s + 1, rofs[r]);
+                    ol[r][q] = ldp(rsC[q], xi0 + s - 7, rofs[r]);
+                }
+            ip = ldp(rsP, x0 + s - 7, oofs);
+            iq = ldp(rsQ, x0 + s - 7, oofs);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        const int p0 = (w + 1) >> 1;
+        const int s1 = 8 + ((w & 1) ? (w >> 1) : (w >> 1) + 4);
+        float S[4][NF];
+#pragma unroll
+        for (int q = 0; q < NF; ++q) {
+            f4_t v = buf[(s1 * NF + q) * 64 + lane];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v += buf[((p0 + k) * NF + q) * 64 + lane];
+            zwin4(v, S[0][q], S[1][q], S[2][q], S[3][q]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const unsigned soff = (unsigned)(x0 + s - 8) * plane_bytes;
+        f4_t g0, g1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (NF == 5) {
+                g0[k] = sc * (pcur[k] * S[k][0] + qcur[k] * S[k][1] - S[k][3]);
+                g1[k] = sc * (qcur[k] * S[k][0] + pcur[k] * S[k][2] - S[k][4]);
+            } else {
+                g0[k] = sc * (pcur[k] * S[k][0] + qcur[k] * S[k][1] - S[k][2]);
+            }
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, g0), rsO0, oofs, soff, 0);
+        if (NF == 5) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, g1), rsO1, oofs, soff, 0);
+        __syncthreads();                                    // the tile is rewritten by the next plane
+        if (TWOPHASE) {
+#pragma unroll
+            for (int r = 0; r < N4_RPW; ++r)
+#pragma unroll
+                for (int q = 0; q < NF; ++q) sub4(W[r][q], nw[r][q]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < N4_RPW; ++r)
+#pragma unroll
+                for (int q = 0; q < NF; ++q) nw[r][q] = ldp(rsC[q], xi0 + s + 1, rofs[r]);
+            ip = ldp(rsP, x0 + s - 7, oofs);
+            iq = ldp(rsQ, x0 + s - 7, oofs);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 }
 
 // x[lane + 1] + x[lane - 1] and x[lane + 1] - x[lane - 1] (0 beyond the wave's ends): one DPP move + one DPP-fused VOP2
@@ -1589,12 +1858,51 @@ extern "C" int mmr_bending_fwd_ticket_f32(const float* flow, float* out, void* w
     return bending_fwd_impl(flow, out, ws, ticket, B, X, Y, Z, scale, accumulate, stream);
 }
 
-// d(-mean cc)/dI and /dJ, scaled by gout[b] (null = 1); dI / dJ may be null.  Workspace: 19 volumes of fp32.
+// d(-mean cc)/dI and /dJ, scaled by gout[b] (null = 1); dI / dJ may be null.  Workspace: the five coefficient fields of the
+// two-pass form (Z % 4 == 0, Z <= 256), else 19 volumes of fp32 for the separable four-launch form.
 extern "C" int64_t mmr_ncc_bwd_ws_bytes(int B, int X, int Y, int Z)
 {
     if (B < 1 || X < 1 || Y < 1 || Z < 1) return MMR_EINVAL;
-    return (int64_t)B * 19 * X * Y * Z * (int64_t)sizeof(float);
+    const int nvol = ncc_fused4_ok((int64_t)X * Y * Z, Z) ? 5 : 19;
+    return (int64_t)B * nvol * X * Y * Z * (int64_t)sizeof(float);
 }
+
+namespace {
+template <int FORM>
+int ncc_bwd_fused(const float* I, const float* J, const float* gout, float* dI, float* dJ, float* coef, int B, int X, int Y, int Z,
+                  float eps, hipStream_t st)
+{
+    int nyt, nxs, xseg;
+    ncc_fused4_geom(B, X, Y, nyt, nxs, xseg);
+    const int64_t nblk = (int64_t)B * nyt * nxs;
+    if (2 * nblk > 0x7fffffff || (int64_t)Y * Z > 0x3fffffff) return MMR_EINVAL;
+    static bool attr = false;
+    if (!attr) {
+        const struct { const void* k; int bytes; } ks[] = {
+            {reinterpret_cast<const void*>(ncc_fused4_kernel<FORM, true>), N4_LDS_BYTES},
+            {reinterpret_cast<const void*>(ncc_boxgrad4_kernel<3>), N4_ROWS * 3 * 64 * 16},
+            {reinterpret_cast<const void*>(ncc_boxgrad4_kernel<5>), N4_ROWS * 5 * 64 * 16}};
+        for (const auto& k : ks) {
+            hipError_t e = hipFuncSetAttribute(k.k, hipFuncAttributeMaxDynamicSharedMemorySize, k.bytes);
+            if (e != hipSuccess) { set_hip_error(e); return MMR_EHIP; }
+        }
+        attr = true;
+    }
+    TicketFin fin{};
+    hipLaunchKernelGGL((ncc_fused4_kernel<FORM, true>), dim3((unsigned)nblk), dim3(N4_WAVES * 64), N4_LDS_BYTES, st, I, J,
+                       (double*)nullptr, X, Y, Z, xseg, nxs, nyt, eps, fin, coef);
+    const NccGradArgs a{coef, I, J, gout, dI, dJ};
+    const bool both = dI && dJ;
+    // both: one filter of five fields, 309 us at 256^3 against 343 us for two of three (profiles/r05_ab_ncc_bwd_two_pass.log)
+    if (both)
+        hipLaunchKernelGGL(ncc_boxgrad4_kernel<5>, dim3((unsigned)nblk), dim3(N4_WAVES * 64), N4_ROWS * 5 * 64 * 16, st, a, X, Y, Z,
+                           xseg, nxs, nyt, (int)nblk, -1);
+    else
+        hipLaunchKernelGGL(ncc_boxgrad4_kernel<3>, dim3((unsigned)nblk), dim3(N4_WAVES * 64), N4_ROWS * 3 * 64 * 16, st, a, X, Y, Z,
+                           xseg, nxs, nyt, (int)nblk, dI ? 0 : 1);
+    return check_launch();
+}
+}  // namespace
 
 extern "C" int mmr_ncc_bwd_f32(const float* I, const float* J, const float* gout, float* dI, float* dJ, void* ws, int B,
                                int X, int Y, int Z, int win, float eps, int ncc_form, void* stream)
@@ -1602,6 +1910,10 @@ extern "C" int mmr_ncc_bwd_f32(const float* I, const float* J, const float* gout
     if (!I || !J || !ws || (!dI && !dJ) || B < 1 || X < 1 || Y < 1 || Z < 1) return MMR_EINVAL;
     if (ncc_form != MMR_NCC_CLASSIC && ncc_form != MMR_NCC_CLAMPED) return MMR_EINVAL;
     if (win != 9) return MMR_EUNSUPPORTED;
+    if (ncc_fused4_ok((int64_t)X * Y * Z, Z))
+        return ncc_form == MMR_NCC_CLAMPED
+                   ? ncc_bwd_fused<MMR_NCC_CLAMPED>(I, J, gout, dI, dJ, (float*)ws, B, X, Y, Z, eps, as_stream(stream))
+                   : ncc_bwd_fused<MMR_NCC_CLASSIC>(I, J, gout, dI, dJ, (float*)ws, B, X, Y, Z, eps, as_stream(stream));
     int nseg, ncolblk;
     ncc_geom(X, Y, Z, nseg, ncolblk);
     if ((int64_t)B * nseg > 65535) return MMR_EINVAL;

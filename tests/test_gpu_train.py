@@ -726,6 +726,33 @@ def test_ncc_and_bending_backward(dev, shape):
     assert _rel(acc, 2 * ut.grad) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(19, 23, 64), (17, 40, 128), (33, 12, 256), (8, 8, 4), (70, 9, 12), (9, 16, 200)])
+@pytest.mark.parametrize("form", ["classic", "clamped"])
+def test_ncc_backward_two_pass_form(dev, shape, form):
+    """Z % 4 == 0, Z <= 256: coefficient pass (the forward's march writing A, 2 Bc, 2 Cc and the two mean terms) + ONE box-filter
+    pass that combines them with I_p, J_p.  Both gradients from one filter of five fields, or one gradient from three; several x
+    segments (X = 70), partial y tiles, rows shorter than a wave, B = 2 with signed gout.  Against float64 autograd."""
+    import mmr
+    from oracle import grad_torch as G
+    rng = np.random.default_rng(5)
+    B = 2
+    I = rng.random((B,) + shape + (1,)).astype(np.float32)
+    J = (0.6 * I + 0.4 * rng.random((B,) + shape + (1,))).astype(np.float32)
+    if form == "clamped":                      # a block where both are constant: all three maxima bind (see test_gpu_semantics)
+        I[:, 1:7, 2:8, 0:4] = 0.25
+        J[:, 1:7, 2:8, 0:4] = 0.75
+    gout = np.array([1.0, -0.5], np.float32)
+    It, Jt = torch.from_numpy(I).double().requires_grad_(True), torch.from_numpy(J).double().requires_grad_(True)
+    (G.ncc_loss(It, Jt, form=form) * torch.from_numpy(gout).double()).sum().backward()
+    Id, Jd, gd = _t(I, dev), _t(J, dev), _t(gout, dev)
+    dI, dJ = mmr.ops.ncc_loss_bwd(Id, Jd, gd, form=form)
+    assert _rel(dI, It.grad) < 2e-5 and _rel(dJ, Jt.grad) < 2e-5
+    oI, none = mmr.ops.ncc_loss_bwd(Id, Jd, gd, want=("I",), form=form)
+    assert none is None and _rel(oI, It.grad) < 2e-5
+    none, oJ = mmr.ops.ncc_loss_bwd(Id, Jd, gd, want=("J",), form=form)
+    assert none is None and _rel(oJ, Jt.grad) < 2e-5
+
+
 def test_dense_dice_backward(dev):
     import mmr
     from oracle import grad_torch as G

@@ -128,7 +128,7 @@ if "thin" in which:
     def chk2():
         assert float((e1 - e2).abs().max() / e1.abs().max()) < 1e-6
     ab("first-layer weight gradient fp32x3 (thin_wgrad_x3), 160^3 x 64", lambda: call(old, e1), lambda: call(new, e2), check=chk2)
-if "ncc" in which or "bending" in which:
+if "ncc" in which or "bending" in which or "nccbwd" in which:
     S = (256, 256, 256)
     I, J = torch.rand((1,) + S + (1,), generator=g).to(dev), torch.rand((1,) + S + (1,), generator=g).to(dev)
     flow = torch.randn((1,) + S + (3,), generator=g).to(dev)
@@ -144,6 +144,30 @@ if "ncc" in which or "bending" in which:
         ab("NCC(9) forward 256^3 (kernel + finalize | in-kernel finalize)", f_old, f_new, check=chk)
         f_new2 = lambda: new.mmr_ncc_fwd_f32(I.data_ptr(), J.data_ptr(), o2.data_ptr(), ws.data_ptr(), 1, *S, 9, 1e-5, 0, st())
         ab("NCC(9) forward 256^3 (both with the finalize launch)", f_old, f_new2, check=chk)
+    if "nccbwd" in which:
+        wso = torch.empty(int(old.mmr_ncc_bwd_ws_bytes(1, *S)) + 1024, dtype=torch.uint8, device=dev)
+        wsn = torch.empty(int(new.mmr_ncc_bwd_ws_bytes(1, *S)) + 1024, dtype=torch.uint8, device=dev)
+        a1, b1, a2, b2 = (torch.empty_like(I) for _ in range(4))
+        f_old = lambda: old.mmr_ncc_bwd_f32(I.data_ptr(), J.data_ptr(), None, a1.data_ptr(), b1.data_ptr(), wso.data_ptr(), 1, *S, 9, 1e-5, 0, st())
+        f_new = lambda: new.mmr_ncc_bwd_f32(I.data_ptr(), J.data_ptr(), None, a2.data_ptr(), b2.data_ptr(), wsn.data_ptr(), 1, *S, 9, 1e-5, 0, st())
+
+        def chk():
+            e = max(float((a1 - a2).abs().max() / a1.abs().max()), float((b1 - b2).abs().max() / b1.abs().max()))
+            assert e < 2e-5, e
+        if hasattr(new, "mmr_ncc_bwd_set_form"):
+            for nf in (5, 3):
+                new.mmr_ncc_bwd_set_form(nf)
+                ab(f"NCC(9) BACKWARD 256^3, dI + dJ (four separable launches | coefficients + box filter, NF = {nf})", f_old, f_new, check=chk, n=5)
+            new.mmr_ncc_bwd_set_form(-1)
+        else:
+            ab("NCC(9) BACKWARD 256^3, dI + dJ (four separable launches | coefficients + box filter)", f_old, f_new, check=chk, n=5)
+        f_old1 = lambda: old.mmr_ncc_bwd_f32(I.data_ptr(), J.data_ptr(), None, None, b1.data_ptr(), wso.data_ptr(), 1, *S, 9, 1e-5, 0, st())
+        f_new1 = lambda: new.mmr_ncc_bwd_f32(I.data_ptr(), J.data_ptr(), None, None, b2.data_ptr(), wsn.data_ptr(), 1, *S, 9, 1e-5, 0, st())
+
+        def chk1():
+            e = float((b1 - b2).abs().max() / b1.abs().max())
+            assert e < 2e-5, e
+        ab("NCC(9) BACKWARD 256^3, dJ only", f_old1, f_new1, check=chk1, n=5)
     if "bending" in which:
         ws = torch.empty(int(new.mmr_bending_ws_bytes(1, *S)) + 1024, dtype=torch.uint8, device=dev)
         f_old = lambda: old.mmr_bending_fwd_f32(flow.data_ptr(), o1.data_ptr(), ws.data_ptr(), 1, *S, st())
