@@ -661,7 +661,7 @@ def main():
                 res["bwd"] = {"ms_per_step": t_ncc + t_ben, "steps": steps, "warmup": warmup,
                               "ncc_bwd": {"ms": t_ncc, "algorithmic_bytes": b_ncc, "GBps": b_ncc / (t_ncc * 1e-3) / 1e9,
                                           "frac_of_hbm_peak": b_ncc / (t_ncc * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                          "note": "two-pass form: zy box sums, x box + coefficients, x gradient (7 launches; the window sums exist as fields)"},
+                                          "note": "two launches: the forward's march writing five coefficient fields, then ONE 9^3 box filter of them combined with I_p, J_p (335 MB of fields between the two)"},
                               "bending_bwd": {"ms": t_ben, "algorithmic_bytes": b_ben, "GBps": b_ben / (t_ben * 1e-3) / 1e9,
                                               "frac_of_hbm_peak": b_ben / (t_ben * 1e-3) / 1e9 / PEAK_HBM_GBS},
                               "fwd_plus_bwd_ms": res["ms_per_step_without_events"] + t_ncc + t_ben}

@@ -128,6 +128,16 @@ if "thin" in which:
     def chk2():
         assert float((e1 - e2).abs().max() / e1.abs().max()) < 1e-6
     ab("first-layer weight gradient fp32x3 (thin_wgrad_x3), 160^3 x 64", lambda: call(old, e1), lambda: call(new, e2), check=chk2)
+if "compose" in which:
+    for S in ((80, 80, 80), (80, 80, 96), (160, 160, 192)):
+        vel = (torch.randn((1,) + S + (3,), generator=g) * 3).to(dev)
+        o1, o2, tmp = torch.empty_like(vel), torch.empty_like(vel), torch.empty_like(vel)
+        f_old = lambda: old.mmr_vecint_f32(vel.data_ptr(), o1.data_ptr(), tmp.data_ptr(), 1, *S, 5, st())
+        f_new = lambda: new.mmr_vecint_f32(vel.data_ptr(), o2.data_ptr(), tmp.data_ptr(), 1, *S, 5, st())
+
+        def chk():
+            assert torch.equal(o1, o2), float((o1 - o2).abs().max())
+        ab(f"VecInt, 5 squaring steps, {S} (thread per voxel x channel | per voxel), bit-identical", f_old, f_new, check=chk)
 if "ncc" in which or "bending" in which or "nccbwd" in which:
     S = (256, 256, 256)
     I, J = torch.rand((1,) + S + (1,), generator=g).to(dev), torch.rand((1,) + S + (1,), generator=g).to(dev)
