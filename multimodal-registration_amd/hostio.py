@@ -86,7 +86,10 @@ class Registered:
 
     def __exit__(self, *exc):
         if self.ok:
-            _lib.load().mmr_host_unregister(ctypes.c_void_p(self.a.ctypes.data))
+            self.ok = False
+            rc = _lib.load().mmr_host_unregister(ctypes.c_void_p(self.a.ctypes.data))
+            if rc != 0 and exc[0] is None:      # pages left pinned behind the caller's back: loud, not silent
+                _lib.check(rc, "mmr_host_unregister")
         return False
 
 
