@@ -80,6 +80,7 @@ struct ConvParams {
     // split-K partials go to a compact buffer kpart[kz][blockIdx.x][tile voxel][Cout] (conv_ktail_finalize_kernel reads it)
     int tile0 = 0;
     int kcompact = 0;
+    int xcd_pair = 0;   // CV_UPFOLD: parity classes per XCD group, 0 = blockIdx.y order (see the kernel)
     // CV_POOLF: gradient of MaxPooling3D(2) of ymask's tensor, [B, X/2, Y/2, Z/2, Cout] (see CV_POOLF)
     const float* dpool = nullptr;
 };
@@ -283,15 +284,36 @@ conv3d_k3_kernel(const ConvParams p)
     const int wm = wave / WN, wn = wave % WN;
     const int h = lane >> 5;
 
-    int bid = (int)blockIdx.x + p.tile0;
+    const int ntn = UPF ? (p.Cout + BN - 1) / BN : 1;
+    int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+    if constexpr (UPF) {
+        // Which (tile, class) a workgroup takes.  Dispatch order is x fastest and workgroup L lands on XCD L & 7, so with
+        // blockIdx.y = class every XCD works through ONE class at a time and each of the 8 classes fetches the layer's whole input
+        // again from HBM / the Infinity Cache (C2: 6.3 GB per step for 0.36 GB of input).  xcd_pair = P: a group of P XCDs takes P
+        // classes of all tiles, a tile's P classes back to back on ONE XCD -- all but the first find the haloed A tile in that
+        // XCD's L2, which then holds P classes' weights instead of one.  A bijection for every grid size (checked on the host for
+        // P = 2, 4, 8).  Same-box, same library, off | on (profiles/r05_ab_upfold_xcd_groups.log): bf16 dec_final_0 -3.3 / -2.8 /
+        // -2.8 % for P = 2 / 4 / 8, dec_conv_3 -1.1 / -1.3 / +0.7 %, fp32x3 dec_final_0 -0.6 / -3.6 / -2.8 %: P = 4.
+        if (p.xcd_pair) {
+            const int P = p.xcd_pair;                              // classes per XCD group
+            const int n = (int)gridDim.x * ntn;                    // (tile, n-tile) blocks per class = workgroups per XCD
+            const int L = by * (int)gridDim.x + bx, x = L & 7, k = L >> 3;
+            const int xg = x % P, full = (n / P) * P, r = n - full;
+            int g, c;
+            if (k < full) { g = (k / P) * P + xg; c = k % P; }
+            else { const int t = xg * r + (k - full); g = full + t / P; c = t % P; }
+            bx = g / ntn;
+            by = ((x / P) * P + c) * ntn + g % ntn;
+        }
+    }
+    int bid = bx + p.tile0;
     const int tzi = bid % p.ntz; bid /= p.ntz;
     const int tyi = bid % p.nty; bid /= p.nty;
     const int txi = bid % p.ntx;
     const int b = bid / p.ntx;
     const int x0 = txi * TXT, y0 = tyi * TY, z0 = tzi * TZ;
-    const int ntn = UPF ? (p.Cout + BN - 1) / BN : 1;
-    const int cls = UPF ? (int)blockIdx.y / ntn : 0;                 // parity class (px, py, pz) = bits 2, 1, 0
-    const int ntile = UPF ? (int)blockIdx.y % ntn : (int)blockIdx.y;
+    const int cls = UPF ? by / ntn : 0;                 // parity class (px, py, pz) = bits 2, 1, 0
+    const int ntile = UPF ? by % ntn : by;
 
     const int pv = row_perm(lane & 31);
     const int vyl = pv >> 3, vz = pv & 7;  // y inside the M-tile's 4-row patch, z
@@ -384,7 +406,7 @@ conv3d_k3_kernel(const ConvParams p)
     const int ncs = (p.C0 + p.C1) / KC;              // channel slices of the input
     const int nslices = DGF ? 8 * ncs : ncs;         // dgrad fold: (parity class, dz-channel slice) pairs
     const int G = nslices * TAPS;
-    const char* wtile = p.wp + (size_t)blockIdx.y * G * B_BYTES;   // UPF: [class][n-tile], else [n-tile]
+    const char* wtile = p.wp + (size_t)by * G * B_BYTES;   // UPF: [class][n-tile], else [n-tile]
     const int X2 = p.X >> 1, Y2 = p.Y >> 1, Z2 = p.Z >> 1;
 
     // global load of item `it` of this thread's share of the haloed tile of channel slice s.
@@ -1566,6 +1588,8 @@ int launch_conv(const ConvParams& p, int ntiles_n, hipStream_t st, int64_t* nblk
         return check_launch();
     }
     q.kpart = nullptr;
+    // more than two rounds of workgroups: below that the classes of a tile run side by side anyway
+    if ((VAR & CV_UPFOLD) != 0) q.xcd_pair = (nblk * ntiles_n * 8 > 2 * (int64_t)conv_ncu()) ? 4 : 0;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk, ((VAR & CV_UPFOLD) != 0 ? 8 : 1) * ntiles_n), dim3(CONV_THREADS), LDS, st, q);
     return check_launch();
 }

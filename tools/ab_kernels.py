@@ -81,6 +81,17 @@ if "upfold" in which:
 
         def chk():
             assert torch.equal(p1, p2), float((p1.float() - p2.float()).abs().max())
+        if hasattr(new, "mmr_conv_set_xcd_pair"):      # same library, class order per XCD off | on
+            def off():
+                new.mmr_conv_set_xcd_pair(0)
+                return call(new, p1)
+
+            for P in (2, 4, 8):
+                def on():
+                    new.mmr_conv_set_xcd_pair(P)
+                    return call(new, p2)
+                ab("upfold " + tag + f" (blockIdx.y = class | {P} classes per group of {P} XCDs)", off, on, check=chk, n=10)
+            new.mmr_conv_set_xcd_pair(2)
         ab("upfold " + tag, lambda: call(old, p1), lambda: call(new, p2), check=chk, n=10)
         for vn, vl in VARIANTS.items():
             if "uploop" in vn:
