@@ -108,4 +108,23 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// Tile of workgroup `bx` in pass `it` of a persistent grid of G workgroups over nt tiles, or -1.  Workgroups are dealt round-robin
+// over the 8 XCDs (bx & 7), each with its own L2; the plain walk `tile = it * G + bx` therefore puts NEIGHBOURING tiles, which
+// share their halo rows, on different XCDs and every halo read misses L2.  Here every XCD takes a contiguous run of the pass's
+// tiles (G % 8 == 0; otherwise the plain walk).  MMR_NO_XCD_TILES: the plain walk, for same-box A/B builds.
+__device__ __forceinline__ int xcd_tile(int bx, int G, int it, int nt)
+{
+    const int base = it * G;
+    const int cnt = nt - base < G ? nt - base : G;
+    if (cnt <= 0) return -1;
+#ifndef MMR_NO_XCD_TILES
+    if ((G & 7) == 0) {
+        const int x = bx & 7, k = bx >> 3, qd = cnt >> 3, rm = cnt & 7;
+        if (k >= qd + (x < rm ? 1 : 0)) return -1;
+        return base + (x < rm ? x * (qd + 1) : rm * (qd + 1) + (x - rm) * qd) + k;
+    }
+#endif
+    return bx < cnt ? base + bx : -1;
+}
+
 }  // namespace mmr

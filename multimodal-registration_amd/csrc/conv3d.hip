@@ -2241,8 +2241,9 @@ flow_head_march_kernel(const char* __restrict__ in, const float* __restrict__ w,
     const float bco1 = (OPT == 2 && bias) ? bias[co1] : 0.f;
     const int nsteps = Cin / 32;
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        int t = tile;
+    for (int it = 0; it * (int)gridDim.x < ntiles; ++it) {
+        int t = xcd_tile((int)blockIdx.x, (int)gridDim.x, it, ntiles);     // y / z neighbours of a segment on one XCD
+        if (t < 0) continue;
         const int tzi = t % ntz; t /= ntz;
         const int tyi = t % nty; t /= nty;
         const int seg = t % nseg;

@@ -2145,9 +2145,12 @@ thin_wgrad_x3_kernel(const float* __restrict__ dense, int Cd, const float* __res
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    int tile = blockIdx.x;
-    if (tile < ntiles) issue(tile);
-    for (; tile < ntiles; tile += gridDim.x) {
+    // passes of the persistent grid; every XCD walks a contiguous run of each pass's tiles (xcd_tile: neighbouring tiles share halo
+    // rows, and with the plain walk they sit on different XCDs)
+    int pass = 0, tile = xcd_tile((int)blockIdx.x, (int)gridDim.x, 0, ntiles), tile_next = -1;
+    if (tile >= 0) issue(tile);
+    for (; tile >= 0; tile = tile_next, ++pass) {
+        tile_next = xcd_tile((int)blockIdx.x, (int)gridDim.x, pass + 1, ntiles);
         // fp32 -> packed (hi, lo) cells in registers
         tw_u32x4 dh[4], dl[4];
 #pragma unroll
@@ -2190,7 +2193,7 @@ thin_wgrad_x3_kernel(const float* __restrict__ dense, int Cd, const float* __res
             *reinterpret_cast<tw_u32x4*>(o + 2 * TW_SPL) = w2h;  *reinterpret_cast<tw_u32x4*>(o + 2 * TW_SPL + TW_SHL) = w2l;
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
+        if (tile_next >= 0) issue(tile_next);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int row = wave * 4 + e * 2 + h;
@@ -2390,9 +2393,10 @@ flow_dgrad_x3_kernel(const float* __restrict__ dy, const float* __restrict__ w, 
 #pragma unroll
         for (int q = 0; q < 4; ++q) cs[n][q] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    int tile = blockIdx.x;
-    if (tile < ntiles) issue(tile);
-    for (; tile < ntiles; tile += gridDim.x) {
+    int pass = 0, tile = xcd_tile((int)blockIdx.x, (int)gridDim.x, 0, ntiles), tile_next = -1;     // (see thin_wgrad_x3_kernel)
+    if (tile >= 0) issue(tile);
+    for (; tile >= 0; tile = tile_next, ++pass) {
+        tile_next = xcd_tile((int)blockIdx.x, (int)gridDim.x, pass + 1, ntiles);
         int t = tile;
         const int tzi = t % ntz; t /= ntz;
         const int tyi = t % nty; t /= nty;
@@ -2422,7 +2426,7 @@ flow_dgrad_x3_kernel(const float* __restrict__ dy, const float* __restrict__ w, 
             *reinterpret_cast<tw_u32x4*>(o + 3 * FD_G_PLANE) = l1;
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
+        if (tile_next >= 0) issue(tile_next);
         float4 mk4[2][4];
         if (ymask) {
 #pragma unroll

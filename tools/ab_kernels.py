@@ -110,6 +110,8 @@ if "flow" in which:
     def chk():
         assert torch.equal(o1, o2), float((o1 - o2).abs().max())
     ab("flow head bf16, 160x160x192 x 256 (C2)", lambda: call(old, o1), lambda: call(new, o2), check=chk)
+    if "noxcd" in VARIANTS:
+        ab("  ... same sources, tile walk plain (-DMMR_NO_XCD_TILES) | XCD-contiguous", lambda: call(VARIANTS["noxcd"], o1), lambda: call(new, o2), check=chk)
     for vn, vl in VARIANTS.items():
         if vn.startswith("fh_"):
             ab(f"  ... variant {vn}", lambda: call(old, o1), lambda: call(vl, o2), check=chk)
@@ -139,6 +141,20 @@ if "thin" in which:
     def chk2():
         assert float((e1 - e2).abs().max() / e1.abs().max()) < 1e-6
     ab("first-layer weight gradient fp32x3 (thin_wgrad_x3), 160^3 x 64", lambda: call(old, e1), lambda: call(new, e2), check=chk2)
+    wfh = (torch.randn((3, 3, 3, 64, 3), generator=g) * 0.05).to(dev)
+    dx1, dx2 = torch.empty_like(x), torch.empty_like(x)
+    db1, db2 = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    ws3 = torch.empty(int(new.mmr_conv3d_k3_cout3_dgrad_masked_ws_bytes(1, *S, 64)) + 1024, dtype=torch.uint8, device=dev)
+    calld = lambda lib, dx, db: lib.mmr_conv3d_k3_cout3_dgrad_masked_f32x3(dflow.data_ptr(), wfh.data_ptr(), dx.data_ptr(), 1, *S, 64, x.data_ptr(), 0.2, db.data_ptr(), ws3.data_ptr(), 0, st())
+
+    def chk3():
+        assert torch.equal(dx1, dx2) and float((db1 - db2).abs().max() / db1.abs().max()) < 1e-5
+    ab("flow-head data gradient + mask + bias sums fp32x3 (flow_dgrad_x3), 160^3 x 64", lambda: calld(old, dx1, db1), lambda: calld(new, dx2, db2), check=chk3)
+    if "noxcd" in VARIANTS:
+        nx = VARIANTS["noxcd"]
+        call = lambda lib, d: lib.mmr_conv3d_k3_wgrad_f32x3(x.data_ptr(), 64, 0, None, 0, dflow.data_ptr(), d.data_ptr(), ws.data_ptr(), 1, *S, 3, 0, st())
+        ab("  ... thin_wgrad_x3: tile walk plain (-DMMR_NO_XCD_TILES) | XCD-contiguous", lambda: call(nx, d1), lambda: call(new, d2), check=chk)
+        ab("  ... flow_dgrad_x3: tile walk plain | XCD-contiguous", lambda: calld(nx, dx1, db1), lambda: calld(new, dx2, db2), check=chk3)
 if "compose" in which:
     for S in ((80, 80, 80), (80, 80, 96), (160, 160, 192)):
         vel = (torch.randn((1,) + S + (3,), generator=g) * 3).to(dev)
