@@ -70,26 +70,47 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_LIVE = {}   # host address -> [references, nbytes, device address] of the regions this module has pinned
+
+
 class Registered:
     """Context: the pages of a C-contiguous NumPy array pinned and mapped for the device; ``dev`` = device-side address.
-    ``ok`` is False when the runtime refuses (read-only mapping, already registered, ...) -- callers fall back to staging."""
+    ``ok`` is False when the runtime refuses (read-only mapping, already registered, ...) -- callers fall back to staging.
+
+    The same buffer may be asked for twice in one call (``predict([a, a])``): the runtime accepts a second registration of a
+    pointer it already holds, replaces its table entry and leaks the first pin (the second unregister then fails with "pointer
+    does not correspond to a registered memory region") -- so identical addresses are counted here and registered once."""
 
     def __init__(self, a):
-        self.a, self.ok, self.dev = a, False, None
+        self.a, self.ok, self.dev, self._key = a, False, None, None
 
     def __enter__(self):
+        key, nbytes = int(self.a.ctypes.data), int(self.a.nbytes)
+        live = _LIVE.get(key)
+        if live is not None:
+            if live[1] >= nbytes:
+                live[0] += 1
+                self.ok, self.dev, self._key = True, live[2], key
+            return self            # a longer region from the same address while a shorter one is pinned: staging
         d = ctypes.c_void_p()
-        rc = _lib.load().mmr_host_register(ctypes.c_void_p(self.a.ctypes.data), self.a.nbytes, ctypes.byref(d))
+        rc = _lib.load().mmr_host_register(ctypes.c_void_p(key), nbytes, ctypes.byref(d))
         self.ok = rc == 0 and bool(d.value)
         self.dev = d.value
+        if self.ok:
+            self._key = key
+            _LIVE[key] = [1, nbytes, d.value]
         return self
 
     def __exit__(self, *exc):
         if self.ok:
             self.ok = False
-            rc = _lib.load().mmr_host_unregister(ctypes.c_void_p(self.a.ctypes.data))
-            if rc != 0 and exc[0] is None:      # pages left pinned behind the caller's back: loud, not silent
-                _lib.check(rc, "mmr_host_unregister")
+            live = _LIVE[self._key]
+            live[0] -= 1
+            if live[0] == 0:
+                del _LIVE[self._key]
+                rc = _lib.load().mmr_host_unregister(ctypes.c_void_p(self._key))
+                if rc != 0 and exc[0] is None:      # pages left pinned behind the caller's back: loud, not silent
+                    _lib.check(rc, "mmr_host_unregister")
         return False
 
 

@@ -283,8 +283,9 @@ def test_predict_host_handover_every_input_kind_and_fallback(dev):
         for mode in ("register", "staging", "torch"):
             got = hostio.to_device_f32(a, dev, mode=mode).cpu()
             assert got.shape == want.shape and torch.equal(got, want), (name, mode)
-        pair = hostio.pair_to_device([a, a], dev)
+        pair = hostio.pair_to_device([a, a], dev)        # the SAME buffer twice: pinned once, counted twice, released once
         assert torch.equal(pair[0].cpu(), want) and torch.equal(pair[1].cpu(), want), name
+        assert not hostio._LIVE, name                    # nothing stays pinned behind the caller's back
     t = torch.randn((1, 16, 32, 16, 3), device=dev)
     for mode in ("register", "staging", "torch"):
         assert np.array_equal(hostio.to_host(t, mode=mode), t.cpu().numpy()), mode
@@ -296,6 +297,8 @@ def test_predict_host_handover_every_input_kind_and_fallback(dev):
     w[-2] = (np.random.default_rng(1).standard_normal(w[-2].shape) * 3e-2).astype(np.float32)
     m.set_weights(w)
     mov, fix = rng.random(shape), rng.random(shape)
+    same = m.predict([mov, mov])                         # moving = fixed, one array: the registration is shared, not doubled
+    assert not hostio._LIVE and np.isfinite(same[0]).all()
     keep = (hostio.MODE_IN, hostio.MODE_OUT)
     res = {}
     try:
