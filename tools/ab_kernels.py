@@ -99,6 +99,24 @@ if "upfold" in which:
             if "skip" in vn:    # timing-only builds (wrong results): bounds on what fewer A restages could buy
                 ab(f"  ... TIMING-ONLY {vn}", lambda: call(old, p1), lambda: call(vl, p2), check=None, n=10)
         del xl, p1, p2
+if "conv" in which:
+    # the plain 27-tap bf16 256 -> 256 conv of C2's top level (enc / dec layers at 160x160x192 are this kernel or its CINIT form)
+    S, C = (160, 160, 192), 256
+    x = (torch.randn((1,) + S + (C,), generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    wk = (torch.randn((27, C, C), generator=g) * 0.02).to(dev)
+    bias = torch.zeros(C, device=dev)
+    wp = torch.empty(int(new.mmr_conv3d_k3_packed_bytes(C, C, 1)), dtype=torch.uint8, device=dev)
+    assert new.mmr_conv3d_k3_pack(wk.data_ptr(), wp.data_ptr(), C, C, 1, 0, st()) == 0
+    o1, o2 = torch.empty((1,) + S + (C,), dtype=torch.bfloat16, device=dev), torch.empty((1,) + S + (C,), dtype=torch.bfloat16, device=dev)
+    call = lambda lib, o: lib.mmr_conv3d_k3_fwd(x.data_ptr(), C, 0, None, 0, wp.data_ptr(), bias.data_ptr(), o.data_ptr(), None, 1, *S, C, 1, 0.2, 1, 0, st())
+
+    def chk():
+        assert torch.equal(o1, o2)
+    ab("conv bf16 256 -> 256, 160x160x192 (C2 top level)", lambda: call(old, o1), lambda: call(new, o2), check=chk, n=5)
+    for vn in ("xo1", "xo2"):
+        if vn in VARIANTS:
+            ab(f"  ... tile order plain | variant {vn} (XCD-contiguous runs{' in 2x4x4 blocks' if vn == 'xo2' else ''})", lambda: call(new, o1), lambda: call(VARIANTS[vn], o2), check=chk, n=5)
+    del x, o1, o2
 if "flow" in which:
     S, C = (160, 160, 192), 256
     x = (torch.randn((1,) + S + (C,), generator=g) * 0.5).to(torch.bfloat16).to(dev)
