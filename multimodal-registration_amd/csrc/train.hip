@@ -1073,8 +1073,9 @@ wgrad_kernel(const WgradParams p)
     };
 
     float4 pa[A_IT], pb[B_IT];
-    int tile = blockIdx.x;
-    if (tile < p.ntiles) {
+    // passes of the persistent grid; every XCD walks a contiguous run of each pass's tiles (common.hpp: xcd_tile)
+    int pass = 0, nxt = -1, tile = xcd_tile((int)blockIdx.x, (int)gridDim.x, 0, p.ntiles);
+    if (tile >= 0) {
         int b, x0, y0, z0;
         tile_origin(tile, b, x0, y0, z0);
 #pragma unroll
@@ -1082,15 +1083,15 @@ wgrad_kernel(const WgradParams p)
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) pb[it] = load_b(b, x0, y0, z0, it);
     }
-    for (; tile < p.ntiles; tile += gridDim.x) {
+    for (; tile >= 0; tile = nxt, ++pass) {
         __syncthreads();  // everyone is done with the previous tile's LDS image
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) store_a(it, pa[it]);
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) store_b(it, pb[it]);
         __syncthreads();
-        const int nxt = tile + gridDim.x;
-        if (nxt < p.ntiles) {  // register prefetch of the next tile, hidden under this tile's MFMAs
+        nxt = xcd_tile((int)blockIdx.x, (int)gridDim.x, pass + 1, p.ntiles);
+        if (nxt >= 0) {  // register prefetch of the next tile, hidden under this tile's MFMAs
             int b, x0, y0, z0;
             tile_origin(nxt, b, x0, y0, z0);
 #pragma unroll
@@ -1432,12 +1433,12 @@ wgrad_x3_kernel(const WgradParams p)
     // next to 112 accumulator registers: it is what spilled.  An empty asm makes the thread index opaque per use, so
     // the arithmetic (a few hundred VALU per 45 k-cycle tile) is redone where it is needed and nothing stays live.
     auto opaque_tid = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t; };
-    int tile = blockIdx.x;
+    int pass = 0, nxt = -1, tile = xcd_tile((int)blockIdx.x, (int)gridDim.x, 0, p.ntiles);      // (see wgrad_kernel)
     if constexpr (FOLD) {
         // Four classes per workgroup and voxel tile: the x_low tile is staged once, then per class its dz sub-lattice tile and a
         // k-loop over the class's two accumulator tiles.  The next operand tile (dz of the next class, or x_low + dz of the next
         // voxel tile) is prefetched into registers under each k-loop.
-        if (tile < p.ntiles) {
+        if (tile >= 0) {
             const int tv = opaque_tid();
             int b, x0, y0, z0;
             tile_origin(tile, b, x0, y0, z0);
@@ -1446,12 +1447,12 @@ wgrad_x3_kernel(const WgradParams p)
 #pragma unroll
             for (int it = 0; it < B_IT; ++it) pz[it] = load_z(tv, b, x0, y0, z0, it, fcls0);
         }
-        for (; tile < p.ntiles; tile += gridDim.x) {
+        for (; tile >= 0; tile = nxt, ++pass) {
             int b, x0, y0, z0;
             tile_origin(tile, b, x0, y0, z0);
-            const int nxt = tile + gridDim.x;
+            nxt = xcd_tile((int)blockIdx.x, (int)gridDim.x, pass + 1, p.ntiles);
             int nb = 0, nx0 = 0, ny0 = 0, nz0 = 0;
-            if (nxt < p.ntiles) tile_origin(nxt, nb, nx0, ny0, nz0);
+            if (nxt >= 0) tile_origin(nxt, nb, nx0, ny0, nz0);
             __syncthreads();          // the previous tile's last k-loop is done with sX and sZ
             {
                 const int tv = opaque_tid();
@@ -1472,7 +1473,7 @@ wgrad_x3_kernel(const WgradParams p)
                     if constexpr (C + 1 < FNC) {
 #pragma unroll
                         for (int it = 0; it < B_IT; ++it) pz[it] = load_z(tv2, b, x0, y0, z0, it, fcls0 + C + 1);
-                    } else if (nxt < p.ntiles) {
+                    } else if (nxt >= 0) {
 #pragma unroll
                         for (int it = 0; it < A_IT; ++it) px[it] = load_x(tv2, nb, nx0, ny0, nz0, it);
 #pragma unroll
@@ -1501,7 +1502,7 @@ wgrad_x3_kernel(const WgradParams p)
             one_class(IC<0>{}); one_class(IC<1>{}); one_class(IC<2>{}); one_class(IC<3>{});
         }
     } else {
-    if (tile < p.ntiles) {
+    if (tile >= 0) {
         const int tv = opaque_tid();
         int b, x0, y0, z0;
         tile_origin(tile, b, x0, y0, z0);
@@ -1514,7 +1515,7 @@ wgrad_x3_kernel(const WgradParams p)
             for (int it = 0; it < B_IT; ++it) pz[it] = load_z(tv, b, x0, y0, z0, it);
         }
     }
-    for (; tile < p.ntiles; tile += gridDim.x) {
+    for (; tile >= 0; tile = nxt, ++pass) {
         if constexpr (STAMP) st_t = wstamp_now();
         __syncthreads();
         if constexpr (STAMP) { const unsigned long long t = wstamp_now(); st_acc[0] += t - st_t; st_t = t; }
@@ -1537,14 +1538,14 @@ wgrad_x3_kernel(const WgradParams p)
         for (int it = 0; it < B_IT; ++it) store_z(tv, it, convert_z(it, pz[it]));
         __syncthreads();
         if constexpr (STAMP) { const unsigned long long t = wstamp_now(); st_acc[1] += t - st_t; st_t = t; }
-        const int nxt = tile + gridDim.x;
+        nxt = xcd_tile((int)blockIdx.x, (int)gridDim.x, pass + 1, p.ntiles);
         // the next tile's loads go out in one burst in front of the k-loop (spread over its quarters they compete with the
         // transposing LDS reads for the VGPR write path: same 2.6 ms per launch)
         int nb = 0, nx0 = 0, ny0 = 0, nz0 = 0;
-        if (nxt < p.ntiles) tile_origin(nxt, nb, nx0, ny0, nz0);
+        if (nxt >= 0) tile_origin(nxt, nb, nx0, ny0, nz0);
         auto issue_group = [&](auto gc) {
             constexpr int GQ = decltype(gc)::value;          // 0, 1: X items; 2, 3: dZ items
-            if (nxt < p.ntiles) {
+            if (nxt >= 0) {
                 const int tv2 = opaque_tid();
                 if constexpr (GQ < 2 && PFX) {
                     constexpr int A0 = GQ == 0 ? 0 : (A_IT + 1) / 2, A1 = GQ == 0 ? (A_IT + 1) / 2 : A_IT;

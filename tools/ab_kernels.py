@@ -173,6 +173,20 @@ if "thin" in which:
         call = lambda lib, d: lib.mmr_conv3d_k3_wgrad_f32x3(x.data_ptr(), 64, 0, None, 0, dflow.data_ptr(), d.data_ptr(), ws.data_ptr(), 1, *S, 3, 0, st())
         ab("  ... thin_wgrad_x3: tile walk plain (-DMMR_NO_XCD_TILES) | XCD-contiguous", lambda: call(nx, d1), lambda: call(new, d2), check=chk)
         ab("  ... flow_dgrad_x3: tile walk plain | XCD-contiguous", lambda: calld(nx, dx1, db1), lambda: calld(new, dx2, db2), check=chk3)
+if "wgrad" in which:
+    S = (160, 160, 160)
+    x = torch.randn((1,) + S + (64,), generator=g).to(dev)
+    dz = torch.randn((1,) + S + (64,), generator=g).to(dev)
+    d1, d2 = torch.zeros((3, 3, 3, 64, 64), device=dev), torch.zeros((3, 3, 3, 64, 64), device=dev)
+    ws = torch.empty(int(new.mmr_conv3d_k3_wgrad_ws_bytes(1, *S, 64, 64)) + 1024, dtype=torch.uint8, device=dev)
+    call = lambda lib, d: lib.mmr_conv3d_k3_wgrad_f32x3(x.data_ptr(), 64, 0, None, 0, dz.data_ptr(), d.data_ptr(), ws.data_ptr(), 1, *S, 64, 0, st())
+
+    def chk():
+        assert float((d1 - d2).abs().max() / d1.abs().max()) < 1e-5
+    ab("weight gradient fp32x3 64 -> 64, 160^3 (wgrad_x3_kernel)", lambda: call(old, d1), lambda: call(new, d2), check=chk, n=10)
+    if "noxcd" in VARIANTS:
+        ab("  ... tile walk plain (-DMMR_NO_XCD_TILES) | XCD-contiguous", lambda: call(VARIANTS["noxcd"], d1), lambda: call(new, d2), check=chk, n=10)
+    del x, dz
 if "compose" in which:
     for S in ((80, 80, 80), (80, 80, 96), (160, 160, 192)):
         vel = (torch.randn((1,) + S + (3,), generator=g) * 3).to(dev)
