@@ -3,7 +3,7 @@ tools/ab/build_r04_lib.sh from git 09a1874), both loaded into ONE process throug
 (3 rounds of 20 launches each, HIP events) on the same tensors.  Boxes of the pool differ by 5 - 15 %; only alternated runs on one
 box rank two builds.
 
-    python tools/ab_kernels.py [flow] [thin] [ncc] [bending] [cin2]
+    python tools/ab_kernels.py [upfold] [conv] [flow] [thin] [wgrad] [compose] [ncc] [nccbwd] [bending] [cin2]
 """
 import ctypes
 import os
