@@ -253,6 +253,44 @@ def test_c5_ncc_and_bending_full_size(dev):
     assert abs(got - ref) < 2e-3 * ref, (got, ref)  # fp32 second differences of values up to ~330
 
 
+def test_c5_ncc_backward_full_size_windows_vs_float64(dev):
+    """BASELINE configs[4] as a LOSS at its own size: d(-mean cc) / dI, dJ at 256^3 from the two-pass backward (coefficient pass + one
+    box filter), checked against float64 autograd on CROPS.  The gradient at a voxel depends on the images within 8 voxels (every
+    9^3 window that contains it), so the oracle on a 72^3 crop is exact for the voxels 8 or more away from the crop's ARTIFICIAL
+    faces; faces that are faces of the volume carry the same zero padding in both.  Three crops: a corner (three real faces), the
+    centre, and the far corner; the mean's 1 / N is rescaled from the crop to the volume.  Plus exact linearity in gout and the
+    one-gradient form (three fields) against the two-gradient form (five fields)."""
+    import mmr
+    from oracle import grad_torch as G
+    S, C = (256, 256, 256), 72
+    g = torch.Generator(device="cpu").manual_seed(7)
+    I = torch.rand((1,) + S + (1,), generator=g)
+    J = 0.6 * I + 0.4 * torch.rand((1,) + S + (1,), generator=g)
+    Id, Jd = I.to(dev), J.to(dev)
+    dI, dJ = mmr.ops.ncc_loss_bwd(Id, Jd)
+    scale = float(dI.abs().max())
+    worst = 0.0
+    for o in ((0, 0, 0), (92, 92, 92), (S[0] - C, S[1] - C, S[2] - C)):
+        sl = tuple(slice(a, a + C) for a in o)
+        Ic = I[(slice(None),) + sl].double().requires_grad_(True)
+        Jc = J[(slice(None),) + sl].double().requires_grad_(True)
+        G.ncc_loss(Ic, Jc).sum().backward()
+        k = (C ** 3) / float(S[0] * S[1] * S[2])            # -mean over the crop -> -mean over the volume
+        keep = tuple(slice(0 if a == 0 else 8, C if a + C == n else C - 8) for a, n in zip(o, S))     # away from artificial faces
+        for got, ref in ((dI, Ic.grad), (dJ, Jc.grad)):
+            gw = got[(slice(None),) + sl][(slice(None),) + keep].cpu().double()
+            rw = ref[(slice(None),) + keep] * k
+            worst = max(worst, float((gw - rw).abs().max()) / scale)
+    print(f"NCC backward at 256^3: worst |HIP - float64| / max|grad| over three 72^3 crops = {worst:.2e}")
+    assert worst < 2e-5, worst
+    gout = torch.tensor([-2.5], device=dev)
+    sI, sJ = mmr.ops.ncc_loss_bwd(Id, Jd, gout)
+    assert torch.equal(sI, dI * -2.5) or float((sI - dI * -2.5).abs().max()) <= 2e-7 * scale * 2.5
+    oI, _ = mmr.ops.ncc_loss_bwd(Id, Jd, want=("I",))
+    _, oJ = mmr.ops.ncc_loss_bwd(Id, Jd, want=("J",))
+    assert float((oI - dI).abs().max()) <= 1e-6 * scale and float((oJ - dJ).abs().max()) <= 1e-6 * scale
+
+
 def test_c3_thin_backward_kernels_full_size(dev):
     """The fp32x3 thin-layer backward kernels at C3's size (160^3 x 64, 32 000 tiles over persistent workgroups): the
     flow-head / first-layer weight gradients and the flow-head data gradient against the exact-fp32 kernels (independent
