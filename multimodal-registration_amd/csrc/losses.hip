@@ -1427,9 +1427,10 @@ ncc_xgrad_kernel(const float* __restrict__ zy, const float* __restrict__ I, cons
 //     (2 (1, -4, 6, -4, 1) per axis; 4 / 16 (corners - 2 edge midpoints + 4 centre) per axis pair);
 //   * the others: the 21 masked second differences that touch an output, each recomputed from the LDS tile.
 constexpr int BB_TX = 4, BB_TY = 8, BB_TZ = 32;
-constexpr int BB_UX = BB_TX + 4, BB_UY = BB_TY + 4, BB_UZ = BB_TZ + 4;      // 8 x 12 x 36
-constexpr int BB_UN = BB_UX * BB_UY * BB_UZ;                                 // 3 456
-constexpr int BB_LDS = 3 * BB_UN * (int)sizeof(float);                       // 41 472 B
+constexpr int BB_UX = BB_TX + 4, BB_UY = BB_TY + 4, BB_UZ = BB_TZ + 4;      // 8 x 12 x 36 voxels with the halo
+constexpr int BB_PZ = 40;                                                    // z pitch of a row in LDS (see the lane map in the kernel)
+constexpr int BB_UN = BB_UX * BB_UY * BB_PZ;                                 // 3 840
+constexpr int BB_LDS = 3 * BB_UN * (int)sizeof(float);                       // 46 080 B: three workgroups per CU
 
 __global__ void __launch_bounds__(256, 3)
 bending_bwd_tiled_kernel(const float* __restrict__ u, const float* __restrict__ gout, float* __restrict__ du, int X, int Y, int Z,
@@ -1472,23 +1473,29 @@ bending_bwd_tiled_kernel(const float* __restrict__ u, const float* __restrict__ 
             const int hx = r / BB_UY, hy = r - hx * BB_UY;
             const int gx = x0 + hx - 2, gy = y0 + hy - 2;
             const bool in = zin && gx >= 0 && gx < X && gy >= 0 && gy < Y;
-            const int i = r * BB_UZ + zq;
+            const int i = r * BB_PZ + zq;
             su[i] = in ? ld[it].v[0] : 0.f;
             su[BB_UN + i] = in ? ld[it].v[1] : 0.f;
             su[2 * BB_UN + i] = in ? ld[it].v[2] : 0.f;
         }
     }
-    const int ty = tid >> 5, tz = tid & 31;
-    constexpr int SX = BB_UY * BB_UZ, SY = BB_UZ;          // strides of su in floats (z stride 1)
+    // Lane map: a wave = all 8 y rows x 8 z (wave w takes z 8 w .. 8 w + 7), not 2 rows x 32 z.  The path is then chosen per WAVE: in
+    // a tile at a z face of the volume (a quarter of all tiles at 256^3, tiles being 32 long in z) only the wave column that
+    // touches the face takes the masked path, the other three the 25-point stencil.  With the row pitch 40 the 32 lanes of a
+    // half-wave (4 rows x 8 z) hit banks 8 row + z: distinct.
+    const int wq = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ty = (tid >> 3) & 7, tz = wq * 8 + (tid & 7);
+    constexpr int SX = BB_UY * BB_PZ, SY = BB_PZ;          // strides of su in floats (z stride 1)
     float acc[BB_TX][3];
     __syncthreads();
-    const bool deep = x0 >= 2 && x0 + BB_TX <= X - 2 && y0 >= 2 && y0 + BB_TY <= Y - 2 && z0 >= 2 && z0 + BB_TZ <= Z - 2;
+    const int zw0 = z0 + wq * 8;                         // first z of this wave
+    const bool deep = x0 >= 2 && x0 + BB_TX <= X - 2 && y0 >= 2 && y0 + BB_TY <= Y - 2 && zw0 >= 2 && zw0 + 8 <= Z - 2;
     if (deep) {
         // x columns of the tile + halo at the 13 (y, z) offsets the stencil touches, read ONCE per channel for the thread's four
         // outputs (72 LDS reads issued together, then arithmetic; written per output hipcc interleaved 131 reads with 69 waits)
 #pragma unroll 1
         for (int k = 0; k < 3; ++k) {
-            const float* s = su + k * BB_UN + (ty + 2) * BB_UZ + (tz + 2);      // (hx = 0, y, z); output xi sits at hx = xi + 2
+            const float* s = su + k * BB_UN + (ty + 2) * BB_PZ + (tz + 2);      // (hx = 0, y, z); output xi sits at hx = xi + 2
             float c0[8], yp2[8], ym2[8], zp2[8], zm2[8], yp1[4], ym1[4], zp1[4], zm1[4], pp[4], pm[4], mp[4], mm[4];
 #pragma unroll
             for (int hx = 0; hx < 8; ++hx) {
@@ -1539,7 +1546,7 @@ bending_bwd_tiled_kernel(const float* __restrict__ u, const float* __restrict__ 
             };
 #pragma unroll 1
             for (int k = 0; k < 3; ++k) {
-                const float* s = su + k * BB_UN + ((xi + 2) * BB_UY + (ty + 2)) * BB_UZ + (tz + 2);
+                const float* s = su + k * BB_UN + ((xi + 2) * BB_UY + (ty + 2)) * BB_PZ + (tz + 2);
                 // masked pure second difference along stride a at centre offset c (in floats), factor m
                 auto daa = [&](int c, int a, float m) { return m * (s[c + a] - 2.f * s[c] + s[c - a]); };
                 auto dab = [&](int c, int a, int bq, float m) {
