@@ -49,6 +49,7 @@ class Staging:
     def __del__(self):
         try:
             if getattr(self, "ptr", None):
+                self.wait()          # no copy may still read the pages that are being released
                 self._buf = None
                 _lib.load().mmr_host_free(ctypes.c_void_p(self.ptr))
                 self.ptr = None
@@ -70,7 +71,79 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_SCRATCH = [None]
+
+
+def upload(a, device):
+    """C-contiguous NumPy array -> device tensor of the same dtype and shape, through ONE grow-only pinned scratch buffer and the
+    copy engine (weights, whole volumes that are not pinned in place).  A plain ``tensor.to(device)`` of pageable memory above
+    1 MB makes the runtime pin the CALLER's pages in place for the copy; this path never creates such a mapping."""
+    a = np.ascontiguousarray(a)
+    out = torch.empty(a.shape, dtype=torch.from_numpy(a.reshape(-1)[:0]).dtype, device=device)
+    if a.nbytes == 0:
+        return out
+    st = _SCRATCH[0]
+    if st is None or st.nbytes < a.nbytes:
+        _SCRATCH[0] = None            # (the old buffer waits for its last copy in __del__)
+        st = _SCRATCH[0] = Staging(max(a.nbytes, 1 << 24))
+    st.wait()
+    np.copyto(st.view(a.dtype, a.shape), a)
+    rc = _lib.load().mmr_memcpy_async(out.data_ptr(), ctypes.c_void_p(st.ptr), a.nbytes, 0, _stream())
+    _lib.check(rc, "mmr_memcpy_async")
+    st.event = torch.cuda.Event()
+    st.event.record()
+    st.event.synchronize()
+    return out
+
+
 _LIVE = {}   # host address -> [references, nbytes, device address] of the regions this module has pinned
+
+# Which caller buffers are pinned in place.  hipHostRegister makes a user-pointer mapping of whole PAGES.  A buffer that shares
+# pages with other heap data (anything glibc serves from an arena: small arrays, and mid-sized ones once the dynamic mmap threshold
+# has grown) drags that data's pages into the mapping, two buffers registered together can share a page, and the same pages come
+# back later as the source of somebody's pageable copy, which the runtime pins in place again.  Round 5 saw three GPU memory
+# faults inside plain torch host-to-device copies in test processes that had registered such small heap arrays before
+# (profiles/HISTORY.md).  Only buffers that certainly own their pages are registered: above glibc's largest mmap threshold
+# (32 MiB: always a mapping of their own; a 160 x 160 x 192 float64 volume is 39 MB), or allocated here page-aligned
+# (``exclusive_empty``).  Everything else goes through the pinned staging buffers.
+REGISTER_MIN_BYTES = (32 << 20) + 4096
+_PAGE = 4096
+_OWNED = set()   # addresses of exclusive_empty() arrays that are alive
+
+
+_POOL, _POOL_MAX_PER_SIZE = {}, 3   # size -> idle anonymous mappings (pages already faulted in: pinning them again takes microseconds)
+
+
+def _recycle(size, buf, addr):
+    lst = _POOL.setdefault(size, [])
+    if len(lst) < _POOL_MAX_PER_SIZE:
+        lst.append(buf)
+    else:
+        _OWNED.discard(addr)       # (not buf.close(): the dying array still holds its buffer export here; dropping the last
+                                   # reference unmaps it a moment later)
+
+
+def exclusive_empty(shape, dtype=np.float32):
+    """``np.empty`` on an anonymous mapping of its own (page-aligned, whole pages): safe to pin.  The mapping goes back to a small
+    pool when the last array that views it dies -- a FRESH mapping costs its page faults when it is pinned (3 ms for predict's
+    27 MB of outputs), a recycled one does not; np.empty is fast for the same reason (glibc hands out used heap), which is
+    exactly why its pages cannot be trusted to be the array's own."""
+    import mmap
+    import weakref
+    count = int(np.prod(shape))
+    size = max((count * np.dtype(dtype).itemsize + _PAGE - 1) // _PAGE * _PAGE, _PAGE)
+    lst = _POOL.get(size)
+    buf = lst.pop() if lst else mmap.mmap(-1, size)
+    root = np.frombuffer(buf, dtype=dtype, count=count)      # every view handed out keeps `root` alive through .base
+    _OWNED.add(int(root.ctypes.data))
+    weakref.finalize(root, _recycle, size, buf, int(root.ctypes.data))
+    return root.reshape(shape)
+
+
+def registrable(a):
+    """True if ``a`` certainly owns the pages it lies on (see REGISTER_MIN_BYTES)."""
+    return a.nbytes >= REGISTER_MIN_BYTES or int(a.ctypes.data) in _OWNED
+
 
 
 class Registered:
@@ -86,6 +159,8 @@ class Registered:
 
     def __enter__(self):
         key, nbytes = int(self.a.ctypes.data), int(self.a.nbytes)
+        if not registrable(self.a):
+            return self            # ok stays False: staging
         live = _LIVE.get(key)
         if live is not None:
             if live[1] >= nbytes:
@@ -171,7 +246,7 @@ def to_host(t, tag=0, mode=None):
     if np_dtype is None:
         return t.cpu().numpy()
     if mode == "register":
-        out = np.empty(tuple(t.shape), dtype=np_dtype)
+        out = exclusive_empty(tuple(t.shape), np_dtype)
         if out.ctypes.data % 16 == 0:
             with Registered(out) as r:
                 if r.ok:
@@ -261,7 +336,7 @@ def many_to_host(tensors, mode=None):
     if mode == "register":
         # the result arrays themselves are pinned for the duration of the copy: the copy kernels write them over PCIe, no
         # staging buffer and no host-side copy
-        outs = [np.empty(tuple(t.shape), np.float32) for t in tensors]
+        outs = [exclusive_empty(tuple(t.shape), np.float32) for t in tensors]      # pages of their own: safe to pin
         regs = [Registered(o).__enter__() for o in outs]
         try:
             if all(r.ok and r.dev % 16 == 0 for r in regs):

@@ -34,7 +34,9 @@ def _ring_slot(shape, dtype):
 def to_device(a, dtype=torch.float32, device="cuda"):
     """NumPy / tensor -> contiguous device tensor (Keras casts float64 inputs to fp32)."""
     if isinstance(a, torch.Tensor):
-        return a.to(device=device, dtype=dtype).contiguous()
+        if a.is_cuda or torch.device(device).type != "cuda" or a.numel() * a.element_size() <= _ASYNC_H2D_BYTES:
+            return a.to(device=device, dtype=dtype).contiguous()
+        a = a.detach().to(dtype).contiguous().numpy()      # large host tensor: the pinned-scratch path below
     a = np.asarray(a)
     if torch.device(device).type == "cuda" and a.size * np.dtype(a.dtype).itemsize <= _ASYNC_H2D_BYTES and a.size > 0:
         # per-step inputs (label maps, generator draws, blur kernels, ...): a pageable copy would block the host until the
@@ -50,6 +52,11 @@ def to_device(a, dtype=torch.float32, device="cuda"):
         slot[1] = ev
         return out
     t = torch.from_numpy(np.ascontiguousarray(a))
+    if torch.device(device).type == "cuda" and t.numel() > 0:
+        # large host arrays (weights): cast on the host, then pinned scratch + copy engine (hostio.upload) -- a pageable
+        # tensor.to(device) above 1 MB has the runtime pin the caller's own pages in place
+        from . import hostio
+        return hostio.upload(t.to(dtype).numpy(), device)
     return t.to(device=device, dtype=dtype).contiguous()
 
 

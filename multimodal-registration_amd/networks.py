@@ -506,11 +506,13 @@ class VxmDense:
                 a = a.astype(np.float64)
             prep.append(np.ascontiguousarray(a))
         half = tuple(s // self.svf_resolution for s in self.inshape)
-        out_m = np.empty((n,) + self.inshape + (1,), np.float32)
-        out_f = np.empty((n,) + half + (3,), np.float32)
+        out_m = hostio.exclusive_empty((n,) + self.inshape + (1,), np.float32)      # mappings of their own: safe to pin
+        out_f = hostio.exclusive_empty((n,) + half + (3,), np.float32)
+        # inputs are pinned in place only when they certainly own their pages (hostio.registrable: large volumes); otherwise each
+        # pair is memcpy'd into pinned staging memory on the host while the previous pair is in the forward
         regs = [hostio.Registered(a).__enter__() for a in (prep[0], prep[1], out_m, out_f)]
         try:
-            if not all(r.ok for r in regs) or any(r.dev % 16 for r in regs):
+            if not (regs[2].ok and regs[3].ok):
                 res = [self.predict([prep[0][b:b + 1], prep[1][b:b + 1]]) for b in range(n)]
                 return [np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res])]
             main = torch.cuda.current_stream(dev)
@@ -531,9 +533,19 @@ class VxmDense:
                 with torch.cuda.stream(cs):
                     for k in range(2):
                         raw = torch.empty((1,) + prep[k].shape[1:], dtype=tdt[code[k]], device=dev)
-                        srcp = prep[k].ctypes.data + b * per[k] * prep[k].itemsize
+                        st = None
+                        if regs[k].ok:
+                            srcp = prep[k].ctypes.data + b * per[k] * prep[k].itemsize
+                        else:
+                            st = hostio.staging(per[k] * prep[k].itemsize, ("ovl", k, b & 1))
+                            st.wait()                                    # the copy that last read this buffer (pair b - 2) is done
+                            np.copyto(st.view(prep[k].dtype, (1,) + prep[k].shape[1:]), prep[k][b:b + 1])
+                            srcp = st.ptr
                         _lib.check(lib.mmr_memcpy_async(raw.data_ptr(), ctypes.c_void_p(srcp), per[k] * prep[k].itemsize, 0, cs.cuda_stream),
                                    "mmr_memcpy_async")
+                        if st is not None:
+                            st.event = torch.cuda.Event()
+                            st.event.record(cs)
                         if code[k] == hostio.F32:
                             d = raw
                         else:

@@ -283,9 +283,20 @@ def test_predict_host_handover_every_input_kind_and_fallback(dev):
         for mode in ("register", "staging", "torch"):
             got = hostio.to_device_f32(a, dev, mode=mode).cpu()
             assert got.shape == want.shape and torch.equal(got, want), (name, mode)
-        pair = hostio.pair_to_device([a, a], dev)        # the SAME buffer twice: pinned once, counted twice, released once
+        pair = hostio.pair_to_device([a, a], dev)
         assert torch.equal(pair[0].cpu(), want) and torch.equal(pair[1].cpu(), want), name
-        assert not hostio._LIVE, name                    # nothing stays pinned behind the caller's back
+        assert hostio.LAST["in"]["mode"] == "staging" and not hostio._LIVE, name       # small heap arrays are never pinned in place
+        # the same values on pages of their own (what a > 32 MiB volume is by construction): pinned in place.  The SAME buffer twice
+        # is pinned once, counted twice, released once -- nothing stays pinned behind the caller's back
+        ac = np.ascontiguousarray(a)
+        if ac.dtype in hostio._CODES:
+            ex = hostio.exclusive_empty(ac.shape, ac.dtype)
+            ex[...] = ac
+            assert hostio.registrable(ex) and not hostio.registrable(ac)
+            assert torch.equal(hostio.to_device_f32(ex, dev, mode="register").cpu(), want), name
+            pair = hostio.pair_to_device([ex, ex], dev)
+            assert torch.equal(pair[0].cpu(), want) and torch.equal(pair[1].cpu(), want), name
+            assert hostio.LAST["in"]["mode"] == "register" and not hostio._LIVE, name
     t = torch.randn((1, 16, 32, 16, 3), device=dev)
     for mode in ("register", "staging", "torch"):
         assert np.array_equal(hostio.to_host(t, mode=mode), t.cpu().numpy()), mode
@@ -297,8 +308,13 @@ def test_predict_host_handover_every_input_kind_and_fallback(dev):
     w[-2] = (np.random.default_rng(1).standard_normal(w[-2].shape) * 3e-2).astype(np.float32)
     m.set_weights(w)
     mov, fix = rng.random(shape), rng.random(shape)
-    same = m.predict([mov, mov])                         # moving = fixed, one array: the registration is shared, not doubled
+    same = m.predict([mov, mov])                         # moving = fixed, one array
     assert not hostio._LIVE and np.isfinite(same[0]).all()
+    big = hostio.exclusive_empty(shape, np.float64)      # stands in for a volume above the mmap threshold: pinned in place
+    big[...] = mov
+    same2 = m.predict([big, big])                        # one registration shared by both inputs, not doubled
+    assert hostio.LAST["in"]["mode"] == "register" and not hostio._LIVE
+    assert np.array_equal(same2[0], same[0]) and np.array_equal(same2[1], same[1])
     keep = (hostio.MODE_IN, hostio.MODE_OUT)
     res = {}
     try:
@@ -309,8 +325,9 @@ def test_predict_host_handover_every_input_kind_and_fallback(dev):
         hostio.MODE_IN, hostio.MODE_OUT = keep
     for k in ("staging", "torch"):
         assert np.array_equal(res[k][0], res["register"][0]) and np.array_equal(res[k][1], res["register"][1]), k
-    # a registration the runtime refuses (the same pages pinned twice) falls back to the staging copy, silently and correctly
-    with hostio.Registered(mov) as r:
+    # a buffer that is already pinned by the caller is shared (counted), not pinned a second time
+    with hostio.Registered(big) as r:
         assert r.ok
-        again = m.predict([mov, fix])
-    assert np.array_equal(again[0], res["register"][0])
+        again = m.predict([big, big])
+        assert hostio._LIVE[int(big.ctypes.data)][0] == 1      # predict's references are gone, the caller's is still there
+    assert np.array_equal(again[0], same[0]) and not hostio._LIVE
