@@ -1,11 +1,12 @@
 """NumPy <-> HBM hand-over of whole volumes for ``predict`` (3d_reg.py:310-314: ``get_fdata()`` float64 arrays in, NumPy out).
 
 The host does no arithmetic on the way in: the caller's float64 (or fp32 / uint8 / int16) buffer is either pinned in place
-for the duration of the call (``mmr_host_register``) or memcpy'd into CPU-cached pinned staging memory
-(``mmr_host_alloc(cached=1)``), and ``mmr_cast_to_f32`` -- a kernel reading that host memory over PCIe -- converts to fp32
-straight into HBM.  Outputs come back through ``mmr_copy_to_host`` into cached pinned staging memory and are copied into a
-fresh NumPy array.  (Round 4's path converted on the host into torch's coherent pinned buffers: 1 GB/s on some boxes of the
-pool, predict() at 2x the forward.)
+for the duration of the call (``mmr_host_register`` -- only buffers that certainly own their pages, see REGISTER_MIN_BYTES) or
+memcpy'd into CPU-cached pinned staging memory (``mmr_host_alloc(cached=1)``), and ``mmr_cast_to_f32`` -- a kernel reading that
+host memory over PCIe -- converts to fp32 straight into HBM.  Outputs are written by ``mmr_copy_to_host`` straight into result
+arrays that live on pooled anonymous mappings of their own (``exclusive_empty``), pinned for the duration of the copy; the
+staging mode copies through pinned staging memory into a fresh array instead.  (Round 4's path converted on the host into
+torch's coherent pinned buffers: 1 GB/s on some boxes of the pool, predict() at 2x the forward.)
 
 ``MODE_IN`` / ``MODE_OUT`` select the strategy; tools/time_hostio.py measures all of them on the box at hand.
 """
