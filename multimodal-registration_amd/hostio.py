@@ -115,9 +115,12 @@ _OWNED = set()   # addresses of exclusive_empty() arrays that are alive
 _POOL, _POOL_MAX_PER_SIZE = {}, 3   # size -> idle anonymous mappings (pages already faulted in: pinning them again takes microseconds)
 
 
+_POOL_MAX_BYTES = 1 << 30
+
+
 def _recycle(size, buf, addr):
     lst = _POOL.setdefault(size, [])
-    if len(lst) < _POOL_MAX_PER_SIZE:
+    if len(lst) < _POOL_MAX_PER_SIZE and sum(k * len(v) for k, v in _POOL.items()) + size <= _POOL_MAX_BYTES:
         lst.append(buf)
     else:
         _OWNED.discard(addr)       # (not buf.close(): the dying array still holds its buffer export here; dropping the last

@@ -39,3 +39,4 @@ def test_exclusive_empty_is_page_aligned_pooled_and_never_shared():
     del many
     gc.collect()
     assert all(len(v) <= hostio._POOL_MAX_PER_SIZE for v in hostio._POOL.values())
+    assert sum(k * len(v) for k, v in hostio._POOL.items()) <= hostio._POOL_MAX_BYTES
