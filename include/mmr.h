@@ -225,7 +225,8 @@ int mmr_ncc_fwd_ticket_f32(const float* I, const float* J, float* out, void* ws,
 int mmr_bending_fwd_ticket_f32(const float* flow, float* out, void* ws, unsigned* ticket,
                                int B, int X, int Y, int Z, float scale, int accumulate, void* stream);
 /* Backward of the two losses (SURVEY 8b families ncc_bwd / bending_bwd): gradients of out[b] scaled by gout[b]
- * (gout == NULL: 1).  NCC: dI and/or dJ [B,X,Y,Z] (either may be NULL); workspace mmr_ncc_bwd_ws_bytes. */
+ * (gout == NULL: 1).  NCC: dI and/or dJ [B,X,Y,Z] (either may be NULL); workspace mmr_ncc_bwd_ws_bytes (five volumes for the
+ * two-launch form, Z % 4 == 0 and Z <= 256: coefficient pass + one 9^3 box filter; 19 volumes for the separable form otherwise). */
 int64_t mmr_ncc_bwd_ws_bytes(int B, int X, int Y, int Z);
 int mmr_ncc_bwd_f32(const float* I, const float* J, const float* gout, float* dI, float* dJ, void* ws,
                     int B, int X, int Y, int Z, int win, float eps, int ncc_form, void* stream);
